@@ -1,0 +1,159 @@
+/*
+ * lvllm_hip.h — C-ABI of the MI355X (gfx950) paged-attention decode path.
+ *
+ * This is the drop-in boundary: every entry point replaces one operator the
+ * reference registers in csrc/torch_bindings.cpp (namespaces `_C`,
+ * `_C_cache_ops`, `_C_cuda_utils`) and declares in csrc/ops.h / csrc/cache.h.
+ * Signatures are plain pointers + sizes + a HIP stream; no torch types.  The
+ * torch-side binding (light-vllm_amd/csrc/torch_bindings.cpp) unpacks tensors
+ * and forwards here, so `torch.ops._C.*` keeps the reference schemas verbatim.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless a comment says "host";
+ *   - strides are in ELEMENTS, as the reference passes them to its kernels;
+ *   - `stream` is a hipStream_t (void* here so that C callers need no HIP
+ *     headers); kernels are launched asynchronously on it and never
+ *     synchronise (graph-capture safe);
+ *   - return value: 0 on success, non-zero on a rejected argument or HIP
+ *     error; lvllm_last_error() returns the message (thread-local).  The torch
+ *     binding turns non-zero into RuntimeError, which is what TORCH_CHECK does
+ *     in the reference (csrc/attention/attention_kernels.cu:767,804).
+ */
+#ifndef LVLLM_HIP_H_
+#define LVLLM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of activations (scalar_t in the reference) */
+enum lvllm_dtype {
+  LVLLM_F32 = 0,
+  LVLLM_F16 = 1,
+  LVLLM_BF16 = 2,
+};
+
+/* kv_cache_dtype strings of the reference ("auto" | "fp8" | "fp8_e4m3"),
+ * csrc/quantization/fp8/amd/quant_utils.cuh:547-573 */
+enum lvllm_kv_dtype {
+  LVLLM_KV_AUTO = 0,
+  LVLLM_KV_FP8_E4M3 = 1,
+};
+
+const char* lvllm_last_error(void);
+/* build identification: "lvllm_hip gfx950 <abi version>" */
+const char* lvllm_version(void);
+
+/* ---- attention (replaces csrc/ops.h:8-27, attention_kernels.cu:808-997) --- */
+
+/* paged_attention_v1: out[num_seqs,num_heads,head_size] (contiguous).
+ * query rows may be strided (q_stride = query.stride(0)).
+ * key_cache  [num_blocks, num_kv_heads, head_size/x, block_size, x], x=16/sizeof(cache elt)
+ * value_cache[num_blocks, num_kv_heads, head_size, block_size]
+ * block_tables int32 [num_seqs, max_num_blocks_per_seq]; seq_lens int32 [num_seqs].
+ * alibi_slopes: float32 [num_heads] or NULL.
+ * blocksparse_*: as csrc/ops.h:13-16; vert_stride <= 1 means dense. */
+int lvllm_paged_attention_v1(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int dtype, int kv_dtype, float k_scale, float v_scale, int tp_rank,
+    int blocksparse_local_blocks, int blocksparse_vert_stride,
+    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream);
+
+/* paged_attention_v2: as v1, split in partitions of 512 tokens
+ * (attention_kernels.cu:850) and merged by a reduce pass.  Scratch, caller
+ * allocated exactly as light_vllm/decoding/backends/attention/ops/paged_attn.py:156-166:
+ *   tmp_out   [num_seqs,num_heads,max_num_partitions,head_size] (dtype)
+ *   exp_sums, max_logits float32 [num_seqs,num_heads,max_num_partitions]
+ * On return they hold the per-partition values the reference's kernel writes
+ * (attention_kernels.cu:349-357,483-495). */
+int lvllm_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, void* stream);
+
+/* ---- cache ops (replaces csrc/cache.h:9-33, cache_kernels.cu) ------------- */
+
+/* reshape_and_cache: scatter key/value [num_tokens,num_heads,head_size]
+ * (row strides key_stride/value_stride) into the paged caches via
+ * slot_mapping int64 [num_tokens]; slot < 0 is skipped (cache_kernels.cu:164-203). */
+int lvllm_reshape_and_cache(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, void* stream);
+
+/* reshape_and_cache_flash: cache layout [num_blocks, block_size, num_heads,
+ * head_size], block_stride = key_cache.stride(0) (cache_kernels.cu:206-247). */
+int lvllm_reshape_and_cache_flash(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int64_t block_stride, int64_t key_stride,
+    int64_t value_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream);
+
+/* copy_blocks: for every layer and every (src,dst) pair copy one block in the
+ * key cache and in the value cache (cache_kernels.cu:67-148).
+ * key_cache_ptrs/value_cache_ptrs: DEVICE arrays of num_layers device
+ * pointers; block_mapping: DEVICE int64 [num_pairs,2]; block_bytes = bytes of
+ * one block of one layer's K (== V) cache. */
+int lvllm_copy_blocks(const void* const* key_cache_ptrs,
+                      const void* const* value_cache_ptrs,
+                      const int64_t* block_mapping, int num_layers,
+                      int num_pairs, int64_t block_bytes, void* stream);
+
+/* swap_blocks: block_mapping is a HOST int64 [num_pairs,2] array
+ * (cache_kernels.cu:40-43).  src/dst may each be device or (pinned) host
+ * memory: src_is_device / dst_is_device say which (cache_kernels.cu:26-39).
+ * Runs of consecutive (src,dst) block numbers are merged into one copy. */
+int lvllm_swap_blocks(const void* src, void* dst, const int64_t* block_mapping,
+                      int num_pairs, int64_t block_bytes, int src_is_device,
+                      int dst_is_device, void* stream);
+
+/* ---- norm / rope / activation (csrc/ops.h:29-45) -------------------------- */
+
+/* rms_norm: out = T(x * rsqrt(mean(x^2)+eps)) * w   (layernorm_kernels.cu:21-45) */
+int lvllm_rms_norm(void* out, const void* input, const void* weight,
+                   float epsilon, int num_tokens, int hidden_size, int dtype,
+                   void* stream);
+
+/* fused_add_rms_norm: residual = T(input+residual); input = norm(residual)*w
+ * in place (layernorm_kernels.cu:200-287). */
+int lvllm_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                             float epsilon, int num_tokens, int hidden_size,
+                             int dtype, void* stream);
+
+/* rotary_embedding: in-place on query [num_tokens, num_heads*head_size] and
+ * key [num_tokens, num_kv_heads*head_size] with row strides query_stride /
+ * key_stride; cos_sin_cache [max_position, rot_dim] = [cos | sin] in dtype;
+ * positions int64 [num_tokens] (pos_encoding_kernels.cu:10-92). */
+int lvllm_rotary_embedding(const int64_t* positions, void* query, void* key,
+                           int num_tokens, int num_heads, int num_kv_heads,
+                           int head_size, int rot_dim, int64_t query_stride,
+                           int64_t key_stride, const void* cos_sin_cache,
+                           int is_neox, int dtype, void* stream);
+
+/* silu_and_mul: out[t,i] = T(silu(x[t,i])) * x[t,d+i]  (activation_kernels.cu:9-30) */
+int lvllm_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
+                       int dtype, void* stream);
+
+/* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
+int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
+int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVLLM_HIP_H_ */

@@ -1,0 +1,286 @@
+// C-ABI entry points of paged_attention_v1 / paged_attention_v2 (see attention_mfma.h for
+// the MI355X kernel design), the v2 partition reduce and the generic kernel
+// for fp32 caches.  Reference: csrc/attention/attention_kernels.cu:86-997.
+#include <float.h>
+
+#include "attention_params.h"
+#include "common.h"
+
+namespace lvllm {
+
+// defined in attention_bf16.hip / attention_f16.hip (one translation unit per
+// element type keeps the instantiation ladder compiling in parallel)
+template <typename T>
+int launch_mfma_hs(const AttnParams& p, int head_size, int block_size, int num_seqs,
+                   int num_parts, int max_tokens_per_wg, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// Generic kernel: any element type (fp32 included), any head size, any block
+// size.  One workgroup (256 threads) per (query head, sequence, partition),
+// logits in LDS, same math as above without MFMA.  It serves fp32 caches
+// and shapes the MFMA kernel is not instantiated for.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParams p,
+                                                                 const int head_size,
+                                                                 const int block_size,
+                                                                 const int chunk_tokens) {
+  using S = typename T::store_t;
+  constexpr int X = 16 / sizeof(S);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* logits = reinterpret_cast<float*>(smem_raw);  // [chunk_tokens]
+  float* qs = logits + chunk_tokens;                   // [head_size]
+  __shared__ float red[16];
+
+  const int head = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+  const int G = p.num_heads / p.num_kv_heads;
+  const int kvh = head / G;
+  const int seq_len = p.seq_lens[seq];
+  const int t0 = p.partitioned ? part * kPartitionSize : 0;
+  if (p.partitioned && t0 >= seq_len) return;
+  const int t1 = p.partitioned ? min(seq_len, t0 + kPartitionSize) : seq_len;
+  const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
+  const S* kc = (const S*)p.k_cache + (int64_t)kvh * p.kv_head_stride;
+  const S* vc = (const S*)p.v_cache + (int64_t)kvh * p.kv_head_stride;
+  const float alibi = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+
+  const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)head * head_size;
+  for (int d = threadIdx.x; d < head_size; d += blockDim.x) qs[d] = T::to_float(qrow[d]);
+  __syncthreads();
+
+  // The context is walked in chunks of chunk_tokens logits (online softmax
+  // across chunks) so LDS use does not grow with the sequence length.
+  float m_run = -FLT_MAX, l_run = 0.f;
+  // each thread owns output elements d = threadIdx.x, threadIdx.x + 256, ... (head_size <= 512)
+  float o0 = 0.f, o1 = 0.f;
+  for (int cs = t0; cs < t1; cs += chunk_tokens) {
+    const int ce = min(t1, cs + chunk_tokens);
+    float m_loc = -FLT_MAX;
+    for (int tok = cs + threadIdx.x; tok < ce; tok += blockDim.x) {
+      const int64_t bn = block_table[tok / block_size];
+      const int off = tok % block_size;
+      const S* kb = kc + bn * p.kv_block_stride + off * X;
+      float dot = 0.f;
+      for (int d = 0; d < head_size; ++d)
+        dot += qs[d] * T::to_float(kb[(d / X) * block_size * X + (d % X)]);
+      float x = dot * p.scale;
+      x += (alibi != 0.f) ? alibi * (float)(tok - seq_len + 1) : 0.f;
+      logits[tok - cs] = x;
+      m_loc = fmaxf(m_loc, x);
+    }
+    m_loc = wave_max(m_loc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m_loc;
+    __syncthreads();
+    float m_new = m_run;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m_new = fmaxf(m_new, red[w]);
+    __syncthreads();
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    for (int i = threadIdx.x; i < ce - cs; i += blockDim.x) {
+      const float e = __expf(logits[i] - m_new);
+      // probabilities are rounded to T before P.V (attention_kernels.cu:398-400)
+      logits[i] = T::to_float(T::from_float(e));
+      psum += e;
+    }
+    psum = block_sum(psum, red);
+    l_run = l_run * alpha + psum;
+    o0 *= alpha;
+    o1 *= alpha;
+    __syncthreads();
+    for (int tok = cs; tok < ce; ++tok) {
+      const int64_t bn = block_table[tok / block_size];
+      const int off = tok % block_size;
+      const S* vb = vc + bn * p.kv_block_stride + off;
+      const float pr = logits[tok - cs];
+      const int d0 = threadIdx.x, d1 = threadIdx.x + 256;
+      if (d0 < head_size) o0 += pr * T::to_float(vb[(int64_t)d0 * block_size]);
+      if (d1 < head_size) o1 += pr * T::to_float(vb[(int64_t)d1 * block_size]);
+    }
+    __syncthreads();
+  }
+  const int P = p.partitioned ? p.max_num_partitions : 1;
+  const float inv = __fdividef(1.f, l_run + 1e-6f);
+  const int64_t row = ((int64_t)seq * p.num_heads + head) * P + (p.partitioned ? part : 0);
+  const int d0 = threadIdx.x, d1 = threadIdx.x + 256;
+  if (d0 < head_size) reinterpret_cast<S*>(p.out)[row * head_size + d0] = T::from_float(o0 * inv);
+  if (d1 < head_size) reinterpret_cast<S*>(p.out)[row * head_size + d1] = T::from_float(o1 * inv);
+  if (p.partitioned && threadIdx.x == 0) {
+    p.max_logits[row] = m_run;
+    p.exp_sums[row] = l_run;
+  }
+}
+
+template <typename T>
+__global__ void paged_attn_v2_reduce_generic_kernel(typename T::store_t* __restrict__ out,
+                                                    const float* __restrict__ exp_sums,
+                                                    const float* __restrict__ max_logits,
+                                                    const typename T::store_t* __restrict__ tmp_out,
+                                                    const int32_t* __restrict__ seq_lens,
+                                                    const int max_num_partitions,
+                                                    const int num_rows, const int num_heads,
+                                                    const int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= num_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int seq_len = seq_lens[row / num_heads];
+  const int np = (seq_len + kPartitionSize - 1) / kPartitionSize;
+  typename T::store_t* o = out + (int64_t)row * D;
+  const typename T::store_t* tmp = tmp_out + (int64_t)row * max_num_partitions * D;
+  if (np == 1) {
+    for (int d = lane; d < D; d += 64) o[d] = tmp[d];
+    return;
+  }
+  const float* ml = max_logits + (int64_t)row * max_num_partitions;
+  const float* es = exp_sums + (int64_t)row * max_num_partitions;
+  float M = -FLT_MAX;
+  for (int j = 0; j < np; ++j) M = fmaxf(M, ml[j]);
+  float gsum = 0.f;
+  for (int j = 0; j < np; ++j) gsum += es[j] * expf(ml[j] - M);
+  const float inv = __fdividef(1.0f, gsum + 1e-6f);
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < np; ++j)
+      acc += T::to_float(tmp[(int64_t)j * D + d]) * (es[j] * expf(ml[j] - M)) * inv;
+    o[d] = T::from_float(acc);
+  }
+}
+
+static bool mfma_head_size(int d) {
+  return d == 64 || d == 80 || d == 96 || d == 112 || d == 120 || d == 128 || d == 192 ||
+         d == 256;
+}
+
+template <typename T>
+static int launch_generic(const AttnParams& p, int head_size, int block_size, int num_seqs,
+                          int num_parts, hipStream_t stream) {
+  LV_CHECK(head_size <= 512, "Unsupported head size: " + std::to_string(head_size));
+  const int chunk = 2048;
+  const size_t smem = (size_t)(chunk + head_size) * sizeof(float);
+  hipLaunchKernelGGL((paged_attn_generic_kernel<T>), dim3(p.num_heads, num_seqs, num_parts),
+                     dim3(256), smem, stream, p, head_size, block_size, chunk);
+  return 0;
+}
+
+static int check_common(int num_seqs, int num_heads, int head_size, int num_kv_heads,
+                        int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+                        int blocksparse_vert_stride) {
+  LV_CHECK(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+           "num_heads must be a positive multiple of num_kv_heads");
+  LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO,
+           "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
+  LV_CHECK(k_scale == 1.0f && v_scale == 1.0f, "k_scale/v_scale must be 1.0 with kv_cache_dtype 'auto'");
+  LV_CHECK(blocksparse_vert_stride <= 1, "block-sparse attention is not built in this round");
+  LV_CHECK(block_size == 8 || block_size == 16 || block_size == 32,
+           "Unsupported block size: " + std::to_string(block_size));
+  LV_CHECK(mfma_head_size(head_size), "Unsupported head size: " + std::to_string(head_size));
+  return 0;
+}
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+extern "C" int lvllm_paged_attention_v1(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int dtype, int kv_dtype, float k_scale, float v_scale, int tp_rank,
+    int blocksparse_local_blocks, int blocksparse_vert_stride,
+    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+  (void)tp_rank; (void)blocksparse_local_blocks; (void)blocksparse_block_size;
+  (void)blocksparse_head_sliding_step;
+  if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
+                            kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
+    return rc;
+  if (num_seqs == 0) return 0;
+  AttnParams p{};
+  p.out = out; p.exp_sums = nullptr; p.max_logits = nullptr;
+  p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = 1;
+  p.partitioned = 0; p.scale = scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
+                      (q_stride * 2) % 16 == 0 && (kv_block_stride * 2) % 16 == 0 &&
+                      (kv_head_stride * 2) % 16 == 0 && block_size >= 16;
+  int rc = 0;
+  if (dtype == LVLLM_BF16 && vec_ok)
+    rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, 1, max_seq_len, s);
+  else if (dtype == LVLLM_F16 && vec_ok)
+    rc = launch_mfma_hs<F16>(p, head_size, block_size, num_seqs, 1, max_seq_len, s);
+  else {
+    LV_DISPATCH_DTYPE(dtype, rc = launch_generic<scalar_t>(p, head_size, block_size, num_seqs, 1, s));
+  }
+  if (rc) return rc;
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, void* stream) {
+  (void)tp_rank; (void)blocksparse_local_blocks; (void)blocksparse_block_size;
+  (void)blocksparse_head_sliding_step;
+  if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
+                            kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
+    return rc;
+  LV_CHECK(max_num_partitions >= 1 &&
+               (int64_t)max_num_partitions * kPartitionSize >= (int64_t)max_seq_len,
+           "exp_sums.size(-1) must be >= ceil(max_seq_len / 512)");
+  if (num_seqs == 0) return 0;
+  AttnParams p{};
+  p.out = tmp_out; p.exp_sums = exp_sums; p.max_logits = max_logits;
+  p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = max_num_partitions;
+  p.partitioned = 1; p.scale = scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
+                      (q_stride * 2) % 16 == 0 && (kv_block_stride * 2) % 16 == 0 &&
+                      (kv_head_stride * 2) % 16 == 0 && block_size >= 16;
+  // partitions that can hold tokens: ceil(max_seq_len/512) (grid z of the reference)
+  int num_parts = (max_seq_len + kPartitionSize - 1) / kPartitionSize;
+  if (num_parts < 1) num_parts = 1;
+  const int tokens_per_wg = max_seq_len < kPartitionSize ? max_seq_len : kPartitionSize;
+  int rc = 0;
+  if (dtype == LVLLM_BF16 && vec_ok)
+    rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, num_parts, tokens_per_wg, s);
+  else if (dtype == LVLLM_F16 && vec_ok)
+    rc = launch_mfma_hs<F16>(p, head_size, block_size, num_seqs, num_parts, tokens_per_wg, s);
+  else {
+    LV_DISPATCH_DTYPE(dtype, rc = launch_generic<scalar_t>(p, head_size, block_size, num_seqs, num_parts, s));
+  }
+  if (rc) return rc;
+  LV_LAUNCH_CHECK();
+
+  const int num_rows = num_seqs * num_heads;
+  const int waves_per_block = 4;
+  const int grid = (num_rows + waves_per_block - 1) / waves_per_block;
+#define LV_REDUCE(T_)                                                                              \
+  hipLaunchKernelGGL((paged_attn_v2_reduce_generic_kernel<T_>), dim3(grid), dim3(waves_per_block * 64), \
+                     0, s, (typename T_::store_t*)out, exp_sums, max_logits,                        \
+                     (const typename T_::store_t*)tmp_out, seq_lens, max_num_partitions, num_rows,  \
+                     num_heads, head_size)
+  if (dtype == LVLLM_BF16) LV_REDUCE(BF16);
+  else if (dtype == LVLLM_F16) LV_REDUCE(F16);
+  else LV_REDUCE(F32);
+#undef LV_REDUCE
+  LV_LAUNCH_CHECK();
+  return 0;
+}

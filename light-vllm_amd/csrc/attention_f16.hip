@@ -1,0 +1,6 @@
+// Instantiates the MFMA paged-attention ladder for f16 (see attention_mfma.h).
+#include "attention_mfma.h"
+
+namespace lvllm {
+template int launch_mfma_hs<F16>(const AttnParams&, int, int, int, int, int, hipStream_t);
+}  // namespace lvllm

@@ -1,0 +1,378 @@
+// Paged-attention decode for MI355X (gfx950 / CDNA4): paged_attention_v1, paged_attention_v2
+// and the v2 partition reduce.
+//
+// WHAT (reference semantics, csrc/attention/attention_kernels.cu:86-496, 564-669):
+//   for every (sequence, query head): softmax(scale * q.K^T (+ALiBi)) . V over the
+//   sequence's KV blocks, addressed through block_tables; fp32 logits/softmax/
+//   accumulation; the softmax normaliser is 1/(sum + 1e-6); v2 does this per
+//   512-token partition, stores (max_logit, exp_sum, normalised partial out)
+//   per partition and merges them in a second pass.
+//
+// HOW (MI355X-first, not the reference's launch shape):
+//   * one workgroup per (kv head, sequence, partition) serves ALL query heads
+//     of the GQA group (up to 16) from a single read of the K/V blocks -- the
+//     reference launches one workgroup per *query* head and re-reads every KV
+//     block H/KVH times.
+//   * the paged K layout [D/8][BS][8] *is* the A-operand fragment layout of
+//     v_mfma_f32_16x16x32_{bf16,f16} with rows = tokens: lane (g = lane>>4,
+//     c = lane&15) needs K[token c][d = 32j + 8g .. +7], which is the 16-byte
+//     chunk (d8 = 4j + g, token c) of the block.  Four fully coalesced
+//     dwordx4 wave loads (1 KiB each) fetch a 16-token K tile straight into
+//     MFMA operand registers; nothing is staged through LDS.
+//   * S = K.Q^T lands with lane (g, c) holding tokens 4g..4g+3 of head c.  The
+//     P.V product uses the same token->k-slot permutation on both operands
+//     (k-slot 8g + e  <->  tile e>>2, token 4g + (e&3)), so the probabilities
+//     never move between lanes: V is fetched as 8-byte pieces
+//     V[d][4g..4g+3] (each wave load covers 512 contiguous bytes per tile).
+//   * online softmax per wave (running max / sum, fp32), waves of a workgroup
+//     own interleaved 32-token pairs and are merged once through LDS.
+//   * two register sets per wave: the loads of pair i+1 are in flight while
+//     pair i is multiplied (32 KiB per wave, >= 128 KiB per CU outstanding).
+//
+// Rounding: q.k products are exact bf16 x bf16 in fp32 accumulation; exp is
+// __expf; probabilities are rounded to T before P.V as in the reference
+// (attention_kernels.cu:398-400) -- here un-normalised exp values, the
+// normaliser 1/(sum+1e-6) is applied in fp32 at the end.
+#pragma once
+#include <float.h>
+
+#include "attention_params.h"
+#include "common.h"
+
+namespace lvllm {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// S = K.Q^T : 16 tokens x 16 heads, contraction over 32 head-dim elements
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma_qk(u32x4_t a, u32x4_t b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma_qk<BF16>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma_qk<F16>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// O^T += V^T.P^T : 16 head-dim rows x 16 heads, contraction over 16 tokens
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma_pv(u32x2_t a, u32x2_t b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma_pv<BF16>(u32x2_t a, u32x2_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a),
+                                                   __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma_pv<F16>(u32x2_t a, u32x2_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a),
+                                               __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)T::from_float(lo) | ((uint32_t)T::from_float(hi) << 16);
+}
+
+// gfx9-family raw buffer descriptor word 3 (32-bit data format, no swizzle)
+constexpr int kSrdFlags = 0x00020000;
+
+// ---------------------------------------------------------------------------
+// The kernel.  Unit of work = one 16-token tile of one kv head:
+//   K tile  : NS  x buffer_load_dwordx4 per lane (1 KiB per wave instruction)
+//   V tile  : NDT x buffer_load_dwordx2 per lane (512 B per wave instruction)
+// Tiles of a partition are dealt round-robin to the NWAVES waves; each wave
+// keeps NBUF tiles in flight.  All tile loads go through a per-tile buffer
+// descriptor whose size is 0 for tiles past the end of the context: such
+// loads fetch nothing and return zeros, so the loop body has no branches and
+// the compiler's vmcnt waits stay exact (the next tiles remain in flight
+// while one tile is multiplied).
+// ---------------------------------------------------------------------------
+template <typename T, int D, int BS, int NWAVES, int NBUF>
+__global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const AttnParams p) {
+  using S = typename T::store_t;
+  static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
+  static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
+  static_assert(NBUF == 2 || NBUF == 3, "register sets per wave");
+  constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
+  constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
+  constexpr int DPAD = NDT * 16;
+  constexpr int kHeadBytes = D * BS * 2;  // one kv head's K (or V) bytes inside a block
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 15) >> 4;
+  const int kvh = blockIdx.x / HG;
+  const int hg = blockIdx.x - kvh * HG;
+  const int head0 = kvh * G + hg * 16;
+  const int nh = min(16, G - hg * 16);
+  const int nh_lds = min(16, G);
+  const int seq = blockIdx.y;
+  const int part = blockIdx.z;
+  const int seq_len = p.seq_lens[seq];
+
+  const int t0 = p.partitioned ? part * kPartitionSize : 0;
+  if (p.partitioned && t0 >= seq_len) return;  // attention_kernels.cu:116-119
+  const int t1 = p.partitioned ? min(seq_len, t0 + kPartitionSize) : seq_len;
+  const int ntiles = (t1 - t0 + 15) >> 4;
+  const int tile0 = t0 >> 4;
+  // tiles of this wave: lt = wave + j * NWAVES, j = 0 .. nmy-1
+  const int nmy = ntiles > wave ? (ntiles - wave + NWAVES - 1) / NWAVES : 0;
+
+  const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
+  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const int64_t bsb = p.kv_block_stride * 2;
+
+  // per-lane byte offsets inside a (block, kv head) region
+  const int koff = (g * BS + c) * 16;      // K chunk (d8 = g (+4j), token c)
+  const int voff = (c * BS + 4 * g) * 2;   // V piece (row c (+16t), tokens 4g..4g+3)
+
+  // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
+  u32x4_t qf[NS];
+  {
+    const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + c) * D;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int d8 = 4 * j + g;
+      qf[j] = u32x4_t{0, 0, 0, 0};
+      if (c < nh && d8 * 8 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d8 * 8);
+    }
+  }
+  const float alibi = (p.alibi_slopes != nullptr && c < nh) ? p.alibi_slopes[head0 + c] : 0.f;
+
+  // Physical block number of this wave's j-th tile.  The index is wave-uniform, so
+  // this is a scalar load; callers request it one rotation before it is needed.
+  auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
+    const int lt = min(wave + j * NWAVES, ntiles - 1);  // clamp: stay inside the table row
+    return (ntiles > 0) ? block_table[((tile0 + lt) << 4) / BS] : 0;
+  };
+
+  // running softmax state of this wave: column c of lanes (g, c) is head head0 + c
+  float m_run = -FLT_MAX;
+  float l_run = 0.f;  // per-lane partial sum over its own tokens
+  f32x4_t acc[NDT];
+#pragma unroll
+  for (int t = 0; t < NDT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto load_tile = [&](u32x4_t (&k)[NS], u32x2_t (&v)[NDT], const int j, const int bn32)
+                       __attribute__((always_inline)) {
+    const int lt = wave + j * NWAVES;
+    const bool valid = j < nmy;
+    const int64_t bn = bn32;
+    const int tok_base = (tile0 + lt) << 4;
+    const int off = (BS == 32) ? (tok_base & 16) : 0;  // second half of a 32-token block
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    // chunks with d8 >= D/8 and rows with d >= D fall outside kHeadBytes -> zeros
+#pragma unroll
+    for (int jj = 0; jj < NS; ++jj)
+      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, 0);
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
+  };
+
+  // One tile: S = K.Q^T (NS MFMAs), online softmax, O^T += V^T.P^T (NDT MFMAs).
+  auto compute_tile = [&](const u32x4_t (&k)[NS], const u32x2_t (&v)[NDT], const int j)
+                          __attribute__((always_inline)) {
+    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < NS; ++jj) s = mfma_qk<T>(k[jj], qf[jj], s);
+    // lane (g, c): logits of tokens tok0 .. tok0+3 for head c
+    const int tok0 = ((tile0 + wave + j * NWAVES) << 4) + 4 * g;
+    float x[4];
+    float m_loc = -FLT_MAX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = s[r] * p.scale;
+      y += (alibi != 0.f) ? alibi * (float)(tok0 + r - seq_len + 1) : 0.f;
+      y = (tok0 + r < t1) ? y : -FLT_MAX;  // masked / out-of-context tokens
+      x[r] = y;
+      m_loc = fmaxf(m_loc, y);
+    }
+    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16));
+    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32));
+    const float m_new = fmaxf(m_run, m_loc);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x[r] = (tok0 + r < t1) ? __expf(x[r] - m_new) : 0.f;
+      psum += x[r];
+    }
+    l_run = l_run * alpha + psum;
+    u32x2_t pb;  // B operand: P[token 4g + r][head c], rounded to T (attention_kernels.cu:398-400)
+    pb.x = pack2<T>(x[0], x[1]);
+    pb.y = pack2<T>(x[2], x[3]);
+    // V of tokens beyond the context may hold anything (NaN included): zero it,
+    // as the reference does for the last block (attention_kernels.cu:420-430).
+    uint32_t mx = 0xffffffffu, my = 0xffffffffu;
+    if (tok0 + 0 >= t1) mx &= 0xffff0000u;
+    if (tok0 + 1 >= t1) mx &= 0x0000ffffu;
+    if (tok0 + 2 >= t1) my &= 0xffff0000u;
+    if (tok0 + 3 >= t1) my &= 0x0000ffffu;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      acc[t] *= alpha;
+      u32x2_t va;
+      va.x = v[t].x & mx;
+      va.y = v[t].y & my;
+      acc[t] = mfma_pv<T>(va, pb, acc[t]);  // rows: d = 16t + (lane&15); cols: head
+    }
+  };
+
+  // ---- main loop: NBUF register sets rotate; NBUF-1 tiles stay in flight ----
+  {
+    u32x4_t k0[NS], k1[NS], k2[NS];
+    u32x2_t v0[NDT], v1[NDT], v2[NDT];
+    int bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
+    load_tile(k0, v0, 0, bn0);
+    bn0 = block_number(3);
+    if constexpr (NBUF == 3) {
+      load_tile(k1, v1, 1, bn1);
+      bn1 = block_number(4);
+      for (int j = 0; j < nmy; j += 3) {
+        load_tile(k2, v2, j + 2, bn2);
+        bn2 = block_number(j + 5);
+        compute_tile(k0, v0, j);
+        load_tile(k0, v0, j + 3, bn0);
+        bn0 = block_number(j + 6);
+        compute_tile(k1, v1, j + 1);
+        load_tile(k1, v1, j + 4, bn1);
+        bn1 = block_number(j + 7);
+        compute_tile(k2, v2, j + 2);
+      }
+    } else {
+      (void)bn2;
+      for (int j = 0; j < nmy; j += 2) {
+        load_tile(k1, v1, j + 1, bn1);
+        bn1 = block_number(j + 3);
+        compute_tile(k0, v0, j);
+        load_tile(k0, v0, j + 2, bn0);
+        bn0 = block_number(j + 4);
+        compute_tile(k1, v1, j + 1);
+      }
+    }
+  }
+
+  // ---- merge the waves of the workgroup -------------------------------------
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+
+  float* sm_m = reinterpret_cast<float*>(smem_raw);  // [NWAVES][16]
+  float* sm_l = sm_m + NWAVES * 16;                  // [NWAVES][16]
+  float* sm_acc = sm_l + NWAVES * 16;                // [NWAVES][nh_lds][DPAD]
+  if (g == 0) {
+    sm_m[wave * 16 + c] = m_run;
+    sm_l[wave * 16 + c] = l_run;
+  }
+  if (c < nh) {
+    float* dst = sm_acc + ((int64_t)(wave * nh_lds + c)) * DPAD + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+      *reinterpret_cast<f32x4_t*>(dst + 16 * t) = acc[t];  // acc[t][r]: d = 16t + 4g + r
+  }
+  __syncthreads();
+
+  const int P = p.partitioned ? p.max_num_partitions : 1;
+  for (int idx = threadIdx.x; idx < nh * D; idx += NWAVES * 64) {
+    const int h = idx / D, d = idx - h * D;
+    float M = -FLT_MAX;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) M = fmaxf(M, sm_m[w * 16 + h]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+      const float f = __expf(sm_m[w * 16 + h] - M);
+      L += sm_l[w * 16 + h] * f;
+      o += sm_acc[(w * nh_lds + h) * DPAD + d] * f;
+    }
+    o *= __fdividef(1.f, L + 1e-6f);
+    const int64_t row = ((int64_t)seq * p.num_heads + head0 + h) * P + (p.partitioned ? part : 0);
+    reinterpret_cast<S*>(p.out)[row * D + d] = T::from_float(o);
+    if (p.partitioned && d == 0) {
+      p.max_logits[row] = M;
+      p.exp_sums[row] = L;
+    }
+  }
+}
+
+// ---- host side: instantiation ladder (head size x block size x waves) ----
+#ifndef LVLLM_ATTN_NBUF
+#define LVLLM_ATTN_NBUF 3
+#endif
+
+template <typename T, int D, int BS, int NWAVES>
+static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStream_t stream) {
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 15) / 16;
+  const int nh_lds = G < 16 ? G : 16;
+  constexpr int DPAD = ((D + 15) / 16) * 16;
+  const size_t smem = (size_t)NWAVES * 16 * 2 * sizeof(float) +
+                      (size_t)NWAVES * nh_lds * DPAD * sizeof(float);
+  auto kern = paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+  hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64),
+                     smem, stream, p);
+}
+
+template <typename T, int D, int BS>
+static void launch_mfma_waves(const AttnParams& p, int num_seqs, int num_parts,
+                              int max_tokens_per_wg, hipStream_t stream) {
+  // 16-token tiles per workgroup decide how many waves can be kept busy
+  const int tiles = (max_tokens_per_wg + 15) / 16;
+  const int G = p.num_heads / p.num_kv_heads;
+  const bool lds8_ok =
+      (size_t)8 * (G < 16 ? G : 16) * (((D + 15) / 16) * 16) * 4 + 1024 <= 160 * 1024;
+  if (tiles >= 64 && lds8_ok)
+    launch_mfma<T, D, BS, 8>(p, num_seqs, num_parts, stream);
+  else
+    launch_mfma<T, D, BS, 4>(p, num_seqs, num_parts, stream);
+}
+
+template <typename T, int D>
+static int launch_mfma_bs(const AttnParams& p, int block_size, int num_seqs, int num_parts,
+                          int max_tokens_per_wg, hipStream_t stream) {
+  switch (block_size) {
+    case 16: launch_mfma_waves<T, D, 16>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
+    case 32: launch_mfma_waves<T, D, 32>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
+    default: LV_CHECK(false, "Unsupported block size: " + std::to_string(block_size));
+  }
+  return 0;
+}
+
+// block sizes the MFMA kernel covers (8-token blocks go to the generic kernel)
+inline bool mfma_block_size(int bs) { return bs == 16 || bs == 32; }
+
+template <typename T>
+int launch_mfma_hs(const AttnParams& p, int head_size, int block_size, int num_seqs,
+                   int num_parts, int max_tokens_per_wg, hipStream_t stream) {
+  switch (head_size) {
+#define LV_HS(D_) \
+  case D_: return launch_mfma_bs<T, D_>(p, block_size, num_seqs, num_parts, max_tokens_per_wg, stream);
+    LV_HS(64) LV_HS(80) LV_HS(96) LV_HS(112) LV_HS(120) LV_HS(128) LV_HS(192) LV_HS(256)
+#undef LV_HS
+    default: LV_CHECK(false, "Unsupported head size: " + std::to_string(head_size));
+  }
+  return 0;
+}
+
+}  // namespace lvllm

@@ -1,0 +1,246 @@
+// KV-cache block operations for gfx950: reshape_and_cache, reshape_and_cache_flash,
+// copy_blocks, swap_blocks.  Pure byte movement, bit-exact by construction.
+//
+// Semantics follow the reference kernels (index formulas only):
+//   reshape_and_cache        csrc/cache_kernels.cu:152-204
+//   reshape_and_cache_flash  csrc/cache_kernels.cu:206-247
+//   copy_blocks              csrc/cache_kernels.cu:67-148
+//   swap_blocks              csrc/cache_kernels.cu:24-63
+// The launch shapes are not the reference's: work is cut into 16-byte chunks so
+// that every global access is a dwordx4 wherever the layout allows it, and
+// copy_blocks takes device pointer tables so it never synchronises the host.
+#include "common.h"
+
+namespace lvllm {
+
+// One thread per x-element chunk of one (token, head): K chunk is contiguous
+// in both the source row and the paged layout [.., D/x, BS, x]; V elements of
+// the chunk go to x different rows of [.., D, BS].
+template <typename store_t, int X>
+__global__ void reshape_and_cache_kernel(
+    const store_t* __restrict__ key, const store_t* __restrict__ value,
+    store_t* __restrict__ key_cache, store_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, const int64_t num_chunks,
+    const int chunks_per_head, const int num_heads, const int head_size,
+    const int block_size, const int64_t key_stride, const int64_t value_stride,
+    const bool vec_ok) {
+  using vec_t = uint4;
+  static_assert(sizeof(store_t) * X == 16, "chunk must be 16 bytes");
+  const int chunks_per_token = chunks_per_head * num_heads;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < num_chunks; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t token = idx / chunks_per_token;
+    const int rem = (int)(idx - token * chunks_per_token);
+    const int64_t slot = slot_mapping[token];
+    if (slot < 0) continue;  // padding token
+    const int head = rem / chunks_per_head;
+    const int x_idx = rem - head * chunks_per_head;
+    const int64_t block_idx = slot / block_size;
+    const int64_t block_off = slot % block_size;
+
+    const store_t* ksrc = key + token * key_stride + head * head_size + x_idx * X;
+    const store_t* vsrc = value + token * value_stride + head * head_size + x_idx * X;
+    store_t* kdst = key_cache +
+                    ((block_idx * num_heads + head) * chunks_per_head + x_idx) *
+                        (int64_t)block_size * X +
+                    block_off * X;
+    store_t* vdst = value_cache +
+                    ((block_idx * num_heads + head) * head_size + x_idx * X) *
+                        (int64_t)block_size +
+                    block_off;
+    store_t kv[X], vv[X];
+    if (vec_ok) {
+      *reinterpret_cast<vec_t*>(kv) = *reinterpret_cast<const vec_t*>(ksrc);
+      *reinterpret_cast<vec_t*>(vv) = *reinterpret_cast<const vec_t*>(vsrc);
+      *reinterpret_cast<vec_t*>(kdst) = *reinterpret_cast<const vec_t*>(kv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < X; ++i) {
+        kv[i] = ksrc[i];
+        vv[i] = vsrc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < X; ++i) kdst[i] = kv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < X; ++i) vdst[(int64_t)i * block_size] = vv[i];
+  }
+}
+
+// Flash layout [NB, BS, H, D]: both K and V rows are contiguous per token.
+template <typename store_t, int X>
+__global__ void reshape_and_cache_flash_kernel(
+    const store_t* __restrict__ key, const store_t* __restrict__ value,
+    store_t* __restrict__ key_cache, store_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, const int64_t num_chunks,
+    const int chunks_per_token, const int row_elems, const int block_size,
+    const int64_t block_stride, const int64_t key_stride,
+    const int64_t value_stride, const bool vec_ok) {
+  using vec_t = uint4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < num_chunks; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t token = idx / chunks_per_token;
+    const int c = (int)(idx - token * chunks_per_token);
+    const int64_t slot = slot_mapping[token];
+    if (slot < 0) continue;
+    const int64_t block_idx = slot / block_size;
+    const int64_t block_off = slot % block_size;
+    const int64_t dst = block_idx * block_stride + block_off * row_elems + (int64_t)c * X;
+    const store_t* ksrc = key + token * key_stride + (int64_t)c * X;
+    const store_t* vsrc = value + token * value_stride + (int64_t)c * X;
+    if (vec_ok) {
+      *reinterpret_cast<vec_t*>(key_cache + dst) = *reinterpret_cast<const vec_t*>(ksrc);
+      *reinterpret_cast<vec_t*>(value_cache + dst) = *reinterpret_cast<const vec_t*>(vsrc);
+    } else {
+      const int n = min(X, row_elems - c * X);
+      for (int i = 0; i < n; ++i) {
+        key_cache[dst + i] = ksrc[i];
+        value_cache[dst + i] = vsrc[i];
+      }
+    }
+  }
+}
+
+// grid (layer, pair, 2 = K|V).  16-byte chunks, fully coalesced.
+__global__ void copy_blocks_kernel(const void* const* __restrict__ key_cache_ptrs,
+                                   const void* const* __restrict__ value_cache_ptrs,
+                                   const int64_t* __restrict__ block_mapping,
+                                   const int64_t block_bytes) {
+  const int layer = blockIdx.x, pair = blockIdx.y;
+  char* base = (char*)(blockIdx.z == 0 ? key_cache_ptrs[layer] : value_cache_ptrs[layer]);
+  const int64_t src = block_mapping[2 * pair], dst = block_mapping[2 * pair + 1];
+  const char* s = base + src * block_bytes;
+  char* d = base + dst * block_bytes;
+  if ((block_bytes & 15) == 0 && (((uintptr_t)base) & 15) == 0) {
+    const int64_t n = block_bytes >> 4;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < block_bytes; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+extern "C" int lvllm_reshape_and_cache(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, void* stream) {
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO, "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
+  (void)k_scale; (void)v_scale;
+  if (num_tokens == 0) return 0;
+  const int esize = dtype == LVLLM_F32 ? 4 : 2;
+  LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
+  LV_CHECK(x == 16 / esize, "key_cache.size(4) must be 16/sizeof(element)");
+  LV_CHECK(head_size % x == 0, "head_size must be a multiple of x");
+  const int chunks_per_head = head_size / x;
+  const int64_t num_chunks = (int64_t)num_tokens * num_heads * chunks_per_head;
+  const bool vec_ok = aligned16(key) && aligned16(value) && aligned16(key_cache) &&
+                      (key_stride * esize) % 16 == 0 && (value_stride * esize) % 16 == 0;
+  const int threads = 256;
+  const int64_t want = (num_chunks + threads - 1) / threads;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (esize == 2) {
+    hipLaunchKernelGGL((reshape_and_cache_kernel<uint16_t, 8>), dim3(grid), dim3(threads), 0, s,
+                       (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
+                       (uint16_t*)value_cache, slot_mapping, num_chunks, chunks_per_head,
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok);
+  } else {
+    hipLaunchKernelGGL((reshape_and_cache_kernel<float, 4>), dim3(grid), dim3(threads), 0, s,
+                       (const float*)key, (const float*)value, (float*)key_cache,
+                       (float*)value_cache, slot_mapping, num_chunks, chunks_per_head,
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok);
+  }
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_reshape_and_cache_flash(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int64_t block_stride, int64_t key_stride,
+    int64_t value_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream) {
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO, "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
+  (void)k_scale; (void)v_scale;
+  if (num_tokens == 0) return 0;
+  LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
+  const int esize = dtype == LVLLM_F32 ? 4 : 2;
+  const int X = 16 / esize;
+  const int row_elems = num_heads * head_size;
+  const int chunks_per_token = (row_elems + X - 1) / X;
+  const int64_t num_chunks = (int64_t)num_tokens * chunks_per_token;
+  const bool vec_ok = row_elems % X == 0 && aligned16(key) && aligned16(value) &&
+                      aligned16(key_cache) && aligned16(value_cache) &&
+                      (key_stride * esize) % 16 == 0 && (value_stride * esize) % 16 == 0 &&
+                      (block_stride * esize) % 16 == 0;
+  const int threads = 256;
+  const int64_t want = (num_chunks + threads - 1) / threads;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (esize == 2) {
+    hipLaunchKernelGGL((reshape_and_cache_flash_kernel<uint16_t, 8>), dim3(grid), dim3(threads), 0, s,
+                       (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
+                       (uint16_t*)value_cache, slot_mapping, num_chunks, chunks_per_token,
+                       row_elems, block_size, block_stride, key_stride, value_stride, vec_ok);
+  } else {
+    hipLaunchKernelGGL((reshape_and_cache_flash_kernel<float, 4>), dim3(grid), dim3(threads), 0, s,
+                       (const float*)key, (const float*)value, (float*)key_cache,
+                       (float*)value_cache, slot_mapping, num_chunks, chunks_per_token,
+                       row_elems, block_size, block_stride, key_stride, value_stride, vec_ok);
+  }
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_copy_blocks(const void* const* key_cache_ptrs,
+                                 const void* const* value_cache_ptrs,
+                                 const int64_t* block_mapping, int num_layers,
+                                 int num_pairs, int64_t block_bytes, void* stream) {
+  if (num_layers == 0 || num_pairs == 0) return 0;
+  LV_CHECK(block_bytes > 0, "block_bytes must be positive");
+  LV_CHECK(num_pairs <= 65535, "more than 65535 pairs in one call");
+  const int64_t chunks = (block_bytes + 15) / 16;
+  const int threads = (int)(chunks >= 1024 ? 1024 : ((chunks + 63) / 64) * 64);
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(num_layers, num_pairs, 2), dim3(threads), 0,
+                     (hipStream_t)stream, key_cache_ptrs, value_cache_ptrs, block_mapping,
+                     block_bytes);
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* block_mapping,
+                                 int num_pairs, int64_t block_bytes, int src_is_device,
+                                 int dst_is_device, void* stream) {
+  LV_CHECK(src_is_device || dst_is_device, "Invalid device combination");
+  hipMemcpyKind kind = src_is_device && dst_is_device ? hipMemcpyDeviceToDevice
+                       : src_is_device               ? hipMemcpyDeviceToHost
+                                                     : hipMemcpyHostToDevice;
+  const char* s = (const char*)src;
+  char* d = (char*)dst;
+  // Merge runs where both block numbers advance by one: one DMA per run
+  // instead of one per block (the reference issues one per block,
+  // cache_kernels.cu:54-62; the bytes moved are identical).
+  int i = 0;
+  while (i < num_pairs) {
+    const int64_t s0 = block_mapping[2 * i], d0 = block_mapping[2 * i + 1];
+    int run = 1;
+    while (i + run < num_pairs && block_mapping[2 * (i + run)] == s0 + run &&
+           block_mapping[2 * (i + run) + 1] == d0 + run)
+      ++run;
+    hipError_t e = hipMemcpyAsync(d + d0 * block_bytes, s + s0 * block_bytes,
+                                  (size_t)run * block_bytes, kind, (hipStream_t)stream);
+    if (e != hipSuccess) {
+      set_error(std::string("lvllm_swap_blocks: ") + hipGetErrorString(e));
+      return 2;
+    }
+    i += run;
+  }
+  return 0;
+}

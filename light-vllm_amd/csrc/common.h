@@ -1,0 +1,119 @@
+// Shared device/host helpers for the gfx950 kernels of the paged-attention
+// decode path.  CDNA4 only: wave = 64 lanes, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/lvllm_hip.h"
+
+namespace lvllm {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const std::string& msg);
+
+#define LV_CHECK(cond, msg)                                   \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      ::lvllm::set_error(std::string(__func__) + ": " + msg); \
+      return 1;                                               \
+    }                                                         \
+  } while (0)
+
+#define LV_LAUNCH_CHECK()                                                    \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      ::lvllm::set_error(std::string(__func__) + ": " + hipGetErrorString(e_)); \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+
+// ---- element types --------------------------------------------------------
+// Tags carry the storage type (16-bit patterns are moved as uint16_t) and the
+// float conversions.  Rounding is round-to-nearest-even, the same rounding
+// c10::BFloat16 / __half conversions perform in the reference.
+struct F32 {
+  using store_t = float;
+  static constexpr int kDtype = LVLLM_F32;
+  __device__ static inline float to_float(store_t v) { return v; }
+  __device__ static inline store_t from_float(float f) { return f; }
+};
+
+struct F16 {
+  using store_t = uint16_t;
+  static constexpr int kDtype = LVLLM_F16;
+  __device__ static inline float to_float(store_t v) {
+    return (float)__builtin_bit_cast(_Float16, v);
+  }
+  __device__ static inline store_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+};
+
+struct BF16 {
+  using store_t = uint16_t;
+  static constexpr int kDtype = LVLLM_BF16;
+  __device__ static inline float to_float(store_t v) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+  }
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
+  __device__ static inline store_t from_float(float f) {
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+  }
+};
+
+// 16-byte vector of storage elements
+template <typename T>
+struct Vec16 {
+  static constexpr int N = 16 / sizeof(typename T::store_t);
+  typename T::store_t v[N];
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// Block-wide sum for blocks of up to 16 waves; `red` is 16 floats of LDS.
+__device__ inline float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = (lane < nw) ? red[lane] : 0.f;
+  r = wave_sum(r);
+  __syncthreads();
+  return r;
+}
+
+#define LV_DISPATCH_DTYPE(dtype, ...)            \
+  switch (dtype) {                               \
+    case LVLLM_F32: {                            \
+      using scalar_t = ::lvllm::F32;             \
+      __VA_ARGS__;                               \
+    } break;                                     \
+    case LVLLM_F16: {                            \
+      using scalar_t = ::lvllm::F16;             \
+      __VA_ARGS__;                               \
+    } break;                                     \
+    case LVLLM_BF16: {                           \
+      using scalar_t = ::lvllm::BF16;            \
+      __VA_ARGS__;                               \
+    } break;                                     \
+    default:                                     \
+      LV_CHECK(false, "unsupported dtype");      \
+  }
+
+}  // namespace lvllm

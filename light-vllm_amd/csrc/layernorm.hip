@@ -1,0 +1,160 @@
+// RMSNorm kernels for gfx950: rms_norm and fused_add_rms_norm.
+//
+// Rounding points follow the reference kernels so results agree with the
+// reference's GPU forward (csrc/layernorm_kernels.cu:21-45 and :254-287):
+//   variance      : fp32 sum of squares of the (already rounded) T values
+//   normalisation : t = T(x * rsqrt(var/hidden + eps))   -- rounded to T first
+//   scaling       : out = T(float(t) * float(w))          -- a T x T multiply
+//   fused add     : z = T(float(input) + float(residual)); residual = z
+// One workgroup per token row; 16-byte loads; the row is kept in registers
+// between the variance pass and the scaling pass (one HBM read per element).
+#include "common.h"
+
+namespace lvllm {
+
+constexpr int kMaxCached = 4;  // 16-byte chunks a thread keeps in registers
+
+template <typename T, bool FUSED_ADD>
+__global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUSED_ADD (no restrict)
+                                    typename T::store_t* __restrict__ res,  // residual (FUSED_ADD)
+                                    const typename T::store_t* in,
+                                    const typename T::store_t* __restrict__ weight,
+                                    const float epsilon, const int hidden_size) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  __shared__ float red[16];
+  __shared__ float s_scale;
+  const int nvec = hidden_size / N;
+  const int64_t row = (int64_t)blockIdx.x * nvec;
+  const V* in_v = reinterpret_cast<const V*>(in) + row;
+  V* res_v = reinterpret_cast<V*>(res) + row;
+  V* out_v = reinterpret_cast<V*>(out) + row;
+  const V* w_v = reinterpret_cast<const V*>(weight);
+
+  V cache[kMaxCached];
+  float var = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V x = in_v[i];
+    if (FUSED_ADD) {
+      V r = res_v[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        x.v[j] = T::from_float(T::to_float(x.v[j]) + T::to_float(r.v[j]));
+      res_v[i] = x;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float f = T::to_float(x.v[j]);
+      var += f * f;
+    }
+    // static indices only: a runtime-indexed register array would go to scratch
+#pragma unroll
+    for (int k = 0; k < kMaxCached; ++k)
+      if (c == k) cache[k] = x;
+  }
+  var = block_sum(var, red);
+  if (threadIdx.x == 0) s_scale = rsqrtf(var / hidden_size + epsilon);
+  __syncthreads();
+  const float s = s_scale;
+
+  c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V x;
+    if (c < kMaxCached) {
+#pragma unroll
+      for (int k = 0; k < kMaxCached; ++k)
+        if (c == k) x = cache[k];
+    } else {
+      x = FUSED_ADD ? res_v[i] : in_v[i];
+    }
+    const V w = w_v[i];
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const typename T::store_t t = T::from_float(T::to_float(x.v[j]) * s);
+      o.v[j] = T::from_float(T::to_float(t) * T::to_float(w.v[j]));
+    }
+    out_v[i] = o;
+  }
+}
+
+// element-wise path for rows that are not 16-byte friendly
+template <typename T, bool FUSED_ADD>
+__global__ void rms_norm_scalar_kernel(typename T::store_t* out,
+                                       typename T::store_t* __restrict__ res,
+                                       const typename T::store_t* in,
+                                       const typename T::store_t* __restrict__ weight,
+                                       const float epsilon, const int hidden_size) {
+  __shared__ float red[16];
+  __shared__ float s_scale;
+  const int64_t row = (int64_t)blockIdx.x * hidden_size;
+  float var = 0.f;
+  for (int i = threadIdx.x; i < hidden_size; i += blockDim.x) {
+    typename T::store_t x = in[row + i];
+    if (FUSED_ADD) {
+      x = T::from_float(T::to_float(x) + T::to_float(res[row + i]));
+      res[row + i] = x;
+    }
+    const float f = T::to_float(x);
+    var += f * f;
+  }
+  var = block_sum(var, red);
+  if (threadIdx.x == 0) s_scale = rsqrtf(var / hidden_size + epsilon);
+  __syncthreads();
+  const float s = s_scale;
+  for (int i = threadIdx.x; i < hidden_size; i += blockDim.x) {
+    const typename T::store_t x = FUSED_ADD ? res[row + i] : in[row + i];
+    const typename T::store_t t = T::from_float(T::to_float(x) * s);
+    out[row + i] = T::from_float(T::to_float(t) * T::to_float(weight[i]));
+  }
+}
+
+template <typename T, bool FUSED_ADD>
+static int launch_rms(void* out, void* res, const void* in, const void* weight, float eps,
+                      int num_tokens, int hidden_size, hipStream_t stream) {
+  using S = typename T::store_t;
+  constexpr int N = Vec16<T>::N;
+  const bool vec_ok = hidden_size % N == 0 && (((uintptr_t)out | (uintptr_t)res | (uintptr_t)in |
+                                                (uintptr_t)weight) & 15) == 0;
+  if (vec_ok) {
+    const int nvec = hidden_size / N;
+    int threads = ((nvec + 63) / 64) * 64;
+    threads = threads > 1024 ? 1024 : threads;
+    hipLaunchKernelGGL((rms_norm_vec_kernel<T, FUSED_ADD>), dim3(num_tokens), dim3(threads), 0,
+                       stream, (S*)out, (S*)res, (const S*)in, (const S*)weight, eps, hidden_size);
+  } else {
+    int threads = ((hidden_size + 63) / 64) * 64;
+    threads = threads > 1024 ? 1024 : threads;
+    hipLaunchKernelGGL((rms_norm_scalar_kernel<T, FUSED_ADD>), dim3(num_tokens), dim3(threads), 0,
+                       stream, (S*)out, (S*)res, (const S*)in, (const S*)weight, eps, hidden_size);
+  }
+  return 0;
+}
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+extern "C" int lvllm_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                              int num_tokens, int hidden_size, int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(hidden_size > 0, "hidden_size must be positive");
+  LV_DISPATCH_DTYPE(dtype, (launch_rms<scalar_t, false>(out, nullptr, input, weight, epsilon,
+                                                        num_tokens, hidden_size,
+                                                        (hipStream_t)stream)));
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                                        float epsilon, int num_tokens, int hidden_size,
+                                        int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(hidden_size > 0, "hidden_size must be positive");
+  LV_DISPATCH_DTYPE(dtype, (launch_rms<scalar_t, true>(input, residual, input, weight, epsilon,
+                                                       num_tokens, hidden_size,
+                                                       (hipStream_t)stream)));
+  LV_LAUNCH_CHECK();
+  return 0;
+}

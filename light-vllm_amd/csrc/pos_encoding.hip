@@ -1,0 +1,142 @@
+// Rotary position embedding (in place on query and key) for gfx950.
+//
+// Semantics: csrc/pos_encoding_kernels.cu:10-92 of the reference.  Arithmetic
+// is done in the element type T with a rounding after every operation, as the
+// reference's `x * cos - y * sin` on scalar_t values does:
+//   x' = T(T(x*cos) - T(y*sin));   y' = T(T(y*cos) + T(x*sin))
+// NeoX pairing: (i, i + rot_dim/2); GPT-J pairing: (2i, 2i+1).
+// cos_sin_cache row = [cos(0..rot_dim/2) | sin(0..rot_dim/2)].
+//
+// Launch: one workgroup per token; NeoX rows are processed in 16-byte chunks
+// (8 rotation pairs of bf16 per thread: 4 dwordx4 loads, 2 dwordx4 stores).
+#include "common.h"
+
+namespace lvllm {
+
+template <typename T>
+__device__ inline void rotate(typename T::store_t& x, typename T::store_t& y,
+                              typename T::store_t c, typename T::store_t s) {
+  const float xf = T::to_float(x), yf = T::to_float(y);
+  const float cf = T::to_float(c), sf = T::to_float(s);
+  const float xc = T::to_float(T::from_float(xf * cf));
+  const float ys = T::to_float(T::from_float(yf * sf));
+  const float yc = T::to_float(T::from_float(yf * cf));
+  const float xs = T::to_float(T::from_float(xf * sf));
+  // explicit single operations: keep hipcc from contracting them into FMAs
+  x = T::from_float(__fsub_rn(xc, ys));
+  y = T::from_float(__fadd_rn(yc, xs));
+}
+
+template <typename T, bool IS_NEOX, bool VEC>
+__global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
+                                        typename T::store_t* __restrict__ query,
+                                        typename T::store_t* __restrict__ key,
+                                        const typename T::store_t* __restrict__ cos_sin_cache,
+                                        const int rot_dim, const int64_t query_stride,
+                                        const int64_t key_stride, const int num_heads,
+                                        const int num_kv_heads, const int head_size) {
+  using S = typename T::store_t;
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int64_t token = blockIdx.x;
+  const int64_t pos = positions[token];
+  const S* cos_ptr = cos_sin_cache + pos * rot_dim;
+  const int embed_dim = rot_dim / 2;
+  const S* sin_ptr = cos_ptr + embed_dim;
+  const int total_heads = num_heads + num_kv_heads;
+
+  if constexpr (VEC && IS_NEOX) {
+    const int cpe = embed_dim / N;  // chunks per head half
+    const int n = total_heads * cpe;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int head = i / cpe, ch = i - head * cpe;
+      S* base = head < num_heads
+                    ? query + token * query_stride + (int64_t)head * head_size
+                    : key + token * key_stride + (int64_t)(head - num_heads) * head_size;
+      V x = *reinterpret_cast<const V*>(base + ch * N);
+      V y = *reinterpret_cast<const V*>(base + embed_dim + ch * N);
+      const V c = *reinterpret_cast<const V*>(cos_ptr + ch * N);
+      const V s = *reinterpret_cast<const V*>(sin_ptr + ch * N);
+#pragma unroll
+      for (int j = 0; j < N; ++j) rotate<T>(x.v[j], y.v[j], c.v[j], s.v[j]);
+      *reinterpret_cast<V*>(base + ch * N) = x;
+      *reinterpret_cast<V*>(base + embed_dim + ch * N) = y;
+    }
+  } else if constexpr (VEC && !IS_NEOX) {
+    // one 16-byte chunk = N/2 interleaved (x,y) pairs
+    const int cph = rot_dim / N;
+    const int n = total_heads * cph;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int head = i / cph, ch = i - head * cph;
+      S* base = head < num_heads
+                    ? query + token * query_stride + (int64_t)head * head_size
+                    : key + token * key_stride + (int64_t)(head - num_heads) * head_size;
+      V xy = *reinterpret_cast<const V*>(base + ch * N);
+#pragma unroll
+      for (int j = 0; j < N / 2; ++j) {
+        const int r = ch * (N / 2) + j;
+        rotate<T>(xy.v[2 * j], xy.v[2 * j + 1], cos_ptr[r], sin_ptr[r]);
+      }
+      *reinterpret_cast<V*>(base + ch * N) = xy;
+    }
+  } else {
+    const int n = total_heads * embed_dim;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int head = i / embed_dim, r = i - head * embed_dim;
+      S* base = head < num_heads
+                    ? query + token * query_stride + (int64_t)head * head_size
+                    : key + token * key_stride + (int64_t)(head - num_heads) * head_size;
+      const int xi = IS_NEOX ? r : 2 * r;
+      const int yi = IS_NEOX ? embed_dim + r : 2 * r + 1;
+      rotate<T>(base[xi], base[yi], cos_ptr[r], sin_ptr[r]);
+    }
+  }
+}
+
+template <typename T>
+static int launch_rope(const int64_t* positions, void* query, void* key, int num_tokens,
+                       int num_heads, int num_kv_heads, int head_size, int rot_dim,
+                       int64_t query_stride, int64_t key_stride, const void* cache, int is_neox,
+                       hipStream_t stream) {
+  using S = typename T::store_t;
+  constexpr int N = Vec16<T>::N;
+  const int esize = sizeof(S);
+  const int embed_dim = rot_dim / 2;
+  const bool ptr_ok = (((uintptr_t)query | (uintptr_t)key | (uintptr_t)cache) & 15) == 0 &&
+                      (query_stride * esize) % 16 == 0 && (key_stride * esize) % 16 == 0 &&
+                      (head_size * esize) % 16 == 0;
+  const bool vec = ptr_ok && (is_neox ? (embed_dim % N == 0) : (rot_dim % N == 0));
+  const int work = (num_heads + num_kv_heads) * (vec ? (is_neox ? embed_dim / N : rot_dim / N) : embed_dim);
+  int threads = ((work + 63) / 64) * 64;
+  threads = threads > 512 ? 512 : (threads < 64 ? 64 : threads);
+#define LV_ROPE(NEOX, VEC)                                                                   \
+  hipLaunchKernelGGL((rotary_embedding_kernel<T, NEOX, VEC>), dim3(num_tokens), dim3(threads), \
+                     0, stream, positions, (S*)query, (S*)key, (const S*)cache, rot_dim,     \
+                     query_stride, key_stride, num_heads, num_kv_heads, head_size)
+  if (is_neox) {
+    if (vec) LV_ROPE(true, true); else LV_ROPE(true, false);
+  } else {
+    if (vec) LV_ROPE(false, true); else LV_ROPE(false, false);
+  }
+#undef LV_ROPE
+  return 0;
+}
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+extern "C" int lvllm_rotary_embedding(const int64_t* positions, void* query, void* key,
+                                      int num_tokens, int num_heads, int num_kv_heads,
+                                      int head_size, int rot_dim, int64_t query_stride,
+                                      int64_t key_stride, const void* cos_sin_cache, int is_neox,
+                                      int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "bad rot_dim");
+  LV_DISPATCH_DTYPE(dtype, (launch_rope<scalar_t>(positions, query, key, num_tokens, num_heads,
+                                                  num_kv_heads, head_size, rot_dim, query_stride,
+                                                  key_stride, cos_sin_cache, is_neox,
+                                                  (hipStream_t)stream)));
+  LV_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,427 @@
+/*
+ * paged_ops_oracle.c -- CPU restatement of the reference's paged-attention decode operators.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under light-vllm_amd/ may import, link or call this
+ * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / the reported CPU baseline, never as the product path.
+ *
+ * Parity pin: this restatement is checked against the reference's own CPU backend
+ * (csrc/cpu/ *.cpp built unmodified into oracle/_ref/ by oracle/build_oracle.py) on seeded
+ * inputs, and against the golden vectors that build produced (tests/golden/ *.npz).  The
+ * reference ships no kernel-level golden vectors of its own.
+ *
+ * Each function restates the arithmetic of the reference's GPU kernel -- the forward a
+ * light-vllm user gets on a GPU -- including its rounding points; the reference's CPU
+ * kernels (csrc/cpu) differ from its GPU kernels only in where they round to the element
+ * type (noted per function), which is inside the tolerance the tests state.
+ *
+ * Element types: 0 = float32, 1 = float16, 2 = bfloat16 (enum lvllm_dtype of
+ * include/lvllm_hip.h).  16-bit values travel as uint16_t bit patterns.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PARTITION_SIZE 512 /* csrc/attention/attention_kernels.cu:850 */
+
+/* ---- element conversions (round to nearest even, NaN preserved) ---------------- */
+static inline float bf16_to_f(uint16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u); /* quiet NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float f16_to_f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, u;
+  if (exp == 0) {
+    if (man == 0) {
+      u = sign;
+    } else { /* subnormal */
+      int e = -1;
+      do {
+        man <<= 1;
+        ++e;
+      } while (!(man & 0x400u));
+      u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    u = sign | 0x7f800000u | (man << 13);
+  } else {
+    u = sign | ((exp + 112u) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f_to_f16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  uint32_t sign = (u >> 16) & 0x8000u;
+  uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          /* NaN */
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);         /* overflow -> inf (>= 65520) */
+  if (a < 0x33000001u) return (uint16_t)sign;                      /* underflow -> 0 (<= 2^-25) */
+  int e = (int)(a >> 23) - 127;
+  uint32_t man = (a & 0x7fffffu) | 0x800000u;
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13; /* subnormal halves lose extra bits */
+  uint32_t half_man = man >> shift;
+  uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (half_man & 1u))) ++half_man;
+  uint32_t h;
+  if (e < -14)
+    h = half_man; /* subnormal (may carry into the smallest normal, which is right) */
+  else
+    h = ((uint32_t)(e + 15) << 10) + (half_man - 0x400u); /* carry bumps the exponent */
+  return (uint16_t)(sign | h);
+}
+
+static inline float ld(const void* p, int dt, int64_t i) {
+  if (dt == 0) return ((const float*)p)[i];
+  if (dt == 1) return f16_to_f(((const uint16_t*)p)[i]);
+  return bf16_to_f(((const uint16_t*)p)[i]);
+}
+static inline void st(void* p, int dt, int64_t i, float f) {
+  if (dt == 0)
+    ((float*)p)[i] = f;
+  else if (dt == 1)
+    ((uint16_t*)p)[i] = f_to_f16(f);
+  else
+    ((uint16_t*)p)[i] = f_to_bf16(f);
+}
+/* round f to the element type and back (the "(scalar_t)(...)" casts of the kernels) */
+static inline float rnd(float f, int dt) {
+  if (dt == 0) return f;
+  if (dt == 1) return f16_to_f(f_to_f16(f));
+  return bf16_to_f(f_to_bf16(f));
+}
+static inline int esize(int dt) { return dt == 0 ? 4 : 2; }
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* exposed for the tests of the conversions themselves */
+uint16_t oracle_f32_to_f16(float f) { return f_to_f16(f); }
+float oracle_f16_to_f32(uint16_t h) { return f16_to_f(h); }
+uint16_t oracle_f32_to_bf16(float f) { return f_to_bf16(f); }
+
+/* ---------------------------------------------------------------------------------
+ * Attention over one token range [t0, t1) of one (sequence, head): the body of
+ * paged_attention_kernel, csrc/attention/attention_kernels.cu:111-496.
+ *   logits   :201-308  qk = scale * dot(q, k) (+ alibi * (token - seq_len + 1)), fp32
+ *   softmax  :310-346  max over valid tokens, __expf, sum, inv = 1 / (sum + 1e-6)
+ *   P.V      :359-434  probabilities rounded to T (from_float, :398-400), fp32 accumulate
+ *   output   :483-495  rounded to T
+ * The reference's CPU kernel (csrc/cpu/attention.cpp:209-214,48-71) keeps fp32
+ * probabilities and divides by sum (no 1e-6): a difference below 2^-8 relative.
+ * ------------------------------------------------------------------------------- */
+static void attend_range(const void* q, int64_t q_off, const void* k_cache, const void* v_cache,
+                         const int32_t* block_table, int kv_head, int64_t kv_block_stride,
+                         int64_t kv_head_stride, int head_size, int block_size, int x, float scale,
+                         float alibi_slope, int seq_len, int t0, int t1, int dt, float* logits,
+                         float* out_f32, float* out_max, float* out_sum) {
+  const int n = t1 - t0;
+  float qk_max = -FLT_MAX;
+  for (int i = 0; i < n; ++i) {
+    const int tok = t0 + i;
+    const int64_t bn = block_table[tok / block_size];
+    const int off = tok % block_size;
+    const int64_t kb = bn * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    float dot = 0.f;
+    for (int d = 0; d < head_size; ++d) {
+      /* key_cache[block][head][d / x][off][d % x], cache_kernels.cu:184-188 */
+      const int64_t ki = kb + (int64_t)(d / x) * block_size * x + (int64_t)off * x + (d % x);
+      dot += ld(q, dt, q_off + d) * ld(k_cache, dt, ki);
+    }
+    float qk = scale * dot;
+    qk += (alibi_slope != 0.f) ? alibi_slope * (float)(tok - seq_len + 1) : 0.f;
+    logits[i] = qk;
+    qk_max = fmaxf(qk_max, qk);
+  }
+  float exp_sum = 0.f;
+  for (int i = 0; i < n; ++i) {
+    logits[i] = expf(logits[i] - qk_max);
+    exp_sum += logits[i];
+  }
+  const float inv_sum = 1.f / (exp_sum + 1e-6f);
+  for (int i = 0; i < n; ++i) logits[i] = rnd(logits[i] * inv_sum, dt);
+  for (int d = 0; d < head_size; ++d) out_f32[d] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const int tok = t0 + i;
+    const int64_t bn = block_table[tok / block_size];
+    const int off = tok % block_size;
+    /* value_cache[block][head][d][off], cache_kernels.cu:189-192 */
+    const int64_t vb = bn * kv_block_stride + (int64_t)kv_head * kv_head_stride + off;
+    const float p = logits[i];
+    for (int d = 0; d < head_size; ++d)
+      out_f32[d] += p * ld(v_cache, dt, vb + (int64_t)d * block_size);
+  }
+  *out_max = qk_max;
+  *out_sum = exp_sum;
+}
+
+/* paged_attention_v1: csrc/attention/attention_kernels.cu:498-527, 690-829 */
+void oracle_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                               const void* value_cache, int num_seqs, int num_heads, int head_size,
+                               int num_kv_heads, float scale, const int32_t* block_tables,
+                               const int32_t* seq_lens, int block_size,
+                               int max_num_blocks_per_seq, const float* alibi_slopes,
+                               int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                               int dt) {
+  const int x = 16 / esize(dt);
+  const int G = num_heads / num_kv_heads;
+  int max_len = 1;
+  for (int s = 0; s < num_seqs; ++s)
+    if (seq_lens[s] > max_len) max_len = seq_lens[s];
+#pragma omp parallel
+  {
+    float* logits = (float*)malloc(sizeof(float) * (size_t)max_len);
+    float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+#pragma omp for collapse(2) schedule(dynamic, 1)
+    for (int s = 0; s < num_seqs; ++s)
+      for (int h = 0; h < num_heads; ++h) {
+        float mx, sm;
+        attend_range(query, (int64_t)s * q_stride + (int64_t)h * head_size, key_cache, value_cache,
+                     block_tables + (int64_t)s * max_num_blocks_per_seq, h / G, kv_block_stride,
+                     kv_head_stride, head_size, block_size, x, scale,
+                     alibi_slopes ? alibi_slopes[h] : 0.f, seq_lens[s], 0, seq_lens[s], dt, logits,
+                     acc, &mx, &sm);
+        for (int d = 0; d < head_size; ++d)
+          st(out, dt, ((int64_t)s * num_heads + h) * head_size + d, acc[d]);
+      }
+    free(logits);
+    free(acc);
+  }
+}
+
+/* paged_attention_v2 + reduce: csrc/attention/attention_kernels.cu:529-669, 848-997.
+ * tmp_out/exp_sums/max_logits are filled exactly where the GPU kernel fills them
+ * (every partition that holds tokens, also when there is only one). */
+void oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                               const void* query, const void* key_cache, const void* value_cache,
+                               int num_seqs, int num_heads, int head_size, int num_kv_heads,
+                               float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                               int block_size, int max_num_blocks_per_seq, int max_num_partitions,
+                               const float* alibi_slopes, int64_t q_stride,
+                               int64_t kv_block_stride, int64_t kv_head_stride, int dt) {
+  const int x = 16 / esize(dt);
+  const int G = num_heads / num_kv_heads;
+#pragma omp parallel
+  {
+    float logits[PARTITION_SIZE];
+    float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+#pragma omp for collapse(3) schedule(dynamic, 1)
+    for (int s = 0; s < num_seqs; ++s)
+      for (int h = 0; h < num_heads; ++h)
+        for (int pi = 0; pi < max_num_partitions; ++pi) {
+          const int seq_len = seq_lens[s];
+          const int t0 = pi * PARTITION_SIZE;
+          if (t0 >= seq_len) continue; /* :116-119 */
+          const int t1 = t0 + PARTITION_SIZE < seq_len ? t0 + PARTITION_SIZE : seq_len;
+          float mx, sm;
+          attend_range(query, (int64_t)s * q_stride + (int64_t)h * head_size, key_cache,
+                       value_cache, block_tables + (int64_t)s * max_num_blocks_per_seq, h / G,
+                       kv_block_stride, kv_head_stride, head_size, block_size, x, scale,
+                       alibi_slopes ? alibi_slopes[h] : 0.f, seq_len, t0, t1, dt, logits, acc, &mx,
+                       &sm);
+          const int64_t row = ((int64_t)s * num_heads + h) * max_num_partitions + pi;
+          max_logits[row] = mx;
+          exp_sums[row] = sm;
+          for (int d = 0; d < head_size; ++d) st(tmp_out, dt, row * head_size + d, acc[d]);
+        }
+    free(acc);
+  }
+  /* paged_attention_v2_reduce_kernel :577-668 */
+#pragma omp parallel for collapse(2)
+  for (int s = 0; s < num_seqs; ++s)
+    for (int h = 0; h < num_heads; ++h) {
+      const int seq_len = seq_lens[s];
+      const int np = (seq_len + PARTITION_SIZE - 1) / PARTITION_SIZE;
+      const int64_t row = ((int64_t)s * num_heads + h);
+      const int64_t prow = row * max_num_partitions;
+      if (np == 1) {
+        for (int d = 0; d < head_size; ++d)
+          st(out, dt, row * head_size + d, ld(tmp_out, dt, prow * head_size + d));
+        continue;
+      }
+      float mx = -FLT_MAX;
+      for (int j = 0; j < np; ++j) mx = fmaxf(mx, max_logits[prow + j]);
+      float gsum = 0.f;
+      for (int j = 0; j < np; ++j) gsum += exp_sums[prow + j] * expf(max_logits[prow + j] - mx);
+      const float inv = 1.f / (gsum + 1e-6f);
+      for (int d = 0; d < head_size; ++d) {
+        float acc = 0.f;
+        for (int j = 0; j < np; ++j)
+          acc += ld(tmp_out, dt, (prow + j) * head_size + d) *
+                 (exp_sums[prow + j] * expf(max_logits[prow + j] - mx)) * inv;
+        st(out, dt, row * head_size + d, acc);
+      }
+    }
+}
+
+/* reshape_and_cache: csrc/cache_kernels.cu:164-203 (byte movement, bit-exact) */
+void oracle_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                              void* value_cache, const int64_t* slot_mapping, int num_tokens,
+                              int num_heads, int head_size, int block_size, int x,
+                              int64_t key_stride, int64_t value_stride, int dt) {
+  const int es = esize(dt);
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    const int64_t slot = slot_mapping[t];
+    if (slot < 0) continue;
+    const int64_t block_idx = slot / block_size, block_off = slot % block_size;
+    for (int i = 0; i < num_heads * head_size; ++i) {
+      const int head = i / head_size, ho = i % head_size;
+      const int x_idx = ho / x, x_off = ho % x;
+      const int64_t kdst = block_idx * num_heads * (head_size / x) * block_size * x +
+                           (int64_t)head * (head_size / x) * block_size * x +
+                           (int64_t)x_idx * block_size * x + block_off * x + x_off;
+      const int64_t vdst = block_idx * num_heads * head_size * block_size +
+                           (int64_t)head * head_size * block_size + (int64_t)ho * block_size +
+                           block_off;
+      memcpy((char*)key_cache + kdst * es, (const char*)key + (t * key_stride + i) * es, es);
+      memcpy((char*)value_cache + vdst * es, (const char*)value + (t * value_stride + i) * es, es);
+    }
+  }
+}
+
+/* reshape_and_cache_flash: csrc/cache_kernels.cu:218-246 */
+void oracle_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
+                                    void* value_cache, const int64_t* slot_mapping,
+                                    int num_tokens, int num_heads, int head_size, int block_size,
+                                    int64_t block_stride, int64_t key_stride, int64_t value_stride,
+                                    int dt) {
+  const int es = esize(dt);
+  const int n = num_heads * head_size;
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    const int64_t slot = slot_mapping[t];
+    if (slot < 0) continue;
+    const int64_t block_idx = slot / block_size, block_off = slot % block_size;
+    const int64_t dst = block_idx * block_stride + block_off * n;
+    memcpy((char*)key_cache + dst * es, (const char*)key + t * key_stride * es, (size_t)n * es);
+    memcpy((char*)value_cache + dst * es, (const char*)value + t * value_stride * es, (size_t)n * es);
+  }
+}
+
+/* copy_blocks for one layer: csrc/cache_kernels.cu:67-98 (pairs applied in order) */
+void oracle_copy_blocks(void* key_cache, void* value_cache, const int64_t* block_mapping,
+                        int num_pairs, int64_t block_bytes) {
+  for (int p = 0; p < num_pairs; ++p) {
+    const int64_t src = block_mapping[2 * p], dst = block_mapping[2 * p + 1];
+    memmove((char*)key_cache + dst * block_bytes, (char*)key_cache + src * block_bytes, (size_t)block_bytes);
+    memmove((char*)value_cache + dst * block_bytes, (char*)value_cache + src * block_bytes, (size_t)block_bytes);
+  }
+}
+
+/* swap_blocks: csrc/cache_kernels.cu:24-63 (one block-sized copy per pair) */
+void oracle_swap_blocks(const void* src, void* dst, const int64_t* block_mapping, int num_pairs,
+                        int64_t block_bytes) {
+  for (int p = 0; p < num_pairs; ++p)
+    memcpy((char*)dst + block_mapping[2 * p + 1] * block_bytes,
+           (const char*)src + block_mapping[2 * p] * block_bytes, (size_t)block_bytes);
+}
+
+/* rms_norm: csrc/layernorm_kernels.cu:21-45.  out = ((T)(x * s)) * w, a T x T multiply.
+ * (csrc/cpu/layernorm.cpp multiplies in fp32 and rounds once.) */
+void oracle_rms_norm(void* out, const void* input, const void* weight, float eps, int num_tokens,
+                     int hidden, int dt) {
+#pragma omp parallel for
+  for (int t = 0; t < num_tokens; ++t) {
+    const int64_t row = (int64_t)t * hidden;
+    float var = 0.f;
+    for (int i = 0; i < hidden; ++i) {
+      const float x = ld(input, dt, row + i);
+      var += x * x;
+    }
+    const float s = 1.0f / sqrtf(var / hidden + eps);
+    for (int i = 0; i < hidden; ++i) {
+      const float tn = rnd(ld(input, dt, row + i) * s, dt);
+      st(out, dt, row + i, tn * ld(weight, dt, i));
+    }
+  }
+}
+
+/* fused_add_rms_norm: csrc/layernorm_kernels.cu:254-287 (generic form; the packed
+ * fp16 form :200-248 has the same rounding points). */
+void oracle_fused_add_rms_norm(void* input, void* residual, const void* weight, float eps,
+                               int num_tokens, int hidden, int dt) {
+#pragma omp parallel for
+  for (int t = 0; t < num_tokens; ++t) {
+    const int64_t row = (int64_t)t * hidden;
+    float var = 0.f;
+    for (int i = 0; i < hidden; ++i) {
+      const float z = rnd(ld(input, dt, row + i) + ld(residual, dt, row + i), dt);
+      st(residual, dt, row + i, z);
+      var += z * z;
+    }
+    const float s = 1.0f / sqrtf(var / hidden + eps);
+    for (int i = 0; i < hidden; ++i) {
+      const float tn = rnd(ld(residual, dt, row + i) * s, dt);
+      st(input, dt, row + i, tn * ld(weight, dt, i));
+    }
+  }
+}
+
+/* rotary_embedding: csrc/pos_encoding_kernels.cu:10-92.  `x * cos - y * sin` on scalar_t
+ * values: every product and the sum/difference are rounded to T.
+ * (csrc/cpu/pos_encoding.cpp does the arithmetic in fp32 and rounds once.) */
+static void rope_pair(void* arr, int64_t xi, int64_t yi, float c, float s, int dt) {
+  const float x = ld(arr, dt, xi), y = ld(arr, dt, yi);
+  const float xc = rnd(x * c, dt), ys = rnd(y * s, dt);
+  const float yc = rnd(y * c, dt), xs = rnd(x * s, dt);
+  st(arr, dt, xi, xc - ys);
+  st(arr, dt, yi, yc + xs);
+}
+void oracle_rotary_embedding(const int64_t* positions, void* query, void* key, int num_tokens,
+                             int num_heads, int num_kv_heads, int head_size, int rot_dim,
+                             int64_t query_stride, int64_t key_stride, const void* cos_sin_cache,
+                             int is_neox, int dt) {
+  const int embed = rot_dim / 2;
+#pragma omp parallel for
+  for (int t = 0; t < num_tokens; ++t) {
+    const int64_t cache = positions[t] * rot_dim;
+    for (int part = 0; part < 2; ++part) {
+      void* arr = part == 0 ? query : key;
+      const int nh = part == 0 ? num_heads : num_kv_heads;
+      const int64_t stride = part == 0 ? query_stride : key_stride;
+      for (int h = 0; h < nh; ++h)
+        for (int r = 0; r < embed; ++r) {
+          const int64_t base = (int64_t)t * stride + (int64_t)h * head_size;
+          const float c = ld(cos_sin_cache, dt, cache + r);
+          const float s = ld(cos_sin_cache, dt, cache + embed + r);
+          if (is_neox)
+            rope_pair(arr, base + r, base + embed + r, c, s, dt);
+          else
+            rope_pair(arr, base + 2 * r, base + 2 * r + 1, c, s, dt);
+        }
+    }
+  }
+}
+
+/* silu_and_mul: csrc/activation_kernels.cu:9-30.  out = ((T)(x / (1 + expf(-x)))) * y */
+void oracle_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d, int dt) {
+#pragma omp parallel for
+  for (int64_t t = 0; t < num_tokens; ++t)
+    for (int i = 0; i < d; ++i) {
+      const float x = ld(input, dt, t * 2 * d + i), y = ld(input, dt, t * 2 * d + d + i);
+      const float a = rnd(x / (1.0f + expf(-x)), dt);
+      st(out, dt, t * d + i, a * y);
+    }
+}

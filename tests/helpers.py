@@ -1,0 +1,81 @@
+"""Synthetic inputs of the paged-attention decode path shared by the tests,
+the golden-vector generator and bench.py.  Pure torch-CPU construction; callers move the
+tensors where they need them."""
+import math
+
+import torch
+
+
+def make_paged_inputs(num_seqs, num_heads, num_kv_heads, head_size, block_size, seq_lens,
+                      dtype=torch.bfloat16, seed=0, extra_blocks=7, q_in_qkv=False):
+    """Returns a dict with query, key_cache, value_cache (paged layouts of the reference,
+    csrc/cache_kernels.cu:152-204), block_tables, seq_lens, scale and the dense k/v they hold.
+    Block tables are a random permutation (defeats locality); K/V ~ N(0,1)*0.5."""
+    g = torch.Generator().manual_seed(seed)
+    seq_lens = list(seq_lens)
+    assert len(seq_lens) == num_seqs
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    max_len = max(max(seq_lens), 1)
+    blocks_per_seq = (max_len + block_size - 1) // block_size
+    num_blocks = num_seqs * blocks_per_seq + extra_blocks
+    perm = torch.randperm(num_blocks, generator=g)[: num_seqs * blocks_per_seq]
+    block_tables = perm.view(num_seqs, blocks_per_seq).to(torch.int32).contiguous()
+    key_cache = torch.zeros(num_blocks, num_kv_heads, head_size // x, block_size, x, dtype=dtype)
+    value_cache = torch.zeros(num_blocks, num_kv_heads, head_size, block_size, dtype=dtype)
+    k_dense, v_dense = [], []
+    for s, n in enumerate(seq_lens):
+        k = (torch.randn(n, num_kv_heads, head_size, generator=g) * 0.5).to(dtype)
+        v = (torch.randn(n, num_kv_heads, head_size, generator=g) * 0.5).to(dtype)
+        k_dense.append(k)
+        v_dense.append(v)
+        if n == 0:
+            continue
+        tok = torch.arange(n)
+        blk = block_tables[s, tok // block_size].long()
+        off = tok % block_size
+        # key_cache[blk, h, d // x, off, d % x] = k[tok, h, d]
+        key_cache[blk, :, :, off, :] = k.view(n, num_kv_heads, head_size // x, x)
+        value_cache[blk, :, :, off] = v
+    if q_in_qkv:  # q as a strided view of a fused qkv projection (qwen2.py:151-152)
+        qkv = (torch.randn(num_seqs, (num_heads + 2 * num_kv_heads) * head_size, generator=g) * 0.5).to(dtype)
+        query = qkv[:, : num_heads * head_size].view(num_seqs, num_heads, head_size)
+    else:
+        query = (torch.randn(num_seqs, num_heads, head_size, generator=g) * 0.5).to(dtype)
+    return dict(query=query, key_cache=key_cache, value_cache=value_cache,
+                block_tables=block_tables, seq_lens=torch.tensor(seq_lens, dtype=torch.int32),
+                scale=1.0 / math.sqrt(head_size), k_dense=k_dense, v_dense=v_dense,
+                block_size=block_size, num_kv_heads=num_kv_heads, max_seq_len=max(seq_lens))
+
+
+def dense_attention_fp64(inp, alibi_slopes=None):
+    """Independent fp64 gather-softmax of the same problem (no paging arithmetic shared
+    with the oracle): out[s, h] = softmax(scale * q.K^T + alibi) V."""
+    q = inp["query"]
+    S, H, D = q.shape
+    KVH = inp["num_kv_heads"]
+    out = torch.zeros(S, H, D, dtype=torch.float64)
+    for s in range(S):
+        k, v = inp["k_dense"][s].double(), inp["v_dense"][s].double()
+        n = k.shape[0]
+        if n == 0:
+            continue
+        for h in range(H):
+            kv = h // (H // KVH)
+            logits = (k[:, kv] @ q[s, h].double()) * inp["scale"]
+            if alibi_slopes is not None:
+                logits = logits + alibi_slopes[h].double() * (torch.arange(n).double() - n + 1)
+            p = torch.softmax(logits, dim=0)
+            out[s, h] = p @ v[:, kv]
+    return out
+
+
+def max_partitions(max_seq_len, partition=512):
+    return max(1, (max_seq_len + partition - 1) // partition)
+
+
+def v2_scratch(num_seqs, num_heads, head_size, max_seq_len, dtype, device="cpu"):
+    P = max_partitions(max_seq_len)
+    tmp_out = torch.zeros(num_seqs, num_heads, P, head_size, dtype=dtype, device=device)
+    exp_sums = torch.zeros(num_seqs, num_heads, P, dtype=torch.float32, device=device)
+    max_logits = torch.zeros_like(exp_sums)
+    return exp_sums, max_logits, tmp_out
