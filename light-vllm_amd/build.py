@@ -67,7 +67,7 @@ def build_kernels(verbose=False):
         objs.append(o)
         if _newer(o, [s] + hdrs):
             jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
-                         "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
+                         "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             for out in ex.map(_run, jobs):

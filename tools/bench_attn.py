@@ -1,0 +1,73 @@
+"""Kernel-only micro-benchmark of paged_attention_v1/v2 at the BASELINE shape:
+HIP events on the launch stream, caches rotated so that reads come from HBM, not the
+256 MiB Infinity Cache."""
+import argparse
+import math
+import sys, os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import light_vllm_amd  # noqa
+from light_vllm_amd import _custom_ops as ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=8)
+    ap.add_argument("--head-size", type=int, default=128)
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--ncaches", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    B, H, KVH, D, BS, L = a.bs, a.heads, a.kv_heads, a.head_size, a.block_size, a.seq
+    nblk = (L + BS - 1) // BS
+    NB = B * nblk + 7
+    torch.manual_seed(0)
+    caches = []
+    for i in range(a.ncaches):
+        kc = (torch.randn(NB, KVH, D // 8, BS, 8, device=dev) * 0.5).to(dt)
+        vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(dt)
+        bt = torch.randperm(NB, device=dev)[: B * nblk].view(B, nblk).to(torch.int32)
+        caches.append((kc, vc, bt))
+    q = (torch.randn(B, H, D, device=dev) * 0.5).to(dt)
+    seq_lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    out = torch.zeros_like(q)
+    P = (L + 511) // 512
+    tmp = torch.zeros(B, H, P, D, dtype=dt, device=dev)
+    es = torch.zeros(B, H, P, dtype=torch.float32, device=dev)
+    ml = torch.zeros_like(es)
+    scale = 1 / math.sqrt(D)
+    algo_bytes = 2 * B * L * KVH * D * 2 + 2 * B * H * D * 2 + B * nblk * 4 + B * 4
+
+    def v1(i):
+        kc, vc, bt = caches[i % a.ncaches]
+        ops.paged_attention_v1(out, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, "auto", 1.0, 1.0)
+
+    def v2(i):
+        kc, vc, bt = caches[i % a.ncaches]
+        ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, "auto", 1.0, 1.0)
+
+    for name, fn in (("v1", v1), ("v2", v2)):
+        for i in range(20):
+            fn(i)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        for i, (s, e) in enumerate(evs):
+            s.record()
+            fn(i)
+            e.record()
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+        med, mn = ts[len(ts) // 2], ts[0]
+        print(f"{name}: median {med:.1f} us  min {mn:.1f} us  -> {algo_bytes / med / 1e6:.2f} TB/s median "
+              f"({algo_bytes / med / 1e6 / 8 * 100:.1f}% of 8 TB/s), algorithmic bytes {algo_bytes}")
+
+
+if __name__ == "__main__":
+    main()
