@@ -1,0 +1,60 @@
+"""Configuration of the decode engine (the subset of light_vllm/decoding/config.py and the HF
+model config that the paged-attention decode path reads)."""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class ModelConfig:
+    """Llama / Qwen2-shaped decoder (RMSNorm, NeoX RoPE, SwiGLU, GQA): the only decode-only
+    family the reference registers (light_vllm/decode_only/modelzoo/qwen2.py)."""
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+    qkv_bias: bool = False          # Qwen2: True (qwen2.py:114-121); Llama: False
+    dtype: torch.dtype = torch.bfloat16
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @staticmethod
+    def llama3_8b() -> "ModelConfig":
+        return ModelConfig()
+
+    @staticmethod
+    def tiny(dtype=torch.bfloat16) -> "ModelConfig":
+        return ModelConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                           num_attention_heads=4, num_key_value_heads=2, vocab_size=512,
+                           max_position_embeddings=2048, dtype=dtype)
+
+
+@dataclass
+class CacheConfig:
+    block_size: int = 16
+    gpu_memory_utilization: float = 0.9
+    swap_space_bytes: int = 4 << 30
+    cache_dtype: str = "auto"
+    num_gpu_blocks: Optional[int] = None
+    num_cpu_blocks: Optional[int] = None
+    sliding_window: Optional[int] = None
+    enable_prefix_caching: bool = False
+
+
+@dataclass
+class SchedulerConfig:
+    max_num_batched_tokens: int = 8192
+    max_num_seqs: int = 256
+    max_model_len: int = 8192
+    use_v2_block_manager: bool = False
+    scheduling: str = "sync"          # sync | simple_async | async | double_buffer
+    max_num_on_the_fly: int = 2       # light_vllm/decoding/config.py:149-155
+    preemption_mode: Optional[str] = None  # None | "swap" | "recompute"

@@ -1,0 +1,109 @@
+"""HIP-graph replay of the decode step.
+
+A decode step is ~290 short kernels (32 layers x 9 launches); launched eagerly it is bound by
+the host (3-4 us per launch).  The step is captured once per padded batch size into a HIP
+graph over static input buffers (token ids, positions, slot mapping, block tables, sequence
+lengths) and replayed: the host then pays one launch per step.  This is the "HIP streams and
+graphs instead of a tracing compiler" choice of the design; the reference's decoding workflow
+runs eager.
+
+Attention inside a captured step always uses the partitioned kernel (paged_attention_v2) with
+the partition count of the longest context the block table can hold: partitions past a
+sequence's length exit immediately, so one graph serves every context length.
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from ..attention.backend import PagedAttnMetadata
+
+
+class DecodeGraph:
+    def __init__(self, model, kv_caches: List[torch.Tensor], batch_size: int,
+                 max_blocks_per_seq: int, block_size: int, device):
+        self.model = model
+        self.kv_caches = kv_caches
+        self.batch_size = batch_size
+        self.max_blocks_per_seq = max_blocks_per_seq
+        self.block_size = block_size
+        dev = torch.device(device)
+        self.input_ids = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.positions = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.slot_mapping = torch.full((batch_size,), -1, dtype=torch.int64, device=dev)
+        self.block_tables = torch.zeros(batch_size, max_blocks_per_seq, dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.hidden: Optional[torch.Tensor] = None
+        self.next_tokens: Optional[torch.Tensor] = None
+
+    def _metadata(self) -> PagedAttnMetadata:
+        return PagedAttnMetadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=self.batch_size,
+            slot_mapping=self.slot_mapping, seq_lens=None, seq_lens_tensor=self.seq_lens,
+            max_query_len=1, max_prefill_seq_len=0,
+            max_decode_seq_len=self.max_blocks_per_seq * self.block_size,
+            query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
+            block_tables=self.block_tables, use_cuda_graph=True)
+
+    def _step(self):
+        hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, self._metadata())
+        logits = self.model.compute_logits(hidden)
+        return hidden, torch.argmax(logits, dim=-1)  # greedy sampling stays on the device
+
+    def capture(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        s = stream or torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):  # warm up allocators / hipBLASLt heuristics outside the capture
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s):
+            self.hidden, self.next_tokens = self._step()
+        torch.cuda.synchronize()
+
+    def load(self, input_ids, positions, slot_mapping, block_tables, seq_lens) -> None:
+        """Copy one step's inputs (device or pinned-host tensors) into the static buffers."""
+        n = input_ids.shape[0]
+        self.input_ids[:n].copy_(input_ids, non_blocking=True)
+        self.positions[:n].copy_(positions, non_blocking=True)
+        self.slot_mapping[:n].copy_(slot_mapping, non_blocking=True)
+        self.seq_lens[:n].copy_(seq_lens, non_blocking=True)
+        w = block_tables.shape[1]
+        self.block_tables[:n, :w].copy_(block_tables, non_blocking=True)
+        if n < self.batch_size:  # padding rows: no cache write, empty context
+            self.slot_mapping[n:].fill_(-1)
+            self.seq_lens[n:].zero_()
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.next_tokens
+
+
+class DecodeGraphPool:
+    """One captured graph per padded batch size (powers of two and multiples of 8)."""
+
+    def __init__(self, model, kv_caches, max_blocks_per_seq: int, block_size: int, device):
+        self.model, self.kv_caches = model, kv_caches
+        self.max_blocks_per_seq, self.block_size, self.device = max_blocks_per_seq, block_size, device
+        self.graphs: Dict[int, DecodeGraph] = {}
+
+    @staticmethod
+    def padded(batch_size: int) -> int:
+        if batch_size <= 8:
+            p = 1
+            while p < batch_size:
+                p *= 2
+            return p
+        return (batch_size + 7) // 8 * 8
+
+    def get(self, batch_size: int) -> DecodeGraph:
+        p = self.padded(batch_size)
+        g = self.graphs.get(p)
+        if g is None:
+            g = DecodeGraph(self.model, self.kv_caches, p, self.max_blocks_per_seq, self.block_size,
+                            self.device)
+            g.capture()
+            self.graphs[p] = g
+        return g

@@ -1,0 +1,170 @@
+"""Regenerates the golden fixtures under tests/golden/ from the REAL reference.
+TEST INFRASTRUCTURE ONLY; runs in the dev container only (needs /root/reference and
+oracle/_ref).  The fixtures are data: inputs and the reference's outputs.
+
+  block_manager_<name>.json   traces of the reference's BlockSpaceManagerV1/V2 under the seeded
+                              programs of tests/bm_driver.py (every block table, verdict, CoW and
+                              swap pair after every operation)
+  ops_<name>.npz              seeded inputs and outputs of the reference's csrc/cpu operators
+                              (paged_attention_v1/v2, reshape_and_cache, copy_blocks, rms_norm,
+                              fused_add_rms_norm, rotary_embedding, silu_and_mul)
+
+usage: python oracle/make_golden.py [block_manager] [ops]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _recording_free_hook(bm, op_idx, _recorded):
+    """Logs the order in which the reference releases blocks during one operation."""
+    log = []
+    pools = []
+    for dev, name in ((0, "gpu_allocator"), (1, "cpu_allocator")):
+        alloc = getattr(bm, name, None)
+        if alloc is None:
+            continue
+        orig = alloc.free
+
+        def wrapped(block, _orig=orig, _dev=dev):
+            log.append([_dev, block.block_number])
+            return _orig(block)
+
+        alloc.free = wrapped
+        pools.append((alloc, orig))
+
+    def finish():
+        for alloc, orig in pools:
+            alloc.free = orig
+        return log
+
+    return finish
+
+
+def make_block_manager_traces():
+    import bm_driver
+    from oracle import ref_block_manager
+    ns = ref_block_manager.load()
+    adapter = bm_driver.ReferenceAdapter(ns)
+
+    def make_manager(cfg):
+        cls = ns.BlockSpaceManagerV1 if cfg["version"] == "v1" else ns.BlockSpaceManagerV2
+        return cls(block_size=cfg["block_size"], num_gpu_blocks=cfg["num_gpu_blocks"],
+                   num_cpu_blocks=cfg["num_cpu_blocks"], watermark=cfg["watermark"],
+                   sliding_window=cfg["sliding_window"], enable_caching=cfg["enable_caching"])
+
+    for name, cfg, seed, num_ops in bm_driver.DEFAULT_CONFIGS + getattr(bm_driver, "V2_CONFIGS", []):
+        hook = _recording_free_hook if cfg["version"] == "v1" else None
+        trace = bm_driver.run_program(make_manager, adapter, cfg, seed, num_ops, free_hook=hook)
+        for op in trace:  # only table frees are order-sensitive; drop the rest of the logs
+            if op.get("op") != "free":
+                op.pop("free_order", None)
+        path = os.path.join(GOLDEN, f"block_manager_{name}.json")
+        with open(path, "w") as f:
+            json.dump({"config": cfg, "seed": seed, "num_ops": num_ops, "trace": trace}, f,
+                      separators=(",", ":"))
+        kinds = {}
+        for op in trace:
+            kinds[op["op"]] = kinds.get(op["op"], 0) + 1
+        print(f"{path}: {len(trace)} ops {kinds} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def make_op_vectors():
+    import numpy as np
+    import torch
+    from helpers import make_paged_inputs, v2_scratch
+    from oracle import ref
+    assert ref.load(), "oracle/_ref/_ref_C.so missing: run oracle/build_oracle.py"
+    R, RC = torch.ops._ref_C, torch.ops._ref_C_cache_ops
+
+    def npy(t):  # bf16 travels as uint16 bit patterns
+        if t.dtype == torch.bfloat16:
+            return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+        return t.contiguous().numpy()
+
+    # ---- attention: bf16 and fp32, ragged lengths, GQA; block_size 16 (csrc/cpu limit) ----
+    for name, dtype, (S, H, KVH, D, lens) in [
+        ("attn_bf16_gqa4_d128", torch.bfloat16, (4, 4, 1, 128, [530, 100, 17, 1])),
+        ("attn_f32_gqa2_d64", torch.float32, (3, 4, 2, 64, [520, 33, 16])),
+        ("attn_bf16_mha_d80", torch.bfloat16, (3, 2, 2, 80, [300, 47, 16])),
+    ]:
+        inp = make_paged_inputs(S, H, KVH, D, 16, lens, dtype=dtype, seed=len(name))
+        q = inp["query"]
+        o1 = torch.zeros_like(q)
+        R.paged_attention_v1(o1, q, inp["key_cache"], inp["value_cache"], KVH, inp["scale"], inp["block_tables"],
+                             inp["seq_lens"], 16, inp["max_seq_len"], None, "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+        es, ml, tmp = v2_scratch(S, H, D, inp["max_seq_len"], dtype)
+        o2 = torch.zeros_like(q)
+        R.paged_attention_v2(o2, es, ml, tmp, q, inp["key_cache"], inp["value_cache"], KVH, inp["scale"],
+                             inp["block_tables"], inp["seq_lens"], 16, inp["max_seq_len"], None, "auto", 1.0, 1.0,
+                             0, 0, 0, 64, 0)
+        np.savez_compressed(os.path.join(GOLDEN, f"ops_{name}.npz"), query=npy(q), key_cache=npy(inp["key_cache"]),
+                            value_cache=npy(inp["value_cache"]), block_tables=inp["block_tables"].numpy(),
+                            seq_lens=inp["seq_lens"].numpy(), scale=np.float32(inp["scale"]),
+                            num_kv_heads=np.int32(KVH), out_v1=npy(o1), out_v2=npy(o2),
+                            dtype=str(dtype).split(".")[-1])
+        print(f"ops_{name}.npz")
+
+    # ---- reshape_and_cache + copy_blocks (bit-exact) ----
+    g = torch.Generator().manual_seed(7)
+    T, KVH, D, BS, NB = 37, 2, 128, 16, 9
+    key = torch.randn(T, KVH, D, generator=g).to(torch.bfloat16)
+    value = torch.randn(T, KVH, D, generator=g).to(torch.bfloat16)
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+    slots[5] = -1
+    kc = torch.randn(NB, KVH, D // 8, BS, 8, generator=g).to(torch.bfloat16)
+    vc = torch.randn(NB, KVH, D, BS, generator=g).to(torch.bfloat16)
+    kc0, vc0 = kc.clone(), vc.clone()
+    RC.reshape_and_cache(key, value, kc, vc, slots, "auto", 1.0, 1.0)
+    mapping = torch.tensor([[0, 7], [3, 8], [7, 2]], dtype=torch.int64)
+    kc2, vc2 = kc.clone(), vc.clone()
+    RC.copy_blocks([kc2], [vc2], mapping)
+    np.savez_compressed(os.path.join(GOLDEN, "ops_cache_bf16.npz"), key=npy(key), value=npy(value), slots=slots.numpy(),
+                        key_cache_in=npy(kc0), value_cache_in=npy(vc0), key_cache_out=npy(kc), value_cache_out=npy(vc),
+                        copy_mapping=mapping.numpy(), key_cache_copied=npy(kc2), value_cache_copied=npy(vc2))
+    print("ops_cache_bf16.npz")
+
+    # ---- rms_norm / fused_add_rms_norm / rotary / silu (bf16 + fp32) ----
+    out = {}
+    for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(6, 512, generator=g).to(dtype)
+        w = (1 + 0.1 * torch.randn(512, generator=g)).to(dtype)
+        res = torch.randn(6, 512, generator=g).to(dtype)
+        o = torch.empty_like(x)
+        R.rms_norm(o, x, w, 1e-6)
+        x2, r2 = x.clone(), res.clone()
+        R.fused_add_rms_norm(x2, r2, w, 1e-6)
+        out.update({f"norm_x_{tag}": npy(x), f"norm_w_{tag}": npy(w), f"norm_res_{tag}": npy(res),
+                    f"rms_out_{tag}": npy(o), f"fused_out_{tag}": npy(x2), f"fused_res_{tag}": npy(r2)})
+        H, KVH, D, rot = 4, 2, 64, 64
+        inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+        fr = torch.outer(torch.arange(256).float(), inv)
+        cache = torch.cat([fr.cos(), fr.sin()], -1).to(dtype)
+        pos = torch.randint(0, 256, (6,), generator=g, dtype=torch.int64)
+        qk = torch.randn(6, (H + KVH) * D, generator=g).to(dtype)
+        for neox in (True, False):
+            t = qk.clone()
+            R.rotary_embedding(pos, t[:, :H * D], t[:, H * D:], D, cache, neox)
+            out[f"rope_out_{'neox' if neox else 'gptj'}_{tag}"] = npy(t)
+        out.update({f"rope_in_{tag}": npy(qk), f"rope_cache_{tag}": npy(cache), "rope_pos": pos.numpy()})
+        gu = (torch.randn(6, 2 * 320, generator=g) * 2).to(dtype)
+        so = torch.empty(6, 320, dtype=dtype)
+        R.silu_and_mul(so, gu)
+        out.update({f"silu_in_{tag}": npy(gu), f"silu_out_{tag}": npy(so)})
+    np.savez_compressed(os.path.join(GOLDEN, "ops_elementwise.npz"), **out)
+    print("ops_elementwise.npz")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    what = sys.argv[1:] or ["block_manager", "ops"]
+    if "block_manager" in what:
+        make_block_manager_traces()
+    if "ops" in what:
+        make_op_vectors()

@@ -1,0 +1,67 @@
+"""The C-ABI library loads and exports every symbol include/lvllm_hip.h declares, the torch
+ops are registered with the reference's schemas, and argument checks fail loudly.  No compute
+call is made (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "lvllm_hip.h")) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(lvllm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from light_vllm_amd import _native
+    lib = _native.load_hip_library()
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/lvllm_hip.h but not exported"
+    assert lib.lvllm_version().startswith(b"lvllm_hip gfx950")
+
+
+def test_torch_ops_registered_with_reference_schemas(ops):
+    expected = {
+        "_C": ["paged_attention_v1", "paged_attention_v2", "silu_and_mul", "rms_norm", "fused_add_rms_norm",
+               "rotary_embedding"],
+        "_C_cache_ops": ["swap_blocks", "copy_blocks", "reshape_and_cache", "reshape_and_cache_flash"],
+        "_C_cuda_utils": ["get_device_attribute", "get_max_shared_memory_per_block_device_attribute"],
+    }
+    for ns, names in expected.items():
+        for n in names:
+            assert ops.is_custom_op_supported(f"{ns}::{n}"), f"{ns}::{n}"
+    schema = str(torch.ops._C.paged_attention_v2.default._schema)
+    for frag in ("! -> ) out", "Tensor exp_sums", "Tensor tmp_out", "int num_kv_heads", "float scale",
+                 "Tensor? alibi_slopes", "str kv_cache_dtype", "int blocksparse_head_sliding_step"):
+        assert frag in schema, (frag, schema)
+    assert "! -> ) key_cache" in str(torch.ops._C_cache_ops.reshape_and_cache.default._schema)
+
+
+def test_argument_errors_are_reported_through_the_abi():
+    from light_vllm_amd import _native
+    lib = _native.load_hip_library()
+    lib.lvllm_rotary_embedding.restype = ctypes.c_int
+    # rot_dim larger than head_size is rejected before any launch
+    rc = lib.lvllm_rotary_embedding(None, None, None, ctypes.c_int(1), ctypes.c_int(1), ctypes.c_int(1),
+                                    ctypes.c_int(64), ctypes.c_int(128), ctypes.c_int64(64), ctypes.c_int64(64),
+                                    None, ctypes.c_int(1), ctypes.c_int(2), None)
+    assert rc != 0
+    assert b"rot_dim" in lib.lvllm_last_error()
+    lib.lvllm_swap_blocks.restype = ctypes.c_int
+    rc = lib.lvllm_swap_blocks(None, None, None, ctypes.c_int(0), ctypes.c_int64(16), ctypes.c_int(0),
+                               ctypes.c_int(0), None)
+    assert rc != 0 and b"Invalid device combination" in lib.lvllm_last_error()
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed(ops):
+    """The product path has no CPU fallback: a CPU tensor is an error."""
+    x = torch.randn(2, 64)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ops.rms_norm(torch.empty_like(x), x, torch.ones(64), 1e-6)
