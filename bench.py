@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s at Llama-3-8B shapes, bs=32, context ~1k, bf16, through
+the engine's async decoding scheduler (BASELINE.json configs[1]), plus the HBM roofline of the
+dominant hot-path kernel (paged_attention_v2's partition pass) and a CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one engine step: the scheduler admits one batch of 32 decoding sequences (two such
+batches alternate, `max_num_on_the_fly=2`, so host scheduling overlaps the other batch's
+forward pass), the block manager appends one slot per sequence, the step's inputs are built,
+and the captured HIP graph of the 32-layer decode forward (+ lm_head + greedy argmax) is
+replayed.  Every rank is an independent replica with its own weights, KV cache and scheduler
+(replicas only, no collective on the data path); `value` is the sum over ranks.
+
+Output: ONE JSON line on rank 0 (contract in the task description; roofline / cpu_baseline
+objects described in DESIGN.md §Measurement).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--context", type=int, default=1024)
+    ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
+    ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=96)
+    ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
+    return ap.parse_args()
+
+
+def kernel_leg(engine, B, iters):
+    """Per-launch time of paged_attention_v2's partition pass (the dominant hot-path kernel) on
+    the engine's own KV caches: HIP events on the launch stream, one layer's cache per launch so
+    that consecutive launches read 32 different 134 MB caches (>> the 256 MiB Infinity Cache)."""
+    from light_vllm_amd import _native
+    from light_vllm_amd.paged_attn import PagedAttention
+    lib = _native.load_hip_library()
+    fn = lib.lvllm_paged_attention_v2_phases
+    fn.restype = ctypes.c_int
+    cfg = engine.model_config
+    dev = engine.device
+    H, KVH, D, BS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, engine.cache_config.block_size
+    bm = engine.scheduler.block_manager
+    groups = list(engine.scheduler.running)[:B]
+    seqs = [g.seqs[0] for g in groups]
+    lens = [s.get_len() for s in seqs]
+    tables = [bm.get_block_table(s) for s in seqs]
+    width = max(len(t) for t in tables)
+    bt = torch.zeros(len(seqs), width, dtype=torch.int32)
+    for i, t in enumerate(tables):
+        bt[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    bt = bt.to(dev)
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    max_len = max(lens)
+    P = (max_len + 511) // 512
+    q = (torch.randn(len(seqs), H, D, device=dev) * 0.5).to(cfg.dtype)
+    out = torch.empty_like(q)
+    tmp = torch.empty(len(seqs), H, P, D, dtype=cfg.dtype, device=dev)
+    es = torch.empty(len(seqs), H, P, dtype=torch.float32, device=dev)
+    ml = torch.empty_like(es)
+    caches = [PagedAttention.split_kv_cache(kv, KVH, D) for kv in engine.worker.cache_engine.gpu_cache]
+    dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[cfg.dtype]
+    vp = ctypes.c_void_p
+
+    def launch(i, phases):
+        kc, vc = caches[i % len(caches)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = fn(vp(out.data_ptr()), vp(es.data_ptr()), vp(ml.data_ptr()), vp(tmp.data_ptr()), vp(q.data_ptr()),
+                vp(kc.data_ptr()), vp(vc.data_ptr()), ctypes.c_int(len(seqs)), ctypes.c_int(H), ctypes.c_int(D),
+                ctypes.c_int(KVH), ctypes.c_float(D ** -0.5), vp(bt.data_ptr()), vp(sl.data_ptr()),
+                ctypes.c_int(BS), ctypes.c_int(max_len), ctypes.c_int(width), ctypes.c_int(P), vp(0),
+                ctypes.c_int64(q.stride(0)), ctypes.c_int64(kc.stride(0)), ctypes.c_int64(kc.stride(1)),
+                ctypes.c_int(dt), ctypes.c_int(0), ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_int(0),
+                ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(64), ctypes.c_int(0), ctypes.c_int(phases),
+                vp(stream))
+        assert rc == 0, lib.lvllm_last_error()
+
+    for i in range(8):
+        launch(i, 1)
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        launch(i, 1)
+        b.record()
+    torch.cuda.synchronize(dev)
+    ts = [a.elapsed_time(b) * 1e-3 for a, b in evs]  # seconds
+    avg = sum(ts) / len(ts)
+    esz = 2
+    algo_bytes = 2 * sum(lens) * KVH * D * esz + 2 * len(seqs) * H * D * esz + len(seqs) * width * 4 + len(seqs) * 4
+    return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P)
+
+
+def cpu_baseline_leg(engine, B, budget_s=20.0):
+    """paged_attention_v2 of the same shapes on the host cores: the reference's own csrc/cpu
+    backend (oracle/_ref, kind "reference") when it is present and the CPU has AVX512, else
+    our C restatement (oracle/, kind "port").  Bounded sample: one layer's attention for the
+    batch, repeated until ~budget_s; scaled to decode tokens/s by the 32 layers of the model
+    would be misleading (the CPU would also run the GEMMs), so it is reported per kernel call."""
+    from oracle import oracle as port
+    from oracle import ref
+    from helpers import make_paged_inputs, v2_scratch
+    cfg = engine.model_config
+    H, KVH, D, BS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, engine.cache_config.block_size
+    L = 1024
+    inp = make_paged_inputs(B, H, KVH, D, BS, [L] * B, dtype=torch.bfloat16, seed=0)
+    q = inp["query"]
+    es, ml, tmp = v2_scratch(B, H, D, L, q.dtype)
+    out = torch.zeros_like(q)
+    use_ref = ref.load() and BS == 16
+    cores = torch.get_num_threads()
+    if use_ref:
+        def call():
+            torch.ops._ref_C.paged_attention_v2(out, es, ml, tmp, q, inp["key_cache"], inp["value_cache"], KVH,
+                                                inp["scale"], inp["block_tables"], inp["seq_lens"], BS, L, None,
+                                                "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+        kind = "reference"
+    else:
+        def call():
+            port.paged_attention_v2(out, es, ml, tmp, q, inp["key_cache"], inp["value_cache"], KVH, inp["scale"],
+                                    inp["block_tables"], inp["seq_lens"], BS, L)
+        kind = "port"
+        cores = port.num_threads()
+    call()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        call()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    per_call = el / n
+    algo_bytes = 2 * B * L * KVH * D * 2 + 2 * B * H * D * 2 + B * (L // BS) * 4 + B * 4
+    return dict(value=round(algo_bytes / per_call / 1e9, 3), unit="GB/s", cores=int(cores), kind=kind,
+                sample=f"{n} calls of paged_attention_v2 (one layer, bs={B}, seq={L}, H={H}, KVH={KVH}, D={D}, bf16) "
+                       f"in {el:.1f} s; {per_call * 1e3:.2f} ms/call")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import light_vllm_amd  # noqa: F401
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+
+    B, ctx = a.batch_size, a.context
+    on_the_fly = 2 if a.scheduling == "async" else 1
+    n_req = B * on_the_fly
+    cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    total_steps = a.steps + a.warmup
+    max_len = ctx + total_steps // on_the_fly + 8
+    max_model_len = (max_len + 511) // 512 * 512
+    bs = 16
+    blocks = n_req * ((max_len + bs - 1) // bs + 1) + 64
+    engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0),
+                       SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
+                                       max_model_len=max_model_len, scheduling=a.scheduling,
+                                       max_num_on_the_fly=on_the_fly),
+                       device=dev, use_hip_graph=not a.no_graph,
+                       decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
+    engine.step_returns_outputs = False
+    g = torch.Generator().manual_seed(1234 + rank)
+    for i in range(n_req):
+        prompt = torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist()
+        engine.add_request(str(i), prompt, max_tokens=total_steps + 100)
+    engine.prefill_synthetic(seed=rank)
+    if a.scheduling == "async":
+        def step(i, n):
+            # the last (on_the_fly - 1) calls only collect: the pipeline is empty on both sides
+            # of the timed region, which therefore holds exactly K steps
+            return engine.async_step(schedule_more=i < n - (on_the_fly - 1))
+    else:
+        def step(i, n):
+            return engine.step()
+
+    for i in range(a.warmup):
+        step(i, a.warmup)
+    assert engine.num_on_the_fly == 0
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tokens = 0
+    for i in range(a.steps):
+        tokens += len(step(i, a.steps))
+    assert engine.num_on_the_fly == 0
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    assert tokens == a.steps * B, (tokens, a.steps, B)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * tokens / elapsed
+
+    k = kernel_leg(engine, B, a.kernel_iters)
+    cpu = None
+    if rank == 0 and world == 1 and not a.skip_cpu_baseline:
+        cpu = cpu_baseline_leg(engine, B)
+    ctx_now = sum(k["lens"]) / len(k["lens"])
+    engine.shutdown()
+    if rank == 0:
+        achieved = k["algo_bytes"] / k["avg_s"] / 1e9
+        line = {
+            "metric": "decode tokens/sec Llama-3-8B bs=32 seq=1k; paged-attn HBM GB/s vs roofline",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
+                                   f"decode bs={B} per step, context {ctx}..{int(ctx_now)}, block_size 16, "
+                                   f"{a.scheduling} scheduling ({on_the_fly} batches in flight), "
+                                   f"attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "
+                                   "random-init weights, synthetic KV",
+                       "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)"},
+            "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 partition pass (paged_attn_mfma_kernel)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": k["algo_bytes"],
+                         "avg_launch_us": round(k["avg_s"] * 1e6, 2), "min_launch_us": round(k["min_s"] * 1e6, 2)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,8 +70,11 @@ int lvllm_paged_attention_v1(
  * allocated exactly as light_vllm/decoding/backends/attention/ops/paged_attn.py:156-166:
  *   tmp_out   [num_seqs,num_heads,max_num_partitions,head_size] (dtype)
  *   exp_sums, max_logits float32 [num_seqs,num_heads,max_num_partitions]
- * On return they hold the per-partition values the reference's kernel writes
- * (attention_kernels.cu:349-357,483-495). */
+ * They are SCRATCH: the reference cuts every context at 512 tokens; this library cuts it
+ * into n equal shares, n chosen per call to fill the GPU (n = 1 when the batch alone does:
+ * then the scratch is not touched), n <= max_num_partitions.  Slot j of a (seq, head) row
+ * holds share j's (max logit, exp sum, normalised partial output), the same quantities the
+ * reference stores per partition (attention_kernels.cu:349-357,483-495). */
 int lvllm_paged_attention_v2(
     void* out, float* exp_sums, float* max_logits, void* tmp_out,
     const void* query, const void* key_cache, const void* value_cache,
@@ -83,6 +86,21 @@ int lvllm_paged_attention_v2(
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
     int blocksparse_head_sliding_step, void* stream);
+
+/* The two passes of paged_attention_v2 individually, for profiling and for the benchmark's
+ * per-kernel timing: phases = 1 runs only the partition pass (writes tmp_out / exp_sums /
+ * max_logits), 2 only the reduce pass (attention_kernels.cu:564-669), 3 both (== v2). */
+int lvllm_paged_attention_v2_phases(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, int phases, void* stream);
 
 /* ---- cache ops (replaces csrc/cache.h:9-33, cache_kernels.cu) ------------- */
 

@@ -2,6 +2,7 @@
 // the MI355X kernel design), the v2 partition reduce and the generic kernel
 // for fp32 caches.  Reference: csrc/attention/attention_kernels.cu:86-997.
 #include <float.h>
+#include <stdlib.h>
 
 #include "attention_params.h"
 #include "common.h"
@@ -36,9 +37,8 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
   const int G = p.num_heads / p.num_kv_heads;
   const int kvh = head / G;
   const int seq_len = p.seq_lens[seq];
-  const int t0 = p.partitioned ? part * kPartitionSize : 0;
-  if (p.partitioned && t0 >= seq_len) return;
-  const int t1 = p.partitioned ? min(seq_len, t0 + kPartitionSize) : seq_len;
+  int t0 = 0, t1 = seq_len;
+  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1)) return;
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const S* kc = (const S*)p.k_cache + (int64_t)kvh * p.kv_head_stride;
   const S* vc = (const S*)p.v_cache + (int64_t)kvh * p.kv_head_stride;
@@ -118,17 +118,18 @@ __global__ void paged_attn_v2_reduce_generic_kernel(typename T::store_t* __restr
                                                     const typename T::store_t* __restrict__ tmp_out,
                                                     const int32_t* __restrict__ seq_lens,
                                                     const int max_num_partitions,
+                                                    const int num_splits,
                                                     const int num_rows, const int num_heads,
                                                     const int D) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= num_rows) return;
   const int lane = threadIdx.x & 63;
   const int seq_len = seq_lens[row / num_heads];
-  const int np = (seq_len + kPartitionSize - 1) / kPartitionSize;
+  const int np = num_nonempty_splits(seq_len, num_splits);
   typename T::store_t* o = out + (int64_t)row * D;
   const typename T::store_t* tmp = tmp_out + (int64_t)row * max_num_partitions * D;
-  if (np == 1) {
-    for (int d = lane; d < D; d += 64) o[d] = tmp[d];
+  if (np <= 1) {  // one share: copy through (attention_kernels.cu:582-594); empty context: zeros
+    for (int d = lane; d < D; d += 64) o[d] = np == 1 ? tmp[d] : T::from_float(0.f);
     return;
   }
   const float* ml = max_logits + (int64_t)row * max_num_partitions;
@@ -222,7 +223,7 @@ extern "C" int lvllm_paged_attention_v1(
   return 0;
 }
 
-extern "C" int lvllm_paged_attention_v2(
+extern "C" int lvllm_paged_attention_v2_phases(
     void* out, float* exp_sums, float* max_logits, void* tmp_out,
     const void* query, const void* key_cache, const void* value_cache,
     int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
@@ -232,12 +233,13 @@ extern "C" int lvllm_paged_attention_v2(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, void* stream) {
+    int blocksparse_head_sliding_step, int phases, void* stream) {
   (void)tp_rank; (void)blocksparse_local_blocks; (void)blocksparse_block_size;
   (void)blocksparse_head_sliding_step;
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
+  LV_CHECK((phases & ~3) == 0 && phases != 0, "phases must be 1 (partitions), 2 (reduce) or 3 (both)");
   LV_CHECK(max_num_partitions >= 1 &&
                (int64_t)max_num_partitions * kPartitionSize >= (int64_t)max_seq_len,
            "exp_sums.size(-1) must be >= ceil(max_seq_len / 512)");
@@ -254,20 +256,45 @@ extern "C" int lvllm_paged_attention_v2(
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
                       (q_stride * 2) % 16 == 0 && (kv_block_stride * 2) % 16 == 0 &&
                       (kv_head_stride * 2) % 16 == 0 && block_size >= 16;
-  // partitions that can hold tokens: ceil(max_seq_len/512) (grid z of the reference)
-  int num_parts = (max_seq_len + kPartitionSize - 1) / kPartitionSize;
-  if (num_parts < 1) num_parts = 1;
-  const int tokens_per_wg = max_seq_len < kPartitionSize ? max_seq_len : kPartitionSize;
-  int rc = 0;
-  if (dtype == LVLLM_BF16 && vec_ok)
-    rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, num_parts, tokens_per_wg, s);
-  else if (dtype == LVLLM_F16 && vec_ok)
-    rc = launch_mfma_hs<F16>(p, head_size, block_size, num_seqs, num_parts, tokens_per_wg, s);
-  else {
-    LV_DISPATCH_DTYPE(dtype, rc = launch_generic<scalar_t>(p, head_size, block_size, num_seqs, num_parts, s));
+  // How many equal shares each context is cut into.  The reference always cuts at 512
+  // tokens; here the cut exists only to fill the GPU: with >= 8 waves per CU from
+  // (sequence, kv head) pairs alone there is no cut at all (one pass, no reduce), otherwise
+  // just enough shares, bounded by the caller's scratch (max_num_partitions slots per head)
+  // and by a minimum of 4 tiles of work per share.
+  const int G = num_heads / num_kv_heads;
+  const bool use_mfma = (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && vec_ok;
+  const int64_t pairs = use_mfma ? (int64_t)num_seqs * num_kv_heads * ((G + 15) / 16)
+                                 : (int64_t)num_seqs * num_heads;
+  const int64_t want = use_mfma ? (2048 + 8 * pairs - 1) / (8 * pairs) : (1024 + pairs - 1) / pairs;
+  const int max_tiles = (max_seq_len + 15) / 16;
+  int nsplit = (int)(want < max_num_partitions ? want : max_num_partitions);
+  if (nsplit > max_tiles / 4) nsplit = max_tiles / 4;
+  if (nsplit < 1) nsplit = 1;
+  if (const char* e = getenv("LVLLM_ATTN_SPLITS")) {  // experiments / tests
+    const int forced = atoi(e);
+    if (forced >= 1) nsplit = forced < max_num_partitions ? forced : max_num_partitions;
   }
-  if (rc) return rc;
-  LV_LAUNCH_CHECK();
+  p.num_splits = nsplit;
+  if (nsplit == 1) {  // single share: write `out` directly, nothing to reduce
+    p.out = out;
+    p.partitioned = 0;
+    p.max_num_partitions = 1;
+  }
+  const int tokens_per_wg = (max_seq_len + nsplit - 1) / nsplit;
+  int rc = 0;
+  if (phases & 1) {
+    if (dtype == LVLLM_BF16 && use_mfma)
+      rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, nsplit, tokens_per_wg, s);
+    else if (dtype == LVLLM_F16 && use_mfma)
+      rc = launch_mfma_hs<F16>(p, head_size, block_size, num_seqs, nsplit, tokens_per_wg, s);
+    else {
+      LV_DISPATCH_DTYPE(dtype, rc = launch_generic<scalar_t>(p, head_size, block_size, num_seqs, nsplit, s));
+    }
+    if (rc) return rc;
+    LV_LAUNCH_CHECK();
+  }
+  if (nsplit == 1) return 0;
+  if (!(phases & 2)) return 0;
 
   const int num_rows = num_seqs * num_heads;
   const int waves_per_block = 4;
@@ -275,12 +302,31 @@ extern "C" int lvllm_paged_attention_v2(
 #define LV_REDUCE(T_)                                                                              \
   hipLaunchKernelGGL((paged_attn_v2_reduce_generic_kernel<T_>), dim3(grid), dim3(waves_per_block * 64), \
                      0, s, (typename T_::store_t*)out, exp_sums, max_logits,                        \
-                     (const typename T_::store_t*)tmp_out, seq_lens, max_num_partitions, num_rows,  \
-                     num_heads, head_size)
+                     (const typename T_::store_t*)tmp_out, seq_lens, max_num_partitions, nsplit,    \
+                     num_rows, num_heads, head_size)
   if (dtype == LVLLM_BF16) LV_REDUCE(BF16);
   else if (dtype == LVLLM_F16) LV_REDUCE(F16);
   else LV_REDUCE(F32);
 #undef LV_REDUCE
   LV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int lvllm_paged_attention_v2(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, void* stream) {
+  return lvllm_paged_attention_v2_phases(
+      out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+      head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+      max_num_blocks_per_seq, max_num_partitions, alibi_slopes, q_stride, kv_block_stride,
+      kv_head_stride, dtype, kv_dtype, k_scale, v_scale, tp_rank, blocksparse_local_blocks,
+      blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step, 3, stream);
 }

@@ -123,9 +123,9 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
   const int part = blockIdx.z;
   const int seq_len = p.seq_lens[seq];
 
-  const int t0 = p.partitioned ? part * kPartitionSize : 0;
-  if (p.partitioned && t0 >= seq_len) return;  // attention_kernels.cu:116-119
-  const int t1 = p.partitioned ? min(seq_len, t0 + kPartitionSize) : seq_len;
+  int t0 = 0, t1 = seq_len;
+  // empty share: nothing to do (the reference's early exit, attention_kernels.cu:116-119)
+  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1)) return;
   const int ntiles = (t1 - t0 + 15) >> 4;
   const int tile0 = t0 >> 4;
   // tiles of this wave: lt = wave + j * NWAVES, j = 0 .. nmy-1

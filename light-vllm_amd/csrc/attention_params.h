@@ -1,5 +1,6 @@
 // Kernel argument block shared by the paged-attention translation units.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace lvllm {
@@ -18,8 +19,31 @@ struct AttnParams {
   const float* alibi_slopes;
   int num_heads, num_kv_heads, max_num_blocks_per_seq, max_num_partitions;
   int partitioned;  // 0: whole sequence per workgroup (v1)
+  int num_splits;   // partitioned: every sequence is cut into at most this many equal shares
   float scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
 };
+
+
+// Share `s` of a context of `seq_len` tokens cut into at most `num_splits` equal shares of
+// whole 16-token tiles: tokens [t0, t1).  Returns false for an empty share.  Both passes of
+// paged_attention_v2 (and every kernel variant) use this one function, so the partition
+// pass and the reduce pass always agree on which scratch slots hold data.
+__host__ __device__ inline bool split_range(int seq_len, int num_splits, int s, int* t0, int* t1) {
+  const int ntiles = (seq_len + 15) >> 4;
+  const int chunk = (ntiles + num_splits - 1) / num_splits;  // tiles per share
+  const int first = s * chunk;
+  if (first >= ntiles) return false;
+  *t0 = first << 4;
+  const int end = (first + chunk) << 4;
+  *t1 = end < seq_len ? end : seq_len;
+  return true;
+}
+__host__ __device__ inline int num_nonempty_splits(int seq_len, int num_splits) {
+  const int ntiles = (seq_len + 15) >> 4;
+  if (ntiles == 0) return 0;
+  const int chunk = (ntiles + num_splits - 1) / num_splits;
+  return (ntiles + chunk - 1) / chunk;
+}
 
 }  // namespace lvllm

@@ -1,0 +1,186 @@
+"""Per-step model inputs: token ids, positions and the attention metadata (slot_mapping,
+block_tables, seq_lens) that the paged-attention kernels consume.
+
+Field-for-field the computation of light_vllm/decoding/processor/model_input_builder.py
+(:212-378): per scheduled sequence `context_len` / `seq_len` / `query_len`, the prefix-cache
+shortcut (:270-296), the sliding-window clamp of decode sequence lengths (:298-322), then the
+attention backend's metadata builder.  Tensors are built on the CPU (pinned when a GPU is
+present); the executor moves them with non-blocking copies on its stream.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from .config import CacheConfig, SchedulerConfig
+from .scheduler import SchedulerOutput, SequenceGroupMetadata
+
+
+class InterDataForSeqGroup:
+    """Intermediate per-group record read by the attention metadata builder
+    (same attribute names as ModelInputForGPUBuilder.InterDataForSeqGroup, :110-157)."""
+
+    def __init__(self, *, request_id: str, seq_ids: List[int], is_prompt: bool,
+                 block_tables: Optional[Dict[int, List[int]]], computed_block_nums: List[int]):
+        n = len(seq_ids)
+        self.request_id = request_id
+        self.seq_ids = seq_ids
+        self.is_prompt = is_prompt
+        self.block_tables = block_tables
+        self.computed_block_nums = computed_block_nums
+        self.n_seqs = n
+        self.input_tokens: List[List[int]] = [[] for _ in range(n)]
+        self.input_positions: List[List[int]] = [[] for _ in range(n)]
+        self.seq_lens = [0] * n
+        self.orig_seq_lens = [0] * n
+        self.query_lens = [0] * n
+        self.context_lens = [0] * n
+        self.curr_sliding_window_blocks = [0] * n
+        self.prefix_cache_hit = False
+
+
+@dataclass
+class ModelInput:
+    input_tokens: Optional[torch.Tensor] = None      # [T] int64
+    input_positions: Optional[torch.Tensor] = None   # [T] int64
+    attn_metadata: object = None
+    seq_lens: List[int] = field(default_factory=list)
+    query_lens: List[int] = field(default_factory=list)
+    # rows of the hidden states that feed the sampler, and the sequences they belong to
+    sample_indices: List[int] = field(default_factory=list)
+    sample_seq_ids: List[int] = field(default_factory=list)
+    decode_only: bool = True
+
+    def to(self, device, non_blocking=True) -> "ModelInput":
+        if self.input_tokens is not None:
+            self.input_tokens = self.input_tokens.to(device, non_blocking=non_blocking)
+            self.input_positions = self.input_positions.to(device, non_blocking=non_blocking)
+            self.attn_metadata.to(device, non_blocking=non_blocking)
+        return self
+
+
+@dataclass
+class WorkerInput:
+    """Cache operations to run before the forward pass; [n, 2] int64 CPU tensors
+    (model_input_builder.py:84-101)."""
+    num_seq_groups: int
+    blocks_to_swap_in: torch.Tensor
+    blocks_to_swap_out: torch.Tensor
+    blocks_to_copy: torch.Tensor
+
+
+@dataclass
+class ExecuteInput:
+    worker_input: WorkerInput
+    model_input: ModelInput
+
+
+class ModelInputBuilder:
+
+    def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig, attn_backend,
+                 sliding_window: Optional[int] = None, chunked_prefill_enabled: bool = False):
+        self.scheduler_config = scheduler_config
+        self.cache_config = cache_config
+        self.attn_backend = attn_backend
+        self.sliding_window = sliding_window
+        self.block_size = cache_config.block_size
+        self.chunked_prefill_enabled = chunked_prefill_enabled
+        if sliding_window is not None:
+            self.sliding_window_blocks = (sliding_window + self.block_size - 1) // self.block_size
+            self.block_aligned_sliding_window = self.sliding_window_blocks * self.block_size
+        self.inter_data_list: List[InterDataForSeqGroup] = []
+
+    def _add_seq_group(self, meta: SequenceGroupMetadata) -> InterDataForSeqGroup:
+        seq_ids = list(meta.seq_data.keys())
+        if meta.is_prompt:
+            assert len(seq_ids) == 1
+        d = InterDataForSeqGroup(request_id=meta.request_id, seq_ids=seq_ids, is_prompt=meta.is_prompt,
+                                 block_tables=meta.block_tables,
+                                 computed_block_nums=meta.computed_block_nums)
+        for i, seq_id in enumerate(seq_ids):
+            data = meta.seq_data[seq_id]
+            seq_len = data.get_len()
+            context_len = data.get_num_computed_tokens() if d.is_prompt else seq_len - 1
+            seq_len = min(seq_len, context_len + meta.token_chunk_size)
+            if d.is_prompt:
+                tokens = data.get_token_ids()[context_len:seq_len]
+            else:
+                tokens = [data.get_last_token_id()]
+            positions = list(range(context_len, seq_len))
+            query_len = seq_len - context_len if d.is_prompt else 1
+            # prefix-cache hit: the leading computed blocks are skipped (:270-296)
+            hit = bool(meta.computed_block_nums) and self.sliding_window is None and d.is_prompt
+            d.prefix_cache_hit = hit
+            if hit:
+                if self.chunked_prefill_enabled:
+                    raise RuntimeError("chunked prefill cannot be used with prefix caching now.")
+                context_len = len(meta.computed_block_nums) * self.block_size
+                tokens = tokens[context_len:]
+                positions = positions[context_len:]
+                query_len = seq_len - context_len
+            d.orig_seq_lens[i] = seq_len
+            # sliding window: a decoding sequence only attends to the window (:298-322)
+            sw_blocks = 0
+            sliding_seq_len = seq_len
+            if not d.is_prompt and self.sliding_window is not None:
+                sw_blocks = self.sliding_window_blocks
+                if self.scheduler_config.use_v2_block_manager:
+                    suff = seq_len % self.block_size
+                    sliding_seq_len = min(seq_len, self.block_aligned_sliding_window + suff)
+                    if suff > 0:
+                        sw_blocks += 1
+                else:
+                    sliding_seq_len = min(seq_len, self.sliding_window)
+            d.seq_lens[i] = sliding_seq_len
+            d.curr_sliding_window_blocks[i] = sw_blocks
+            d.context_lens[i] = context_len
+            d.query_lens[i] = query_len
+            d.input_tokens[i] = tokens
+            d.input_positions[i] = positions
+        return d
+
+    def prepare_model_input(self, metas: List[SequenceGroupMetadata]) -> ModelInput:
+        self.inter_data_list = [self._add_seq_group(m) for m in metas]
+        tokens: List[int] = []
+        positions: List[int] = []
+        seq_lens: List[int] = []
+        query_lens: List[int] = []
+        sample_indices: List[int] = []
+        sample_seq_ids: List[int] = []
+        decode_only = True
+        for d, m in zip(self.inter_data_list, metas):
+            if d.is_prompt:
+                decode_only = False
+            for i, seq_id in enumerate(d.seq_ids):
+                tokens.extend(d.input_tokens[i])
+                positions.extend(d.input_positions[i])
+                if m.do_sample:
+                    sample_indices.append(len(tokens) - 1)  # last token of the sequence's chunk
+                    sample_seq_ids.append(seq_id)
+            seq_lens.extend(d.seq_lens)
+            query_lens.extend(d.query_lens)
+        if not tokens:
+            return ModelInput()
+        builder = self.attn_backend.make_metadata_builder(self)
+        attn_metadata = builder.build(seq_lens, query_lens, -1, len(tokens))
+        pin = torch.cuda.is_available()
+        t = torch.tensor(tokens, dtype=torch.long)
+        p = torch.tensor(positions, dtype=torch.long)
+        if pin:
+            t, p = t.pin_memory(), p.pin_memory()
+        return ModelInput(input_tokens=t, input_positions=p, attn_metadata=attn_metadata,
+                          seq_lens=seq_lens, query_lens=query_lens, sample_indices=sample_indices,
+                          sample_seq_ids=sample_seq_ids, decode_only=decode_only)
+
+    @staticmethod
+    def prepare_worker_input(out: SchedulerOutput) -> WorkerInput:
+        def pairs(lst):
+            return torch.tensor(lst, dtype=torch.int64).view(-1, 2)
+        return WorkerInput(num_seq_groups=len(out.seq_group_metadata_list),
+                           blocks_to_swap_in=pairs(out.blocks_to_swap_in),
+                           blocks_to_swap_out=pairs(out.blocks_to_swap_out),
+                           blocks_to_copy=pairs(out.blocks_to_copy))
+
+    def __call__(self, out: SchedulerOutput) -> ExecuteInput:
+        return ExecuteInput(worker_input=self.prepare_worker_input(out),
+                            model_input=self.prepare_model_input(out.seq_group_metadata_list))

@@ -1,0 +1,303 @@
+"""Decode engine: scheduler -> input builder -> executor (cache ops + forward + greedy
+sampling) -> output processing, in the step structure of light_vllm/core/llm_engine.py:
+`sync_step` (:119-130) and `async_step` (:132-176, up to `max_num_on_the_fly` steps in
+flight, legal because scheduled groups are marked busy).
+
+One engine = one GPU (replica).  Multi-GPU serving replicates engines, one process per GPU,
+with no collective on the kernel path.
+"""
+import queue
+import threading
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..attention.backend import PagedAttnBackend
+from .cache_engine import CacheEngine
+from .config import CacheConfig, ModelConfig, SchedulerConfig
+from .graph_runner import DecodeGraphPool
+from .input_builder import ExecuteInput, ModelInputBuilder
+from .model import DecoderModel
+from .scheduler import DecodingScheduler, SchedulerOutput
+from .sequence import Sequence, SequenceGroup, SequenceStatus
+
+
+@dataclass
+class RequestOutput:
+    request_id: str
+    token_ids: List[int]
+    finished: bool
+    finish_reason: Optional[str] = None
+
+
+@dataclass
+class ExecuteOutput:
+    sampled: Optional[torch.Tensor]  # [num sampled rows] int64 on the CPU (pinned)
+    sample_seq_ids: List[int]
+    execute_begin_ts: float = 0.0
+    execute_end_ts: float = 0.0
+
+
+class Worker:
+    """Owns the model, the KV caches and the stream the step runs on
+    (decoding/worker/gpu_worker.py:26-224 + runner/model_runner.py:169-187)."""
+
+    def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, attn_backend,
+                 device: str, use_hip_graph: bool = True, decode_version: Optional[str] = None,
+                 max_model_len: int = 8192, seed: int = 0):
+        self.device = torch.device(device)
+        self.model_config = model_config
+        self.cache_config = cache_config
+        impl_cls = attn_backend.get_impl_cls()
+        self.attn_impl = impl_cls(model_config.num_attention_heads, model_config.head_dim,
+                                  model_config.head_dim ** -0.5, model_config.num_key_value_heads,
+                                  None, cache_config.sliding_window, cache_config.cache_dtype,
+                                  decode_version=decode_version)
+        self.model = DecoderModel(model_config, self.attn_impl, device, seed)
+        self.attn_backend = attn_backend
+        self.cache_engine: Optional[CacheEngine] = None
+        self.use_hip_graph = use_hip_graph
+        self.max_model_len = max_model_len
+        self.graphs: Optional[DecodeGraphPool] = None
+
+    def determine_num_available_blocks(self) -> Tuple[int, int]:
+        """Blocks that fit beside the weights (gpu_worker.py:95-143): a profile forward with no
+        KV cache measures the activation peak; the rest of `gpu_memory_utilization` x total
+        memory is KV cache."""
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(self.device)
+        free, total = torch.cuda.mem_get_info(self.device)
+        peak = total - free
+        block_bytes = CacheEngine.get_cache_block_size(self.cache_config, self.model_config)
+        num_gpu = int((total * self.cache_config.gpu_memory_utilization - peak) // block_bytes)
+        num_cpu = int(self.cache_config.swap_space_bytes // block_bytes)
+        return max(num_gpu, 0), max(num_cpu, 0)
+
+    def initialize_cache(self, num_gpu_blocks: int, num_cpu_blocks: int) -> None:
+        self.cache_config.num_gpu_blocks = num_gpu_blocks
+        self.cache_config.num_cpu_blocks = num_cpu_blocks
+        self.cache_engine = CacheEngine(self.cache_config, self.model_config, self.attn_backend, self.device)
+        if self.use_hip_graph:
+            max_blocks = (self.max_model_len + self.cache_config.block_size - 1) // self.cache_config.block_size
+            self.graphs = DecodeGraphPool(self.model, self.cache_engine.gpu_cache, max_blocks,
+                                          self.cache_config.block_size, self.device)
+
+    @torch.inference_mode()
+    def execute(self, execute_input: ExecuteInput) -> ExecuteOutput:
+        wi, mi = execute_input.worker_input, execute_input.model_input
+        ce = self.cache_engine
+        if wi.blocks_to_swap_in.numel() > 0:
+            ce.swap_in(wi.blocks_to_swap_in)
+        if wi.blocks_to_swap_out.numel() > 0:
+            ce.swap_out(wi.blocks_to_swap_out)
+        if wi.blocks_to_copy.numel() > 0:
+            ce.copy(wi.blocks_to_copy.to(self.device, non_blocking=True))
+        if mi.input_tokens is None:
+            return ExecuteOutput(None, [])
+        md = mi.attn_metadata
+        if self.graphs is not None and mi.decode_only and md.block_tables.shape[1] <= self.graphs.max_blocks_per_seq:
+            g = self.graphs.get(mi.input_tokens.shape[0])
+            g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor)
+            tokens = g.replay()[:mi.input_tokens.shape[0]]
+            if len(mi.sample_indices) != mi.input_tokens.shape[0]:
+                tokens = tokens[torch.tensor(mi.sample_indices, device=self.device)]
+        else:
+            mi.to(self.device)
+            hidden = self.model.forward(mi.input_tokens, mi.input_positions, ce.gpu_cache, md)
+            if len(mi.sample_indices) != hidden.shape[0]:
+                hidden = hidden[torch.tensor(mi.sample_indices, device=self.device)]
+            tokens = torch.argmax(self.model.compute_logits(hidden), dim=-1)
+        out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
+        out.copy_(tokens, non_blocking=True)
+        return ExecuteOutput(out, mi.sample_seq_ids)
+
+
+class LLMEngine:
+
+    def __init__(self, model_config: ModelConfig, cache_config: CacheConfig,
+                 scheduler_config: SchedulerConfig, device: str = "cuda:0", use_hip_graph: bool = True,
+                 decode_version: Optional[str] = None, eos_token_id: Optional[int] = None, seed: int = 0):
+        self.model_config, self.cache_config, self.scheduler_config = model_config, cache_config, scheduler_config
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.attn_backend = PagedAttnBackend()
+        self.worker = Worker(model_config, cache_config, self.attn_backend, device, use_hip_graph,
+                             decode_version, scheduler_config.max_model_len, seed)
+        num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
+        if num_gpu is None:
+            num_gpu, auto_cpu = self.worker.determine_num_available_blocks()
+            num_cpu = auto_cpu if num_cpu is None else num_cpu
+        self.worker.initialize_cache(num_gpu, num_cpu or 0)
+        self.scheduler = DecodingScheduler(scheduler_config, cache_config)
+        self.input_builder = ModelInputBuilder(scheduler_config, cache_config, self.attn_backend,
+                                               cache_config.sliding_window)
+        self.eos_token_id = eos_token_id
+        self.seq_counter = 0
+        self.groups: Dict[str, SequenceGroup] = {}
+        self.seq_to_group: Dict[int, SequenceGroup] = {}
+        # async machinery (core/executor.py:48-185)
+        self.stream = torch.cuda.Stream(self.device)
+        self.executor_in: "queue.Queue" = queue.Queue()
+        self.executor_out: "queue.Queue" = queue.Queue()
+        self.num_on_the_fly = 0
+        self._thread: Optional[threading.Thread] = None
+        self.step_returns_outputs = True
+
+    # ---- requests ----
+    def add_request(self, request_id: str, prompt_token_ids: List[int], max_tokens: int = 16) -> None:
+        seq = Sequence(self.seq_counter, list(prompt_token_ids), self.cache_config.block_size, self.eos_token_id)
+        self.seq_counter += 1
+        g = SequenceGroup(request_id, [seq], time.time(), max_tokens=max_tokens)
+        self.groups[request_id] = g
+        self.seq_to_group[seq.seq_id] = g
+        self.scheduler.add_request(g)
+
+    def has_unfinished_requests(self) -> bool:
+        return self.scheduler.has_unfinished_requests()
+
+    # ---- output processing (decoding/processor/output_processor.py, greedy subset) ----
+    def _process(self, sched: SchedulerOutput, out: ExecuteOutput) -> List[RequestOutput]:
+        sampled = out.sampled.tolist() if out.sampled is not None else []
+        tok_of = dict(zip(out.sample_seq_ids, sampled))
+        results: List[RequestOutput] = []
+        for s in sched.scheduled_seq_groups:
+            g = s.seq_group
+            g.update_num_computed_tokens(s.token_chunk_size)
+            for seq in g.get_seqs(status=SequenceStatus.RUNNING):
+                if seq.seq_id not in tok_of:
+                    continue  # a prompt chunk that sampled nothing
+                tok = tok_of[seq.seq_id]
+                seq.append_token_id(tok, 0.0)
+                if self.eos_token_id is not None and tok == self.eos_token_id:
+                    seq.status = SequenceStatus.FINISHED_STOPPED
+                elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                elif seq.get_len() >= self.scheduler_config.max_model_len:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                if seq.is_finished():
+                    self.scheduler.free_seq(seq)
+            if self.step_returns_outputs:
+                seq0 = g.seqs[0]
+                results.append(RequestOutput(g.request_id, list(seq0.get_output_token_ids()), g.is_finished(),
+                                             SequenceStatus.get_finished_reason(seq0.status)))
+            else:
+                results.append(RequestOutput(g.request_id, [], g.is_finished()))
+        for g in sched.ignored_seq_groups:
+            results.append(RequestOutput(g.request_id, [], True, "length"))
+        self.scheduler.free_finished_request([s.seq_group.request_id for s in sched.scheduled_seq_groups])
+        for r in results:
+            if r.finished:
+                g = self.groups.pop(r.request_id, None)
+                if g is not None:
+                    for seq in g.seqs:
+                        self.seq_to_group.pop(seq.seq_id, None)
+        return results
+
+    # ---- synchronous step (core/llm_engine.py:119-130) ----
+    def step(self) -> List[RequestOutput]:
+        sched = self.scheduler.schedule()
+        if sched is None or sched.is_empty():
+            if sched is not None and sched.ignored_seq_groups:
+                return self._process(sched, ExecuteOutput(None, []))
+            return []
+        ei = self.input_builder(sched)
+        with torch.cuda.stream(self.stream):
+            out = self.worker.execute(ei)
+        self.stream.synchronize()
+        return self._process(sched, out)
+
+    # ---- asynchronous step (core/llm_engine.py:132-176) ----
+    def _execute_loop(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self.executor_in.get()
+            if item is None:
+                return
+            sched, ei = item
+            try:
+                t0 = time.perf_counter()
+                with torch.cuda.stream(self.stream):
+                    out = self.worker.execute(ei)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                ev.synchronize()  # results are on the host; the next step may already be queued
+                out.execute_begin_ts, out.execute_end_ts = t0, time.perf_counter()
+                self.executor_out.put((sched, out))
+            except Exception as e:  # surfaced on the engine thread (core/executor.py:59-60)
+                self.executor_out.put(e)
+
+    def ensure_start_execute_loop(self) -> None:
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._execute_loop, daemon=True)
+            self._thread.start()
+
+    def async_step(self, schedule_more: bool = True) -> List[RequestOutput]:
+        """schedule_more=False only collects a result (used to drain the pipeline)."""
+        self.ensure_start_execute_loop()
+        # keep up to max_num_on_the_fly steps queued behind the one that is executing
+        while schedule_more and self.num_on_the_fly < self.scheduler_config.max_num_on_the_fly:
+            sched = self.scheduler.schedule()
+            if sched is None or sched.is_empty():
+                break
+            self.executor_in.put((sched, self.input_builder(sched)))
+            self.num_on_the_fly += 1
+        if self.num_on_the_fly == 0:
+            return []
+        item = self.executor_out.get()
+        if isinstance(item, Exception):
+            raise item
+        self.num_on_the_fly -= 1
+        sched, out = item
+        return self._process(sched, out)
+
+    def shutdown(self) -> None:
+        if self._thread is not None:
+            self.executor_in.put(None)
+            self._thread.join(timeout=5)
+            self._thread = None
+
+    # ---- synthetic context (benchmarks): mark prompts as computed and fill their KV ----
+    def prefill_synthetic(self, seed: int = 0) -> None:
+        """Admit every waiting request as if its prompt had been prefilled: blocks are
+        allocated through the scheduler's block manager, K/V rows are random values written
+        through `reshape_and_cache`, and the first output token is a random id.  Used by
+        bench.py to start decode at a given context length without timing prompt processing."""
+        from .. import _custom_ops as ops
+        from ..attention.backend import compute_slot_mapping
+        from ..paged_attn import PagedAttention
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        cfg = self.model_config
+        sched = self.scheduler
+        admitted: List[SequenceGroup] = []
+        while sched.waiting:
+            g = sched.waiting[0]
+            if sched.block_manager.can_allocate(g).name != "OK":
+                break
+            sched.waiting.popleft()
+            sched.block_manager.allocate(g)
+            for seq in g.get_seqs(status=SequenceStatus.WAITING):
+                seq.status = SequenceStatus.RUNNING
+            sched.running.append(g)
+            admitted.append(g)
+        slot_mapping: List[int] = []
+        for g in admitted:
+            seq = g.seqs[0]
+            table = {seq.seq_id: sched.block_manager.get_block_table(seq)}
+            compute_slot_mapping(False, slot_mapping, seq.seq_id, seq.get_len(), 0, 0,
+                                 self.cache_config.block_size, table)
+        slots = torch.tensor(slot_mapping, dtype=torch.int64, device=self.device)
+        T = slots.numel()
+        for kv in self.worker.cache_engine.gpu_cache:
+            kc, vc = PagedAttention.split_kv_cache(kv, cfg.num_key_value_heads, cfg.head_dim)
+            for s0 in range(0, T, 8192):
+                n = min(8192, T - s0)
+                k = (torch.randn(n, cfg.num_key_value_heads, cfg.head_dim, generator=gen, device=self.device) * 0.5).to(cfg.dtype)
+                v = (torch.randn(n, cfg.num_key_value_heads, cfg.head_dim, generator=gen, device=self.device) * 0.5).to(cfg.dtype)
+                ops.reshape_and_cache(k, v, kc, vc, slots[s0:s0 + n], "auto", 1.0, 1.0)
+        for g in admitted:
+            seq = g.seqs[0]
+            seq.data.update_num_computed_tokens(seq.get_len())
+            seq.append_token_id(int(torch.randint(0, cfg.vocab_size, (1,), generator=gen, device=self.device)), 0.0)
+        torch.cuda.synchronize(self.device)

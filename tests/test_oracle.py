@@ -95,8 +95,13 @@ def test_elementwise_vs_golden(tag, dtype):
     assert torch.allclose(o.float(), load_t(z, f"rms_out_{tag}").float(), **tol)  # <= 2 ulp (two roundings in T vs one after an fp32 multiply)
     x2, r2 = x.clone(), res.clone()
     oracle.fused_add_rms_norm(x2, r2, w, 1e-6)
-    assert torch.allclose(x2.float(), load_t(z, f"fused_out_{tag}").float(), **tol)
-    assert torch.equal(r2.float(), load_t(z, f"fused_res_{tag}").float())  # the residual add: one rounding both sides
+    # The reference's CPU backend, built without -mavx512bf16 (g++ < 12.3, cmake/cpu_extension.cmake:59-66),
+    # stores fp32 -> bf16 by TRUNCATION (csrc/cpu/cpu_types_x86.hpp:482-488) where its GPU kernels -- and
+    # this oracle -- round to nearest: the residual differs by <= 1 ulp, the normed output by <= 4 ulp.
+    tol4 = dict(rtol=2 ** -5, atol=1e-6) if dtype == torch.bfloat16 else tol
+    assert torch.allclose(x2.float(), load_t(z, f"fused_out_{tag}").float(), **tol4)
+    assert torch.allclose(r2.float(), load_t(z, f"fused_res_{tag}").float(),
+                          rtol=2 ** -7 if dtype == torch.bfloat16 else 0, atol=0)
     qk, cache, pos = load_t(z, f"rope_in_{tag}"), load_t(z, f"rope_cache_{tag}"), torch.from_numpy(z["rope_pos"])
     H, KVH, D = 4, 2, 64
     for neox, key in ((True, "neox"), (False, "gptj")):
