@@ -33,6 +33,8 @@ HIP_SOURCES = [
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# tuning experiments: e.g. LVLLM_EXTRA_HIPCC_FLAGS="-DLVLLM_ATTN_NBUF=2 -DLVLLM_ATTN_TUNE_ONLY"
+EXTRA_FLAGS = os.environ.get("LVLLM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(target, deps):
@@ -67,7 +69,8 @@ def build_kernels(verbose=False):
         objs.append(o)
         if _newer(o, [s] + hdrs):
             jobs.append([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
-                         "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", s, "-o", o])
+                         "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + EXTRA_FLAGS +
+                        ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             for out in ex.map(_run, jobs):

@@ -198,6 +198,12 @@ extern "C" int lvllm_paged_attention_v1(
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
   if (num_seqs == 0) return 0;
+  if (max_num_blocks_per_seq <= 0) {
+    // no block table at all: every context is empty, the result is zeros
+    const size_t bytes = (size_t)num_seqs * num_heads * head_size * (dtype == LVLLM_F32 ? 4 : 2);
+    if (hipMemsetAsync(out, 0, bytes, (hipStream_t)stream) != hipSuccess) LV_CHECK(false, "hipMemsetAsync failed");
+    return 0;
+  }
   AttnParams p{};
   p.out = out; p.exp_sums = nullptr; p.max_logits = nullptr;
   p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
@@ -244,6 +250,12 @@ extern "C" int lvllm_paged_attention_v2_phases(
                (int64_t)max_num_partitions * kPartitionSize >= (int64_t)max_seq_len,
            "exp_sums.size(-1) must be >= ceil(max_seq_len / 512)");
   if (num_seqs == 0) return 0;
+  if (max_num_blocks_per_seq <= 0) {
+    // no block table at all: every context is empty, the result is zeros
+    const size_t bytes = (size_t)num_seqs * num_heads * head_size * (dtype == LVLLM_F32 ? 4 : 2);
+    if (hipMemsetAsync(out, 0, bytes, (hipStream_t)stream) != hipSuccess) LV_CHECK(false, "hipMemsetAsync failed");
+    return 0;
+  }
   AttnParams p{};
   p.out = tmp_out; p.exp_sums = exp_sums; p.max_logits = max_logits;
   p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;

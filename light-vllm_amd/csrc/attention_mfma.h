@@ -83,6 +83,10 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 
 // gfx9-family raw buffer descriptor word 3 (32-bit data format, no swizzle)
 constexpr int kSrdFlags = 0x00020000;
+// cache policy of the K/V stream loads (buffer_load aux bits; 2 = nt: data read once)
+#ifndef LVLLM_ATTN_AUX
+#define LVLLM_ATTN_AUX 2  // measured: nt loads -8 % (profiles/r01_tuning.md)
+#endif
 
 // ---------------------------------------------------------------------------
 // The kernel.  Unit of work = one 16-token tile of one kv head:
@@ -95,12 +99,16 @@ constexpr int kSrdFlags = 0x00020000;
 // the compiler's vmcnt waits stay exact (the next tiles remain in flight
 // while one tile is multiplied).
 // ---------------------------------------------------------------------------
+#ifndef LVLLM_ATTN_MIN_WAVES_PER_SIMD
+#define LVLLM_ATTN_MIN_WAVES_PER_SIMD 2
+#endif
 template <typename T, int D, int BS, int NWAVES, int NBUF>
-__global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
+    const AttnParams p) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
   static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
-  static_assert(NBUF == 2 || NBUF == 3, "register sets per wave");
+  static_assert(NBUF >= 1 && NBUF <= 3, "register sets per wave");
   constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
   constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
   constexpr int DPAD = NDT * 16;
@@ -155,9 +163,12 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
 
   // Physical block number of this wave's j-th tile.  The index is wave-uniform, so
   // this is a scalar load; callers request it one rotation before it is needed.
+  // The index is clamped by the table width (a kernel argument), not by the sequence length,
+  // so the first block-table loads do not wait for the seq_lens load.
+  const int last_block = p.max_num_blocks_per_seq - 1;
   auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
-    const int lt = min(wave + j * NWAVES, ntiles - 1);  // clamp: stay inside the table row
-    return (ntiles > 0) ? block_table[((tile0 + lt) << 4) / BS] : 0;
+    const int blk = ((tile0 + wave + j * NWAVES) << 4) / BS;
+    return block_table[min(blk, last_block)];
   };
 
   // running softmax state of this wave: column c of lanes (g, c) is head head0 + c
@@ -181,10 +192,10 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
     // chunks with d8 >= D/8 and rows with d >= D fall outside kHeadBytes -> zeros
 #pragma unroll
     for (int jj = 0; jj < NS; ++jj)
-      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, 0);
+      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
 #pragma unroll
     for (int t = 0; t < NDT; ++t)
-      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
+      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
   };
 
   // One tile: S = K.Q^T (NS MFMAs), online softmax, O^T += V^T.P^T (NDT MFMAs).
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
     u32x2_t v0[NDT], v1[NDT], v2[NDT];
     int bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
     load_tile(k0, v0, 0, bn0);
-    bn0 = block_number(3);
+    bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
     if constexpr (NBUF == 3) {
       load_tile(k1, v1, 1, bn1);
       bn1 = block_number(4);
@@ -257,6 +268,13 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
         load_tile(k1, v1, j + 4, bn1);
         bn1 = block_number(j + 7);
         compute_tile(k2, v2, j + 2);
+      }
+    } else if constexpr (NBUF == 1) {
+      (void)bn1; (void)bn2;
+      for (int j = 0; j < nmy; ++j) {
+        compute_tile(k0, v0, j);
+        load_tile(k0, v0, j + 1, bn0);
+        bn0 = block_number(j + 2);
       }
     } else {
       (void)bn2;
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(NWAVES * 64) void paged_attn_mfma_kernel(const Attn
 
 // ---- host side: instantiation ladder (head size x block size x waves) ----
 #ifndef LVLLM_ATTN_NBUF
-#define LVLLM_ATTN_NBUF 3
+#define LVLLM_ATTN_NBUF 2  // measured: 2 sets beat 3 by 13 % at bs32/seq1024 (profiles/r01_tuning.md)
 #endif
 
 template <typename T, int D, int BS, int NWAVES>
@@ -342,8 +360,11 @@ static void launch_mfma_waves(const AttnParams& p, int num_seqs, int num_parts,
   const int G = p.num_heads / p.num_kv_heads;
   const bool lds8_ok =
       (size_t)8 * (G < 16 ? G : 16) * (((D + 15) / 16) * 16) * 4 + 1024 <= 160 * 1024;
-  if (tiles >= 64 && lds8_ok)
-    launch_mfma<T, D, BS, 8>(p, num_seqs, num_parts, stream);
+#ifndef LVLLM_ATTN_NWAVES_LONG
+#define LVLLM_ATTN_NWAVES_LONG 8
+#endif
+  if (tiles >= 16 && lds8_ok)  // >= 2 tiles per wave
+    launch_mfma<T, D, BS, LVLLM_ATTN_NWAVES_LONG>(p, num_seqs, num_parts, stream);
   else
     launch_mfma<T, D, BS, 4>(p, num_seqs, num_parts, stream);
 }
@@ -353,7 +374,9 @@ static int launch_mfma_bs(const AttnParams& p, int block_size, int num_seqs, int
                           int max_tokens_per_wg, hipStream_t stream) {
   switch (block_size) {
     case 16: launch_mfma_waves<T, D, 16>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
+#ifndef LVLLM_ATTN_TUNE_ONLY
     case 32: launch_mfma_waves<T, D, 32>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
+#endif
     default: LV_CHECK(false, "Unsupported block size: " + std::to_string(block_size));
   }
   return 0;
@@ -368,7 +391,11 @@ int launch_mfma_hs(const AttnParams& p, int head_size, int block_size, int num_s
   switch (head_size) {
 #define LV_HS(D_) \
   case D_: return launch_mfma_bs<T, D_>(p, block_size, num_seqs, num_parts, max_tokens_per_wg, stream);
+#ifdef LVLLM_ATTN_TUNE_ONLY  // tuning builds: one shape, seconds to compile
+    LV_HS(128)
+#else
     LV_HS(64) LV_HS(80) LV_HS(96) LV_HS(112) LV_HS(120) LV_HS(128) LV_HS(192) LV_HS(256)
+#endif
 #undef LV_HS
     default: LV_CHECK(false, "Unsupported head size: " + std::to_string(head_size));
   }
