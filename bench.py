@@ -159,21 +159,19 @@ def cpu_baseline_leg(engine, B, budget_s=20.0):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
+    from light_vllm_amd.engine.replicas import ReplicaGroup
+
+    # one process per GPU; RCCL is used for the barrier and the max-over-ranks clock only
+    group = ReplicaGroup(device=torch.device(dev))
+    rank, world = group.rank, group.world_size
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     B, ctx = a.batch_size, a.context
     on_the_fly = 2 if a.scheduling == "async" else 1
@@ -209,8 +207,7 @@ def main():
         step(i, a.warmup)
     assert engine.num_on_the_fly == 0
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     tokens = 0
@@ -218,16 +215,12 @@ def main():
         tokens += len(step(i, a.steps))
     assert engine.num_on_the_fly == 0
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    group.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     assert tokens == a.steps * B, (tokens, a.steps, B)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * tokens / elapsed
+    elapsed = group.max(elapsed)            # slowest replica's clock
+    value = group.sum(tokens) / elapsed      # whole-job tokens/s
 
     k = kernel_leg(engine, B, a.kernel_iters)
     cpu = None
@@ -256,9 +249,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.shutdown()
 
 
 if __name__ == "__main__":

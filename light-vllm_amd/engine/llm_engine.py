@@ -61,6 +61,9 @@ class Worker:
         self.use_hip_graph = use_hip_graph
         self.max_model_len = max_model_len
         self.graphs: Optional[DecodeGraphPool] = None
+        # tests: keep the logits of the sampled rows of the last eager step
+        self.capture_logits = False
+        self.last_logits: Optional[torch.Tensor] = None
 
     def determine_num_available_blocks(self) -> Tuple[int, int]:
         """Blocks that fit beside the weights (gpu_worker.py:95-143): a profile forward with no
@@ -108,7 +111,10 @@ class Worker:
             hidden = self.model.forward(mi.input_tokens, mi.input_positions, ce.gpu_cache, md)
             if len(mi.sample_indices) != hidden.shape[0]:
                 hidden = hidden[torch.tensor(mi.sample_indices, device=self.device)]
-            tokens = torch.argmax(self.model.compute_logits(hidden), dim=-1)
+            logits = self.model.compute_logits(hidden)
+            if self.capture_logits:
+                self.last_logits = logits.float().cpu()
+            tokens = torch.argmax(logits, dim=-1)
         out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, mi.sample_seq_ids)

@@ -1,0 +1,135 @@
+"""End-to-end decode loop on the GPU with a small synthetic-weight model: prompts go through the
+scheduler, block manager, input builder, prefill, then paged decode.  Logits are compared with a
+plain fp32 torch forward of the same weights with dense causal attention ("logits within fp16
+tolerance": atol = rtol = 1e-2 at the logits' scale); HIP-graph replay vs eager and
+async vs sync scheduling must give identical tokens."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dense_reference_logits(model, token_ids):
+    """fp32 forward of DecoderModel's weights over one full sequence, dense causal attention."""
+    cfg = model.cfg
+    H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    x = model.embed.float()[torch.tensor(token_ids, device=model.device)]
+    T = x.shape[0]
+    pos = torch.arange(T, device=model.device)
+    cs = model.cos_sin_cache.float()[pos]
+    cos, sin = cs[:, : D // 2], cs[:, D // 2:]
+
+    def rms(h, w):
+        return h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps) * w.float()
+
+    def rope(t):  # NeoX pairing
+        t1, t2 = t[..., : D // 2], t[..., D // 2:]
+        c, s = cos[:, None, :], sin[:, None, :]
+        return torch.cat([t1 * c - t2 * s, t2 * c + t1 * s], dim=-1)
+
+    res = x
+    h = None
+    for lw in model.layers:
+        h = rms(res, lw.input_norm)
+        qkv = h @ lw.qkv.float().T
+        q, k, v = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
+        q, k, v = rope(q.view(T, H, D)), rope(k.view(T, KVH, D)), v.view(T, KVH, D)
+        k = k.repeat_interleave(H // KVH, dim=1)
+        v = v.repeat_interleave(H // KVH, dim=1)
+        att = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(D)
+        att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool, device=x.device).tril(), float("-inf"))
+        o = torch.einsum("hqk,khd->qhd", att.softmax(-1), v).reshape(T, H * D)
+        res = res + o @ lw.o.float().T
+        h2 = rms(res, lw.post_norm)
+        gu = h2 @ lw.gate_up.float().T
+        a, b = gu.chunk(2, dim=-1)
+        res = res + (F.silu(a) * b) @ lw.down.float().T
+    return rms(res, model.final_norm) @ model.lm_head.float().T
+
+
+def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8):
+    import light_vllm_amd  # noqa: F401
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+    cfg = ModelConfig.tiny()
+    return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32),
+                     SchedulerConfig(max_num_batched_tokens=2048, max_num_seqs=max_seqs, max_model_len=512,
+                                     scheduling=scheduling, max_num_on_the_fly=2),
+                     device=DEV, use_hip_graph=graph, seed=0)
+
+
+def prompts():
+    g = torch.Generator().manual_seed(0)
+    return [torch.randint(0, 512, (n,), generator=g).tolist() for n in (5, 37, 16, 90, 1, 64)]
+
+
+def run_to_completion(engine, max_tokens=12, use_async=False):
+    for i, p in enumerate(prompts()):
+        engine.add_request(str(i), p, max_tokens=max_tokens)
+    final = {}
+    step = engine.async_step if use_async else engine.step
+    for _ in range(1000):
+        for out in step():
+            if out.finished:
+                final[out.request_id] = out.token_ids
+        if not engine.has_unfinished_requests() and engine.num_on_the_fly == 0:
+            break
+    engine.shutdown()
+    return [final[str(i)] for i in range(len(prompts()))]
+
+
+def test_logits_match_dense_fp32_reference():
+    engine = make_engine(graph=False)
+    engine.worker.capture_logits = True
+    ps = prompts()
+    for i, p in enumerate(ps):
+        engine.add_request(str(i), p, max_tokens=6)
+    logits_by_req = {str(i): [] for i in range(len(ps))}
+    toks = {}
+    while engine.has_unfinished_requests():
+        sched_before = [g.request_id for g in engine.scheduler.waiting] + \
+                       [g.request_id for g in engine.scheduler.running if not g.busy]
+        outs = engine.step()
+        lg = engine.worker.last_logits
+        assert lg.shape[0] == len(outs)
+        for row, out in zip(lg, outs):
+            logits_by_req[out.request_id].append(row)
+            toks[out.request_id] = out.token_ids
+    for i, p in enumerate(ps):
+        out_tokens = toks[str(i)]
+        full = p + out_tokens
+        ref = dense_reference_logits(engine.worker.model, full)
+        for j, row in enumerate(logits_by_req[str(i)]):
+            want = ref[len(p) - 1 + j].cpu()
+            scale = want.abs().max().item()
+            assert torch.allclose(row, want, atol=1e-2 * scale + 1e-3, rtol=1e-2), (i, j, (row - want).abs().max(), scale)
+
+
+def test_graph_replay_and_async_give_the_same_tokens():
+    eager = run_to_completion(make_engine(graph=False))
+    graph = run_to_completion(make_engine(graph=True))
+    asyn = run_to_completion(make_engine(graph=True, scheduling="async", max_seqs=3), use_async=True)
+    assert all(len(t) == 12 for t in eager)
+    assert eager == graph
+    assert eager == asyn
+
+
+def test_preemption_under_memory_pressure_keeps_results():
+    """A pool too small for all sequences forces preemption-by-recompute; generation still
+    completes with the tokens of an unconstrained run (greedy decoding is deterministic)."""
+    ref = run_to_completion(make_engine(graph=False), max_tokens=40)
+    tight = make_engine(graph=False, num_blocks=16, max_seqs=8)
+    got = run_to_completion(tight, max_tokens=40)
+    assert tight.scheduler.num_cumulative_preemption > 0
+    assert all(len(t) == 40 for t in got)
+    # a recomputed sequence re-runs its prefix through the prefill path (different summation
+    # order than paged decode): with random weights near-tied logits may flip an argmax, after
+    # which the continuations differ.  Most sequences must be identical, all must agree on a prefix.
+    same = sum(a == b for a, b in zip(got, ref))
+    assert same >= len(ref) - 2, (same, len(ref))
+    for a, b in zip(got, ref):
+        assert a[:4] == b[:4]
