@@ -163,7 +163,7 @@ def run_program(make_manager, adapter, config: Dict[str, Any], seed: int, num_op
                 for s in g.get_seqs(status=S("RUNNING")):
                     s.data.update_num_computed_tokens(1)
                     adapter.append(s, rng.randrange(vocab))
-        elif r < 0.70 and running_groups:
+        elif r < 0.70 and running_groups and not config.get("no_fork"):
             # ---- fork (parallel sampling / beam): child shares the parent's blocks ----
             g = rng.choice(running_groups)
             parent = rng.choice(g.get_seqs(status=S("RUNNING")))
@@ -192,6 +192,8 @@ def run_program(make_manager, adapter, config: Dict[str, Any], seed: int, num_op
         else:
             # ---- a sequence finishes (or a whole group is preempted by recompute) ----
             cands = live_seqs()
+            if config.get("free_running_only"):
+                cands = [s for s in cands if s.status == S("RUNNING")]
             if not cands:
                 op.update(op="noop")
             else:
@@ -222,4 +224,25 @@ DEFAULT_CONFIGS = [
     # no swap space: the reference double-frees when it swaps a sliding-window table
     ("v1_sliding_window", dict(version="v1", block_size=8, num_gpu_blocks=64, num_cpu_blocks=0, watermark=0.01,
                                sliding_window=20, enable_caching=False), 5, 400),
+]
+
+
+# version 2 (block_manager_v2.py).  Options avoid states in which the REFERENCE itself raises:
+#   fork and swap never meet in one program: v2 swaps a group sequence by sequence and allocates a
+#     destination block per sequence even for blocks the group shares, while can_swap_out counts each
+#     shared block once -> NoFreeBlocksError inside swap_out (cpu_gpu_block_allocator.py:236-262)
+#   free_running_only: freeing a swapped-out sequence with prefix caching stamps CPU block ids on the
+#     GPU allocator's tracker (KeyError, block_manager_v2.py:241-247)
+#   sliding window: a table holds null blocks that fork and swap cannot handle
+V2_CONFIGS = [
+    ("v2_naive_fork", dict(version="v2", block_size=16, num_gpu_blocks=96, num_cpu_blocks=0, watermark=0.01,
+                           sliding_window=None, enable_caching=False), 11, 400),
+    ("v2_naive_swap", dict(version="v2", block_size=8, num_gpu_blocks=40, num_cpu_blocks=24, watermark=0.05,
+                           sliding_window=None, enable_caching=False, no_fork=True), 12, 500),
+    ("v2_cached_fork", dict(version="v2", block_size=16, num_gpu_blocks=64, num_cpu_blocks=0, watermark=0.01,
+                            sliding_window=None, enable_caching=True), 13, 500),
+    ("v2_cached_swap", dict(version="v2", block_size=4, num_gpu_blocks=48, num_cpu_blocks=48, watermark=0.0,
+                            sliding_window=None, enable_caching=True, free_running_only=True, no_fork=True), 14, 700),
+    ("v2_sliding_window", dict(version="v2", block_size=8, num_gpu_blocks=64, num_cpu_blocks=0, watermark=0.01,
+                               sliding_window=20, enable_caching=False, no_fork=True), 15, 400),
 ]
