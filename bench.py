@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
     ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--library-gemm", action="store_true", help="dense projections through hipBLASLt (F.linear)")
+    ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=96)
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
@@ -177,6 +179,8 @@ def main():
     on_the_fly = 2 if a.scheduling == "async" else 1
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    cfg.pack_weights = not a.library_gemm
+    cfg.fuse_decode_ops = not a.no_fusion
     total_steps = a.steps + a.warmup
     max_len = ctx + total_steps // on_the_fly + 8
     max_model_len = (max_len + 511) // 512 * 512

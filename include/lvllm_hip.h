@@ -167,6 +167,40 @@ int lvllm_rotary_embedding(const int64_t* positions, void* query, void* key,
 int lvllm_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
                        int dtype, void* stream);
 
+/* ---- extension (no counterpart operator in the reference): weight-streaming GEMM --------
+ * Y[M,N] = X[M,K] . W[N,K]^T (+ bias[N]) for decode batches (M <= 64), bf16/f16, fp32
+ * accumulate: the dense projections of light_vllm/backends/linear.py:134-139 (F.linear) at
+ * decode sizes, where they are HBM-bound.  Returns 3 when the shape is outside the kernel's
+ * envelope (caller uses a library GEMM).  `workspace`: lvllm_skinny_gemm_workspace_bytes()
+ * bytes of device memory (fp32 partials when K is split over workgroups), may be NULL if 0.
+ * `packed` != 0: W is in the MFMA-fragment order written by lvllm_pack_weight
+ * ([N/16][K/32][4][16][8]); every wave load is then one contiguous KiB. */
+int64_t lvllm_skinny_gemm_workspace_bytes(int M, int N, int K);
+int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                      int K, int64_t ldx, int dtype, int packed, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+/* Reorders row-major W[N,K] into the packed order (out of place; N % 16 == 0, K % 32 == 0). */
+int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream);
+/* As lvllm_skinny_gemm, plus: act = 1 -> X rows are [gate | up] (2K wide) and the kernel
+ * multiplies by T(T(silu(gate)) * up) (silu_and_mul fused into the down projection);
+ * partial_out != 0 -> the fp32 partial sums [ksplit, M, N] stay in `workspace` (at least
+ * max(ksplit,1)*M*N*4 bytes), y is not written, *ksplit_out = number of partials. */
+int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                         int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
+                         int* ksplit_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* fused_add_rms_norm whose input is the fp32 split-K partials of the preceding projection:
+ * x = T(sum_s partials[s]); residual = T(x + residual); out = norm(residual) * weight. */
+int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,
+                                    int num_partials, const void* weight, float epsilon,
+                                    int num_tokens, int hidden_size, int dtype, void* stream);
+/* rotary_embedding (rot_dim == head_size) and reshape_and_cache of the rotated key and the
+ * value in one launch; returns 3 outside its envelope (use the two separate entry points). */
+int lvllm_rotary_embedding_and_cache(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

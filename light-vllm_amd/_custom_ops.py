@@ -22,145 +22,86 @@ def is_custom_op_supported(op_name: str) -> bool:
     return op is not None
 
 
-# activation ops
+_C = torch.ops._C
+_CACHE = torch.ops._C_cache_ops
+_UTILS = torch.ops._C_cuda_utils
+
+# Optional trailing arguments of the two attention operators and their defaults
+# (_custom_ops.py:86-90,117-121 of the reference).
+_BS_DEFAULTS = dict(tp_rank=0, blocksparse_local_blocks=0, blocksparse_vert_stride=0,
+                    blocksparse_block_size=64, blocksparse_head_sliding_step=0)
+
+
 def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
-    torch.ops._C.silu_and_mul(out, x)
+    _C.silu_and_mul(out, x)
 
 
-# page attention ops
-def paged_attention_v1(
-    out: torch.Tensor,
-    query: torch.Tensor,
-    key_cache: torch.Tensor,
-    value_cache: torch.Tensor,
-    num_kv_heads: int,
-    scale: float,
-    block_tables: torch.Tensor,
-    seq_lens: torch.Tensor,
-    block_size: int,
-    max_seq_len: int,
-    alibi_slopes: Optional[torch.Tensor],
-    kv_cache_dtype: str,
-    k_scale: float,
-    v_scale: float,
-    tp_rank: int = 0,
-    blocksparse_local_blocks: int = 0,
-    blocksparse_vert_stride: int = 0,
-    blocksparse_block_size: int = 64,
-    blocksparse_head_sliding_step: int = 0,
-) -> None:
-    torch.ops._C.paged_attention_v1(
-        out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
-        seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
-        k_scale, v_scale, tp_rank, blocksparse_local_blocks,
-        blocksparse_vert_stride, blocksparse_block_size,
-        blocksparse_head_sliding_step)
+def paged_attention_v1(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                       max_seq_len: int, alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
+                       k_scale: float, v_scale: float, tp_rank: int = 0,
+                       blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64, blocksparse_head_sliding_step: int = 0) -> None:
+    _C.paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                          block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale, v_scale, tp_rank,
+                          blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                          blocksparse_head_sliding_step)
 
 
-def paged_attention_v2(
-    out: torch.Tensor,
-    exp_sum: torch.Tensor,
-    max_logits: torch.Tensor,
-    tmp_out: torch.Tensor,
-    query: torch.Tensor,
-    key_cache: torch.Tensor,
-    value_cache: torch.Tensor,
-    num_kv_heads: int,
-    scale: float,
-    block_tables: torch.Tensor,
-    seq_lens: torch.Tensor,
-    block_size: int,
-    max_seq_len: int,
-    alibi_slopes: Optional[torch.Tensor],
-    kv_cache_dtype: str,
-    k_scale: float,
-    v_scale: float,
-    tp_rank: int = 0,
-    blocksparse_local_blocks: int = 0,
-    blocksparse_vert_stride: int = 0,
-    blocksparse_block_size: int = 64,
-    blocksparse_head_sliding_step: int = 0,
-) -> None:
-    torch.ops._C.paged_attention_v2(
-        out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache,
-        num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-        alibi_slopes, kv_cache_dtype, k_scale, v_scale, tp_rank,
-        blocksparse_local_blocks, blocksparse_vert_stride,
-        blocksparse_block_size, blocksparse_head_sliding_step)
+def paged_attention_v2(out: torch.Tensor, exp_sum: torch.Tensor, max_logits: torch.Tensor,
+                       tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                       max_seq_len: int, alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
+                       k_scale: float, v_scale: float, tp_rank: int = 0,
+                       blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64, blocksparse_head_sliding_step: int = 0) -> None:
+    _C.paged_attention_v2(out, exp_sum, max_logits, tmp_out, query, key_cache, value_cache, num_kv_heads,
+                          scale, block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
+                          kv_cache_dtype, k_scale, v_scale, tp_rank, blocksparse_local_blocks,
+                          blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step)
 
 
-# pos encoding ops
-def rotary_embedding(
-    positions: torch.Tensor,
-    query: torch.Tensor,
-    key: torch.Tensor,
-    head_size: int,
-    cos_sin_cache: torch.Tensor,
-    is_neox: bool,
-) -> None:
-    torch.ops._C.rotary_embedding(positions, query, key, head_size,
-                                  cos_sin_cache, is_neox)
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    _C.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)
 
 
-# layer norm ops
-def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
-             epsilon: float) -> None:
-    torch.ops._C.rms_norm(out, input, weight, epsilon)
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    _C.rms_norm(out, input, weight, epsilon)
 
 
-def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor,
-                       weight: torch.Tensor, epsilon: float) -> None:
-    torch.ops._C.fused_add_rms_norm(input, residual, weight, epsilon)
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       epsilon: float) -> None:
+    _C.fused_add_rms_norm(input, residual, weight, epsilon)
 
 
-# cache ops
-def reshape_and_cache(
-    key: torch.Tensor,
-    value: torch.Tensor,
-    key_cache: torch.Tensor,
-    value_cache: torch.Tensor,
-    slot_mapping: torch.Tensor,
-    kv_cache_dtype: str,
-    k_scale: float,
-    v_scale: float,
-) -> None:
-    torch.ops._C_cache_ops.reshape_and_cache(key, value, key_cache,
-                                             value_cache, slot_mapping,
-                                             kv_cache_dtype, k_scale, v_scale)
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_cache_dtype: str,
+                      k_scale: float, v_scale: float) -> None:
+    _CACHE.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
 
 
-def reshape_and_cache_flash(
-    key: torch.Tensor,
-    value: torch.Tensor,
-    key_cache: torch.Tensor,
-    value_cache: torch.Tensor,
-    slot_mapping: torch.Tensor,
-    kv_cache_dtype: str,
-    k_scale: float,
-    v_scale: float,
-) -> None:
-    torch.ops._C_cache_ops.reshape_and_cache_flash(key, value, key_cache,
-                                                   value_cache, slot_mapping,
-                                                   kv_cache_dtype, k_scale,
-                                                   v_scale)
+def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, slot_mapping: torch.Tensor, kv_cache_dtype: str,
+                            k_scale: float, v_scale: float) -> None:
+    _CACHE.reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale,
+                                   v_scale)
 
 
-def copy_blocks(key_caches: List[torch.Tensor],
-                value_caches: List[torch.Tensor],
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
                 block_mapping: torch.Tensor) -> None:
-    torch.ops._C_cache_ops.copy_blocks(key_caches, value_caches, block_mapping)
+    _CACHE.copy_blocks(key_caches, value_caches, block_mapping)
 
 
-def swap_blocks(src: torch.Tensor, dst: torch.Tensor,
-                block_mapping: torch.Tensor) -> None:
-    torch.ops._C_cache_ops.swap_blocks(src, dst, block_mapping)
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    _CACHE.swap_blocks(src, dst, block_mapping)
 
 
 def get_device_attribute(attribute: int, device: int) -> int:
-    return torch.ops._C_cuda_utils.get_device_attribute(attribute, device)
+    return _UTILS.get_device_attribute(attribute, device)
 
 
 def get_max_shared_memory_per_block_device_attribute(device: int) -> int:
-    # ruff: noqa: E501
-    return torch.ops._C_cuda_utils.get_max_shared_memory_per_block_device_attribute(
-        device)
+    return _UTILS.get_max_shared_memory_per_block_device_attribute(device)

@@ -312,6 +312,30 @@ class PagedAttnImpl:
                 force_version="v1" if use_v1 else "v2", scratch=scratch, output=output[npt:])
         return output.view(num_tokens, hidden_size)
 
+    # ---- entry points for a caller that has already written K/V (fused rope + cache write) ----
+    def split_kv_cache(self, kv_cache: torch.Tensor):
+        return PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
+
+    def decode_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                         attn_metadata: PagedAttnMetadata) -> torch.Tensor:
+        """Decode attention only (all tokens are decode tokens, K/V already in the cache)."""
+        num_tokens, hidden_size = query.shape
+        dq = query.view(-1, self.num_heads, self.head_size)
+        md = attn_metadata.decode_metadata
+        max_len = md.max_decode_seq_len
+        force = self.decode_version
+        use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads,
+                                                                      self.num_heads, max_len)
+        scratch = None if use_v1 else self._v2_scratch(dq.shape[0], max_len, dq)
+        alibi = self.alibi_slopes
+        if alibi is not None and alibi.device != dq.device:
+            alibi = self.alibi_slopes = alibi.to(dq.device)
+        out = torch.empty(dq.shape, dtype=dq.dtype, device=dq.device)
+        PagedAttention.forward_decode(dq, key_cache, value_cache, md.block_tables, md.seq_lens_tensor, max_len,
+                                      self.kv_cache_dtype, self.num_kv_heads, self.scale, alibi, 1.0, 1.0,
+                                      force_version="v1" if use_v1 else "v2", scratch=scratch, output=out)
+        return out.view(num_tokens, hidden_size)
+
     # ---- prompt attention (torch SDPA; not this round's hot path) ----
     def _prefill(self, q, k, v, key_cache, value_cache, meta: PagedAttnMetadata, out) -> None:
         qs = 0

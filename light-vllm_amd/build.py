@@ -30,6 +30,7 @@ HIP_SOURCES = [
     "attention.hip",
     "attention_bf16.hip",
     "attention_f16.hip",
+    "skinny_gemm.hip",
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

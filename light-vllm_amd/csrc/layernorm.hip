@@ -79,6 +79,79 @@ __global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUS
   }
 }
 
+// fused_add_rms_norm whose `input` arrives as fp32 split-K partials [S, M, hidden] of the
+// preceding down projection (csrc/skinny_gemm.hip): x = T(sum_s partial_s) -- the value the GEMM's
+// own reduce pass would have written -- then exactly fused_add_rms_norm.  One launch less per layer.
+template <typename T>
+__global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [M, hidden] normed output
+                                                 typename T::store_t* __restrict__ res,
+                                                 const float* __restrict__ partials, const int num_partials,
+                                                 const int64_t partial_stride,  // M * hidden
+                                                 const typename T::store_t* __restrict__ weight,
+                                                 const float epsilon, const int hidden_size) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;  // 8
+  __shared__ float red[16];
+  __shared__ float s_scale;
+  const int nvec = hidden_size / N;
+  const int64_t row = (int64_t)blockIdx.x * nvec;
+  V* res_v = reinterpret_cast<V*>(res) + row;
+  V* out_v = reinterpret_cast<V*>(out) + row;
+  const V* w_v = reinterpret_cast<const V*>(weight);
+  const float* prow = partials + (int64_t)blockIdx.x * hidden_size;
+
+  V cache[kMaxCached];
+  float var = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    for (int sp = 0; sp < num_partials; ++sp) {
+      const float4* p4 = reinterpret_cast<const float4*>(prow + sp * partial_stride + (int64_t)i * N);
+      const float4 a = p4[0], b = p4[1];
+      acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+      acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+    const V r = res_v[i];
+    V x;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const typename T::store_t y = T::from_float(acc[j]);  // the GEMM output, rounded to T
+      x.v[j] = T::from_float(T::to_float(y) + T::to_float(r.v[j]));
+      const float f = T::to_float(x.v[j]);
+      var += f * f;
+    }
+    res_v[i] = x;
+#pragma unroll
+    for (int k = 0; k < kMaxCached; ++k)
+      if (c == k) cache[k] = x;
+  }
+  var = block_sum(var, red);
+  if (threadIdx.x == 0) s_scale = rsqrtf(var / hidden_size + epsilon);
+  __syncthreads();
+  const float s = s_scale;
+  c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V x;
+    if (c < kMaxCached) {
+#pragma unroll
+      for (int k = 0; k < kMaxCached; ++k)
+        if (c == k) x = cache[k];
+    } else {
+      x = res_v[i];
+    }
+    const V w = w_v[i];
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const typename T::store_t t = T::from_float(T::to_float(x.v[j]) * s);
+      o.v[j] = T::from_float(T::to_float(t) * T::to_float(w.v[j]));
+    }
+    out_v[i] = o;
+  }
+}
+
 // element-wise path for rows that are not 16-byte friendly
 template <typename T, bool FUSED_ADD>
 __global__ void rms_norm_scalar_kernel(typename T::store_t* out,
@@ -155,6 +228,32 @@ extern "C" int lvllm_fused_add_rms_norm(void* input, void* residual, const void*
   LV_DISPATCH_DTYPE(dtype, (launch_rms<scalar_t, true>(input, residual, input, weight, epsilon,
                                                        num_tokens, hidden_size,
                                                        (hipStream_t)stream)));
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+// out = norm(T(sum_s partials[s]) + residual) * weight, residual updated in place; partials fp32
+// [num_partials, num_tokens, hidden_size].  16-bit element types, hidden_size % 8 == 0.
+extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,
+                                               int num_partials, const void* weight, float epsilon,
+                                               int num_tokens, int hidden_size, int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit element types only");
+  LV_CHECK(hidden_size % 8 == 0 && num_partials >= 1, "hidden_size must be a multiple of 8");
+  LV_CHECK((((uintptr_t)out | (uintptr_t)residual | (uintptr_t)partials | (uintptr_t)weight) & 15) == 0,
+           "pointers must be 16-byte aligned");
+  const int nvec = hidden_size / 8;
+  int threads = ((nvec + 63) / 64) * 64;
+  threads = threads > 1024 ? 1024 : threads;
+  const int64_t stride = (int64_t)num_tokens * hidden_size;
+  if (dtype == LVLLM_BF16)
+    hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<BF16>), dim3(num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
+                       (const uint16_t*)weight, epsilon, hidden_size);
+  else
+    hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<F16>), dim3(num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
+                       (const uint16_t*)weight, epsilon, hidden_size);
   LV_LAUNCH_CHECK();
   return 0;
 }

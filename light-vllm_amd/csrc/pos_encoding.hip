@@ -93,6 +93,76 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
   }
 }
 
+// Fused decode-step epilogue of the QKV projection (extension; the reference runs
+// rotary_embedding and reshape_and_cache as two launches, qwen2.py:151-154 + paged_attn.py:65-85):
+// RoPE in place on q and k with the roundings above, and in the same pass the rotated k row and
+// the v row are scattered into the paged caches at slot_mapping[token] (layouts of
+// csrc/cache_kernels.cu:184-192).  rot_dim == head_size, 16-bit types, 16-byte aligned rows.
+template <typename T, bool IS_NEOX>
+__global__ void rotary_embedding_and_cache_kernel(
+    const int64_t* __restrict__ positions, typename T::store_t* __restrict__ query,
+    typename T::store_t* __restrict__ key, const typename T::store_t* __restrict__ value,
+    const typename T::store_t* __restrict__ cos_sin_cache, typename T::store_t* __restrict__ key_cache,
+    typename T::store_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
+    const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
+    const int num_kv_heads, const int head_size, const int block_size) {
+  using S = typename T::store_t;
+  using V = Vec16<T>;
+  constexpr int N = V::N;  // 8
+  const int64_t token = blockIdx.x;
+  const int64_t pos = positions[token];
+  const int embed_dim = head_size / 2;
+  const S* cos_ptr = cos_sin_cache + pos * head_size;
+  const S* sin_ptr = cos_ptr + embed_dim;
+  const int64_t slot = slot_mapping[token];
+  const int64_t block_idx = slot >= 0 ? slot / block_size : 0;
+  const int64_t block_off = slot >= 0 ? slot % block_size : 0;
+  const int cph = head_size / N;  // 16-byte chunks per head
+  // work items: rotation units of q heads, then of k heads, then v chunks
+  const int rot_units = IS_NEOX ? embed_dim / N : cph;  // per head
+  const int nq = num_heads * rot_units, nk = num_kv_heads * rot_units, nv = num_kv_heads * cph;
+  for (int i = threadIdx.x; i < nq + nk + nv; i += blockDim.x) {
+    if (i < nq + nk) {
+      const bool is_k = i >= nq;
+      const int j = is_k ? i - nq : i;
+      const int head = j / rot_units, u = j - head * rot_units;
+      S* base = is_k ? key + token * key_stride + (int64_t)head * head_size
+                     : query + token * query_stride + (int64_t)head * head_size;
+      S* kc = key_cache + ((block_idx * num_kv_heads + head) * cph) * (int64_t)block_size * N + block_off * N;
+      if constexpr (IS_NEOX) {
+        V x = *reinterpret_cast<const V*>(base + u * N);
+        V y = *reinterpret_cast<const V*>(base + embed_dim + u * N);
+        const V c = *reinterpret_cast<const V*>(cos_ptr + u * N);
+        const V sn = *reinterpret_cast<const V*>(sin_ptr + u * N);
+#pragma unroll
+        for (int e = 0; e < N; ++e) rotate<T>(x.v[e], y.v[e], c.v[e], sn.v[e]);
+        *reinterpret_cast<V*>(base + u * N) = x;
+        *reinterpret_cast<V*>(base + embed_dim + u * N) = y;
+        if (is_k && slot >= 0) {  // chunk d8 = u holds x', chunk d8 = D/16 + u holds y'
+          *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = x;
+          *reinterpret_cast<V*>(kc + (int64_t)(embed_dim / N + u) * block_size * N) = y;
+        }
+      } else {
+        V xy = *reinterpret_cast<const V*>(base + u * N);
+#pragma unroll
+        for (int e = 0; e < N / 2; ++e) {
+          const int r = u * (N / 2) + e;
+          rotate<T>(xy.v[2 * e], xy.v[2 * e + 1], cos_ptr[r], sin_ptr[r]);
+        }
+        *reinterpret_cast<V*>(base + u * N) = xy;
+        if (is_k && slot >= 0) *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = xy;
+      }
+    } else if (slot >= 0) {
+      const int j = i - nq - nk;
+      const int head = j / cph, ch = j - head * cph;
+      const V v = *reinterpret_cast<const V*>(value + token * value_stride + (int64_t)head * head_size + ch * N);
+      S* vdst = value_cache + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
+#pragma unroll
+      for (int e = 0; e < N; ++e) vdst[(int64_t)e * block_size] = v.v[e];
+    }
+  }
+}
+
 template <typename T>
 static int launch_rope(const int64_t* positions, void* query, void* key, int num_tokens,
                        int num_heads, int num_kv_heads, int head_size, int rot_dim,
@@ -137,6 +207,41 @@ extern "C" int lvllm_rotary_embedding(const int64_t* positions, void* query, voi
                                                   num_kv_heads, head_size, rot_dim, query_stride,
                                                   key_stride, cos_sin_cache, is_neox,
                                                   (hipStream_t)stream)));
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+// Extension: RoPE (rot_dim == head_size) + paged-cache write of the rotated key and the value in
+// one launch.  Returns 3 when the arguments are outside the fused kernel's envelope (the caller
+// then runs lvllm_rotary_embedding and lvllm_reshape_and_cache).
+extern "C" int lvllm_rotary_embedding_and_cache(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  const bool ok = (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && rot_dim == head_size && head_size % 16 == 0 &&
+                  (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)cos_sin_cache |
+                    (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
+                  (query_stride % 8) == 0 && (key_stride % 8) == 0 && (value_stride % 8) == 0;
+  if (!ok) {
+    set_error("lvllm_rotary_embedding_and_cache: arguments outside the fused kernel's envelope");
+    return 3;
+  }
+  const int units = (num_heads + num_kv_heads) * (is_neox ? head_size / 16 : head_size / 8) + num_kv_heads * head_size / 8;
+  int threads = ((units + 63) / 64) * 64;
+  threads = threads > 512 ? 512 : threads;
+#define LV_RC(T_, NEOX_)                                                                                   \
+  hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_>), dim3(num_tokens), dim3(threads), 0,   \
+                     (hipStream_t)stream, positions, (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value, \
+                     (const uint16_t*)cos_sin_cache, (uint16_t*)key_cache, (uint16_t*)value_cache, slot_mapping, \
+                     query_stride, key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size)
+  if (dtype == LVLLM_BF16) {
+    if (is_neox) LV_RC(BF16, true); else LV_RC(BF16, false);
+  } else {
+    if (is_neox) LV_RC(F16, true); else LV_RC(F16, false);
+  }
+#undef LV_RC
   LV_LAUNCH_CHECK();
   return 0;
 }

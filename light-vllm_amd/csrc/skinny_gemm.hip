@@ -1,0 +1,388 @@
+// Weight-streaming GEMM for decode batches on gfx950:  Y[M,N] = X[M,K] . W[N,K]^T (+ bias),
+// M <= 64 rows (one decode step's tokens), bf16/f16 in, fp32 accumulate.
+//
+// At M <= 64 a projection is a stream of W through the chip exactly once: the roofline is HBM
+// (2 bytes per weight), not MFMA.  hipBLASLt's M=32 kernels reach 2.5-4.4 TB/s on the shapes of
+// an 8B model (profiles/r01_bench_kernel_stats.csv); this kernel is organised like the
+// paged-attention kernel instead:
+//   * the activations live in REGISTERS: wave w of a workgroup owns a fixed K slice (up to 16
+//     k-steps of 32) and keeps its X fragments (B operand of v_mfma_f32_16x16x32) for the whole
+//     launch; they are read once per workgroup from L2;
+//   * W goes HBM -> VGPR -> MFMA A operand with no LDS staging: lane (g, c) of a wave loads the
+//     16 bytes W[n0 + c][k0 + 8g ..], which is its A fragment; 8 such loads per unit, two units in
+//     flight per wave, 8 waves per CU;
+//   * the 8 waves of a workgroup split K; their 16x(16*MT) partial tiles meet in LDS
+//     (double-buffered, one barrier per n-tile) and MT waves write the bf16 result;
+//   * K > 4096 is split over workgroups as well (blockIdx.y); partials go to an fp32 workspace and
+//     a small second kernel adds them (and the bias).
+// Loads outside the problem (k-steps past K, rows past N) use an out-of-range buffer offset and
+// return zeros without touching memory, so the loop is branch-free.
+//
+// Weight layouts.  With row-major W[N,K] a wave-wide fragment load touches 16 rows x 64 bytes
+// (half cache lines): correct, but the texture addresser works twice per byte and the stream tops
+// out near 4 TB/s.  Weights are static, so they can be PACKED once at load time into the order the
+// MFMA wants -- [N/16][K/32][g = 4][c = 16][8 elements], i.e. one contiguous 1 KiB per (n-tile,
+// k-step), the same shape as a paged K-cache tile -- and then every wave load is one contiguous
+// KiB (lvllm_pack_weight / `packed` below).
+#include "common.h"
+
+namespace lvllm {
+
+typedef __bf16 g_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 g_f16x8_t __attribute__((ext_vector_type(8)));
+typedef float g_f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int g_u32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ g_f32x4_t gemm_mfma(g_u32x4_t a, g_u32x4_t b, g_f32x4_t c);
+template <>
+__device__ __forceinline__ g_f32x4_t gemm_mfma<BF16>(g_u32x4_t a, g_u32x4_t b, g_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8_t, a),
+                                                 __builtin_bit_cast(g_bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ g_f32x4_t gemm_mfma<F16>(g_u32x4_t a, g_u32x4_t b, g_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(g_f16x8_t, a),
+                                                __builtin_bit_cast(g_f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kGemmWaves = 8;
+constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load returns 0
+#ifndef LVLLM_GEMM_AUX
+#define LVLLM_GEMM_AUX 2  // nt: weights are read once per launch
+#endif
+#ifndef LVLLM_GEMM_NT
+#define LVLLM_GEMM_NT 8   // partial slabs (n-tiles x m-tiles) accumulated between two wave meetings
+#endif
+
+template <typename T, int MT, int KSTEPS, bool PACKED, int NT>
+__global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
+    typename T::store_t* __restrict__ y,   // [M, N]            (ksplit == 1)
+    float* __restrict__ partial,           // [ksplit, M, N]    (ksplit > 1)
+    const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
+    const typename T::store_t* __restrict__ bias, const int M, const int N, const int K,
+    const int64_t ldx, const int steps_per_wave, const int ntiles, const int act) {
+  using S = typename T::store_t;
+  constexpr int HALF = KSTEPS / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  g_f32x4_t* red = reinterpret_cast<g_f32x4_t*>(smem_raw);  // [2][waves][NT * MT][64]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int total_steps = K >> 5;
+  const int step0 = (blockIdx.y * kGemmWaves + wave) * steps_per_wave;  // first k-step of this wave
+  int nvalid = total_steps - step0;                                     // k-steps that exist
+  nvalid = nvalid < 0 ? 0 : (nvalid > steps_per_wave ? steps_per_wave : nvalid);
+
+  // ---- X fragments: X[m = 16 mt + c][k = 32 (step0 + s) + 8 g ..], kept for the whole launch ----
+  g_u32x4_t xf[MT][KSTEPS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + c;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
+      if (m < M && s < nvalid) {
+        const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
+        g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
+        if (act == 1) {
+          // fused SwiGLU gate: the row holds [gate (K) | up (K)]; X = T(T(silu(gate)) * up), the
+          // roundings of silu_and_mul (activation.hip), so the fused path is bit-identical
+          const g_u32x4_t u = *reinterpret_cast<const g_u32x4_t*>(src + K);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+              const S gs = (S)((v[q] >> (16 * hlf)) & 0xffffu), us = (S)((u[q] >> (16 * hlf)) & 0xffffu);
+              const float gf = T::to_float(gs);
+              const S a = T::from_float(gf / (1.0f + expf(-gf)));
+              out |= (uint32_t)T::from_float(T::to_float(a) * T::to_float(us)) << (16 * hlf);
+            }
+            v[q] = out;
+          }
+        }
+        xf[mt][s] = v;
+      }
+    }
+  }
+
+  __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)N * K * 2), 0x00020000);
+  // byte offset of this lane inside a 16-row tile at k-step step0, the byte stride between
+  // k-steps, and between tiles
+  const unsigned lane_off = PACKED ? (unsigned)(lane * 16 + step0 * 1024)
+                                   : (unsigned)(((int64_t)c * K + (int64_t)step0 * 32 + 8 * g) * 2);
+  const unsigned step_stride = PACKED ? 1024u : 64u;
+  const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2);
+
+  const int my_tiles_ld = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  auto load_unit = [&](g_u32x4_t (&a)[HALF], const int i, const int h) __attribute__((always_inline)) {
+    const int t = blockIdx.x + i * gridDim.x;  // n-tile; h: which half of the wave's k-steps
+    const bool row_ok = i < my_tiles_ld && 16 * t + c < N;
+    const unsigned base = lane_off + (unsigned)t * tile_stride;
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) {
+      const int ks = h * HALF + s;
+      const unsigned off = (row_ok && ks < nvalid) ? base + (unsigned)ks * step_stride : kOutOfRange;
+      a[s] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, LVLLM_GEMM_AUX);
+    }
+  };
+
+  // NT n-tiles are accumulated before the waves meet: one barrier per NT tiles, and the
+  // NT*MT partial slabs are summed by different waves in parallel
+  g_f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[j][mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int ngroups = (my_tiles + NT - 1) / NT;
+
+  auto finish_group = [&](const int grp) __attribute__((always_inline)) {
+#ifdef LVLLM_GEMM_NOREDUCE  // timing experiment only (wrong results): no cross-wave reduction
+    if (wave == 0 && lane == 0 && acc[0][0][0] == 12345.f) y[grp] = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    return;
+#endif
+    // LDS buffer (grp & 1): [wave][slab = j * MT + mt][lane]
+    g_f32x4_t* buf = red + (size_t)(grp & 1) * kGemmWaves * NT * MT * 64;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        buf[(wave * NT * MT + j * MT + mt) * 64 + lane] = acc[j][mt];
+        acc[j][mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();
+    for (int slab = wave; slab < NT * MT; slab += kGemmWaves) {
+      const int j = slab / MT, mt = slab - j * MT;
+      const int i = grp * NT + j;
+      if (i >= my_tiles) continue;
+      g_f32x4_t sum = buf[(0 * NT * MT + slab) * 64 + lane];
+#pragma unroll
+      for (int w2 = 1; w2 < kGemmWaves; ++w2) {
+        const g_f32x4_t v = buf[(w2 * NT * MT + slab) * 64 + lane];
+        sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+      }
+      // lane (g, c): rows n = n0 + 4g + r of column m = 16 mt + c
+      const int t = blockIdx.x + i * gridDim.x;
+      const int n0 = 16 * t + 4 * g;
+      const int m = mt * 16 + c;
+      if (m < M && n0 < N) {
+        if (partial != nullptr) {
+          float* dst = partial + ((int64_t)blockIdx.y * M + m) * N + n0;
+          *reinterpret_cast<g_f32x4_t*>(dst) = sum;
+        } else {
+          if (bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n0 + r]);
+          }
+          uint2 o;
+          o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
+          o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
+          *reinterpret_cast<uint2*>(y + (int64_t)m * N + n0) = o;
+        }
+      }
+    }
+  };
+
+  auto compute_unit = [&](const g_u32x4_t (&a)[HALF], const int h, g_f32x4_t (&ac)[MT])
+                          __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < HALF; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        ac[mt] = gemm_mfma<T>(a[s], h == 0 ? xf[mt][s] : xf[mt][HALF + s], ac[mt]);
+  };
+
+  // units: (n-tile, half of the wave's k-steps); two register sets, one unit always in flight
+  g_u32x4_t a0[HALF], a1[HALF];
+  load_unit(a0, 0, 0);
+  for (int grp = 0; grp < ngroups; ++grp) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int i = grp * NT + j;  // tiles past my_tiles load nothing (out-of-range offsets)
+      load_unit(a1, i, 1);
+      compute_unit(a0, 0, acc[j]);
+      load_unit(a0, i + 1, 0);
+      compute_unit(a1, 1, acc[j]);
+    }
+    finish_group(grp);
+  }
+}
+
+// out[m, n] = T(sum_s partial[s, m, n] + bias[n])
+template <typename T>
+__global__ void skinny_gemm_reduce_kernel(typename T::store_t* __restrict__ y,
+                                          const float* __restrict__ partial,
+                                          const typename T::store_t* __restrict__ bias,
+                                          const int64_t MN, const int N, const int ksplit) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= MN) return;
+  g_f32x4_t sum = *reinterpret_cast<const g_f32x4_t*>(partial + i);
+  for (int s = 1; s < ksplit; ++s) {
+    const g_f32x4_t v = *reinterpret_cast<const g_f32x4_t*>(partial + (int64_t)s * MN + i);
+    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+  }
+  if (bias != nullptr) {
+    const int n = (int)(i % N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n + r]);
+  }
+  uint2 o;
+  o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
+  o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
+  *reinterpret_cast<uint2*>(y + i) = o;
+}
+
+template <typename T, int MT, int KSTEPS>
+static void launch_skinny(void* y, float* partial, const void* x, const void* w, const void* bias, int M,
+                          int N, int K, int64_t ldx, int steps_per_wave, int ntiles, int groups, int ksplit,
+                          bool packed, int act, hipStream_t stream) {
+  using S = typename T::store_t;
+  constexpr int NT = LVLLM_GEMM_NT / MT > 0 ? LVLLM_GEMM_NT / MT : 1;  // NT * MT slabs per meeting
+  const size_t smem = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
+  auto kp = skinny_gemm_kernel<T, MT, KSTEPS, true, NT>;
+  auto ku = skinny_gemm_kernel<T, MT, KSTEPS, false, NT>;
+  if (smem > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)ku, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  }
+  if (packed)
+    hipLaunchKernelGGL(kp, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
+                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act);
+  else
+    hipLaunchKernelGGL(ku, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
+                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act);
+}
+
+// W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
+__global__ void pack_weight_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t nchunks,
+                                   const int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index of the destination chunk
+  if (i >= nchunks) return;
+  const int steps = K >> 5;
+  const int c = (int)(i & 15), g = (int)((i >> 4) & 3);
+  const int64_t ts = i >> 6;
+  const int64_t t = ts / steps;
+  const int s = (int)(ts - t * steps);
+  const int64_t n = t * 16 + c, k = (int64_t)s * 32 + g * 8;
+  dst[i] = src[(n * K + k) >> 3];
+}
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+// Bytes of fp32 workspace lvllm_skinny_gemm needs for this shape (0 when K is not split over
+// workgroups).
+// k-steps one wave may own: its X fragments (MT * steps * 4 VGPRs) must stay in registers
+static inline int max_steps_per_wave(int M) { return M <= 32 ? 16 : 8; }
+
+extern "C" int64_t lvllm_skinny_gemm_workspace_bytes(int M, int N, int K) {
+  const int total_steps = K / 32;
+  const int cap = kGemmWaves * max_steps_per_wave(M);
+  const int ksplit = (total_steps + cap - 1) / cap;
+  return ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0;
+}
+
+// Y[M,N] = X[M,K] . W[N,K]^T (+ bias[N]).  X rows ldx elements apart; W and Y contiguous.
+// Returns 0 on success, 3 when the shape is outside this kernel's envelope (caller falls back
+// to a library GEMM): M > 64, K % 32 != 0, N % 16 != 0, W >= 4 GiB, or fp32.
+extern "C" int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream) {
+  LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit weights only");
+  LV_CHECK(N % 16 == 0 && K % 32 == 0, "N must be a multiple of 16 and K of 32");
+  LV_CHECK(dst != src, "packing is out of place");
+  const int64_t nchunks = (int64_t)N * K / 8;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (uint4*)dst, (const uint4*)src, nchunks, K);
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+// `act` = 1: X rows are [gate (K) | up (K)] and the kernel multiplies W by silu(gate)*up
+// (the SwiGLU activation fused into the down projection); `partial_out` != 0: leave the fp32
+// split-K partials in `workspace` ([ksplit, M, N]) and do not write y (the caller's next kernel
+// sums them: lvllm_fused_add_rms_norm_splitk).  *ksplit_out receives the number of partials.
+extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                                    int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
+                                    int* ksplit_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+extern "C" int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                                 int K, int64_t ldx, int dtype, int packed, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  return lvllm_skinny_gemm_ex(y, x, w, bias, M, N, K, ldx, dtype, packed, 0, 0, nullptr, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                                    int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
+                                    int* ksplit_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 32) != 0 || (N % 16) != 0 ||
+      (int64_t)N * K * 2 >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
+      ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
+    set_error("lvllm_skinny_gemm: shape outside the kernel's envelope");
+    return 3;
+  }
+  const int total_steps = K / 32;
+  const int cap = kGemmWaves * max_steps_per_wave(M);
+  const int ksplit = (total_steps + cap - 1) / cap;
+  const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
+  const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;  // <= max_steps_per_wave(M)
+  const int ntiles = N / 16;
+  int groups = 256 / ksplit;  // one workgroup (8 waves, ~200 VGPRs) per CU
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  if (ksplit_out) *ksplit_out = ksplit;
+  LV_CHECK(!(partial_out && bias != nullptr), "partial_out leaves the bias to the caller");
+  float* partial = nullptr;
+  if (ksplit > 1 || partial_out) {
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
+             "workspace too small (see lvllm_skinny_gemm_workspace_bytes)");
+    partial = (float*)workspace;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int MT = (M + 15) / 16;
+  const bool k8 = steps_per_wave <= 8;
+#define LV_SG(T_, MT_)                                                                              \
+  do {                                                                                              \
+    if (k8)                                                                                         \
+      launch_skinny<T_, MT_, 8>(y, partial, x, w, bias, M, N, K, ldx, steps_per_wave, ntiles, groups, \
+                                ksplit, packed != 0, act, s);                                       \
+    else                                                                                            \
+      launch_skinny<T_, MT_, 16>(y, partial, x, w, bias, M, N, K, ldx, steps_per_wave, ntiles, groups, \
+                                 ksplit, packed != 0, act, s);                                      \
+  } while (0)
+#define LV_SG_MT(T_)                           \
+  switch (MT) {                                \
+    case 1: LV_SG(T_, 1); break;               \
+    case 2: LV_SG(T_, 2); break;               \
+    default:                                   \
+      launch_skinny<T_, 4, 8>(y, partial, x, w, bias, M, N, K, ldx, steps_per_wave, ntiles, groups, ksplit, packed != 0, act, s); \
+      break;                                   \
+  }
+  if (dtype == LVLLM_BF16) { LV_SG_MT(BF16) } else { LV_SG_MT(F16) }
+#undef LV_SG_MT
+#undef LV_SG
+  LV_LAUNCH_CHECK();
+  if (ksplit > 1 && !partial_out) {
+    const int64_t MN = (int64_t)M * N;
+    const int threads = 256;
+    const int grid = (int)((MN / 4 + threads - 1) / threads);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<BF16>), dim3(grid), dim3(threads), 0, s, (uint16_t*)y,
+                         partial, (const uint16_t*)bias, MN, N, ksplit);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(threads), 0, s, (uint16_t*)y,
+                         partial, (const uint16_t*)bias, MN, N, ksplit);
+    LV_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -242,6 +242,117 @@ void reshape_and_cache_flash(torch::Tensor& key, torch::Tensor& value, torch::Te
       (float)v_scale, current_stream(key)));
 }
 
+// Extension ops (not in the reference): F.linear for decode batches through the
+// weight-streaming kernel.  `packed_shape` = [N, K] when `w` is in lvllm_pack_weight order.
+torch::Tensor skinny_linear_impl(const torch::Tensor& x, const torch::Tensor& w,
+                                 const std::optional<torch::Tensor>& bias, bool packed, int64_t N,
+                                 int64_t K) {
+  const int64_t M = x.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto y = torch::empty({M, N}, x.options());
+  const int64_t ws_bytes = lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
+  const int rc = lvllm_skinny_gemm(y.data_ptr(), x.data_ptr(), w.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                                   (int)M, (int)N, (int)K, x.stride(0), dtype_code(x, "skinny_linear"),
+                                   packed ? 1 : 0, ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes,
+                                   current_stream(x));
+  if (rc == 3) return torch::Tensor();  // outside the envelope
+  check(rc);
+  return y;
+}
+
+bool skinny_ok(const torch::Tensor& x, const torch::Tensor& w, const std::optional<torch::Tensor>& bias) {
+  return x.is_cuda() && x.dim() == 2 && (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kHalf) &&
+         w.scalar_type() == x.scalar_type() && w.is_contiguous() && x.stride(1) == 1 && x.size(0) <= 64 &&
+         x.size(0) > 0 && (!bias || bias->is_contiguous());
+}
+
+torch::Tensor skinny_linear(const torch::Tensor& x, const torch::Tensor& w,
+                            const std::optional<torch::Tensor>& bias) {
+  TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && x.size(1) == w.size(1), "skinny_linear: x [M,K], w [N,K]");
+  if (skinny_ok(x, w, bias)) {
+    auto y = skinny_linear_impl(x, w, bias, false, w.size(0), w.size(1));
+    if (y.defined()) return y;
+  }
+  return at::linear(x, w, bias);
+}
+
+torch::Tensor skinny_linear_packed(const torch::Tensor& x, const torch::Tensor& w_packed,
+                                   const std::optional<torch::Tensor>& bias, int64_t N, int64_t K) {
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && w_packed.numel() == N * K, "skinny_linear_packed: bad shapes");
+  TORCH_CHECK(skinny_ok(x, w_packed, bias), "skinny_linear_packed: M <= 64 rows of bf16/f16 on the GPU only");
+  auto y = skinny_linear_impl(x, w_packed, bias, true, N, K);
+  TORCH_CHECK(y.defined(), lvllm_last_error());
+  return y;
+}
+
+// A projection that leaves its fp32 split-K partials [S, M, N] for fused_add_rms_norm_splitk
+// instead of reducing them itself.  swiglu: x = [gate | up] ([M, 2K]) and the activation is applied
+// while loading x (bit-identical to silu_and_mul, but every workgroup redoes it for its K slice:
+// measured 2x slower than the separate activation kernel at inter=14336 -- kept for small shapes).
+torch::Tensor skinny_linear_packed_partials(const torch::Tensor& gate_up, const torch::Tensor& w_packed, int64_t N,
+                                            int64_t K, bool swiglu) {
+  TORCH_CHECK(gate_up.dim() == 2 && gate_up.size(1) == (swiglu ? 2 * K : K) && w_packed.numel() == N * K,
+              "bad shapes");
+  TORCH_CHECK(skinny_ok(gate_up, w_packed, std::nullopt), "M <= 64 rows of bf16/f16 on the GPU only");
+  const int64_t M = gate_up.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(gate_up));
+  int64_t ws_bytes = lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K);
+  if (ws_bytes == 0) ws_bytes = M * N * 4;
+  const int64_t S = ws_bytes / (M * N * 4);
+  auto partials = torch::empty({S, M, N}, gate_up.options().dtype(torch::kFloat));
+  int ksplit = 0;
+  check(lvllm_skinny_gemm_ex(nullptr, gate_up.data_ptr(), w_packed.data_ptr(), nullptr, (int)M, (int)N, (int)K,
+                             gate_up.stride(0), dtype_code(gate_up, "skinny_linear_packed_partials"), 1,
+                             swiglu ? 1 : 0, 1, &ksplit,
+                             partials.data_ptr(), ws_bytes, current_stream(gate_up)));
+  TORCH_CHECK(ksplit == S, "split count mismatch");
+  return partials;
+}
+
+void fused_add_rms_norm_splitk(torch::Tensor& out, torch::Tensor& residual, const torch::Tensor& partials,
+                               const torch::Tensor& weight, double epsilon) {
+  TORCH_CHECK(partials.dim() == 3 && partials.scalar_type() == at::kFloat && partials.is_contiguous());
+  TORCH_CHECK(out.is_contiguous() && residual.is_contiguous() && out.sizes() == residual.sizes());
+  const int hidden = (int)out.size(-1);
+  const int num_tokens = (int)(out.numel() / hidden);
+  TORCH_CHECK(partials.size(1) == num_tokens && partials.size(2) == hidden);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(out));
+  check(lvllm_fused_add_rms_norm_splitk(out.data_ptr(), residual.data_ptr(), partials.data_ptr<float>(),
+                                        (int)partials.size(0), weight.data_ptr(), (float)epsilon, num_tokens,
+                                        hidden, dtype_code(out, "fused_add_rms_norm_splitk"), current_stream(out)));
+}
+
+// returns false when the arguments are outside the fused kernel's envelope (nothing was done)
+bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, torch::Tensor& key,
+                                const torch::Tensor& value, int64_t head_size, torch::Tensor& cos_sin_cache,
+                                bool is_neox, torch::Tensor& key_cache, torch::Tensor& value_cache,
+                                const torch::Tensor& slot_mapping) {
+  LV_CHECK_DEVICE(query);
+  TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
+  const int64_t num_tokens = query.numel() / query.size(-1);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
+  const int rc = lvllm_rotary_embedding_and_cache(
+      positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(), (int)num_tokens,
+      (int)(query.size(-1) / head_size), (int)(key.size(-1) / head_size), (int)head_size,
+      (int)cos_sin_cache.size(1), query.stride(-2), key.stride(-2), value.stride(-2), cos_sin_cache.data_ptr(),
+      is_neox ? 1 : 0, key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
+      (int)value_cache.size(3), dtype_code(query, "rotary_embedding_and_cache"), current_stream(query));
+  if (rc == 3) return false;
+  check(rc);
+  return true;
+}
+
+torch::Tensor pack_weight(const torch::Tensor& w) {
+  TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
+  auto out = torch::empty_like(w);
+  check(lvllm_pack_weight(out.data_ptr(), w.data_ptr(), (int)w.size(0), (int)w.size(1),
+                          dtype_code(w, "pack_weight"), current_stream(w)));
+  return out;
+}
+
 int64_t get_device_attribute(int64_t attribute, int64_t device_id) {
   return lvllm_get_device_attribute(attribute, device_id);
 }
@@ -325,6 +436,25 @@ TORCH_LIBRARY(_C_cache_ops, cache_ops) {
       "                        str kv_cache_dtype,"
       "                        float k_scale, float v_scale) -> ()");
   cache_ops.impl("reshape_and_cache_flash", torch::kCUDA, &reshape_and_cache_flash);
+}
+
+// operators this build adds beyond the reference's list
+TORCH_LIBRARY(_C_amd, amd) {
+  amd.def("skinny_linear(Tensor x, Tensor w, Tensor? bias) -> Tensor");
+  amd.impl("skinny_linear", torch::kCUDA, &skinny_linear);
+  amd.def("skinny_linear_packed(Tensor x, Tensor w_packed, Tensor? bias, int N, int K) -> Tensor");
+  amd.impl("skinny_linear_packed", torch::kCUDA, &skinny_linear_packed);
+  amd.def("pack_weight(Tensor w) -> Tensor");
+  amd.impl("pack_weight", torch::kCUDA, &pack_weight);
+  amd.def("skinny_linear_packed_partials(Tensor x, Tensor w_packed, int N, int K, bool swiglu) -> Tensor");
+  amd.impl("skinny_linear_packed_partials", torch::kCUDA, &skinny_linear_packed_partials);
+  amd.def("fused_add_rms_norm_splitk(Tensor! out, Tensor! residual, Tensor partials, Tensor weight, "
+          "float epsilon) -> ()");
+  amd.impl("fused_add_rms_norm_splitk", torch::kCUDA, &fused_add_rms_norm_splitk);
+  amd.def("rotary_embedding_and_cache(Tensor positions, Tensor! query, Tensor! key, Tensor value, "
+          "int head_size, Tensor cos_sin_cache, bool is_neox, Tensor! key_cache, Tensor! value_cache, "
+          "Tensor slot_mapping) -> bool");
+  amd.impl("rotary_embedding_and_cache", torch::kCUDA, &rotary_embedding_and_cache);
 }
 
 TORCH_LIBRARY(_C_cuda_utils, cuda_utils) {

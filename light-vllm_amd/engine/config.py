@@ -21,6 +21,8 @@ class ModelConfig:
     max_position_embeddings: int = 8192
     qkv_bias: bool = False          # Qwen2: True (qwen2.py:114-121); Llama: False
     dtype: torch.dtype = torch.bfloat16
+    pack_weights: bool = True       # keep an MFMA-ordered copy of each projection for decode
+    fuse_decode_ops: bool = True    # rope+cache write in one launch, split-K sum inside add+norm
 
     @property
     def head_dim(self) -> int:

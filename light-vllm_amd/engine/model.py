@@ -16,6 +16,33 @@ from .. import _custom_ops as ops
 from .config import ModelConfig
 
 
+class Weight:
+    """A projection weight [N, K] kept in two orders: row-major for the library GEMM (prompt
+    batches) and, for decode batches, packed into MFMA-fragment order so that the
+    weight-streaming kernel reads one contiguous KiB per wave load (csrc/skinny_gemm.hip).
+    Twice the bytes; sized for 288 GB of HBM."""
+
+    __slots__ = ("w", "packed", "N", "K")
+
+    def __init__(self, w: torch.Tensor, pack: bool = True):
+        self.w = w
+        self.N, self.K = w.shape
+        ok = pack and w.is_cuda and self.N % 16 == 0 and self.K % 32 == 0 and self.N * self.K * 2 < (1 << 32) - 16
+        self.packed = torch.ops._C_amd.pack_weight(w) if ok else None
+
+    def numel(self) -> int:
+        return self.w.numel()
+
+
+def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense projection.  Decode batches (<= 64 rows) stream the weights through the gfx950
+    weight-streaming kernel; larger batches use the library GEMM (hipBLASLt)."""
+    if x.shape[0] <= 64 and x.is_cuda:
+        if w.packed is not None:
+            return torch.ops._C_amd.skinny_linear_packed(x, w.packed, bias, w.N, w.K)
+    return F.linear(x, w.w, bias)
+
+
 def build_cos_sin_cache(head_dim: int, max_pos: int, base: float, dtype, device) -> torch.Tensor:
     """[max_pos, rot_dim] = [cos | sin] in the model dtype
     (light_vllm/backends/rotary_embedding.py:94-114)."""
@@ -35,11 +62,11 @@ class DecoderLayerWeights:
 
         self.input_norm = (1.0 + 0.05 * torch.randn(hid, generator=gen, device=device)).to(cfg.dtype)
         self.post_norm = (1.0 + 0.05 * torch.randn(hid, generator=gen, device=device)).to(cfg.dtype)
-        self.qkv = w((H + 2 * KVH) * D, hid)
+        self.qkv = Weight(w((H + 2 * KVH) * D, hid), cfg.pack_weights)
         self.qkv_bias = w((H + 2 * KVH) * D) if cfg.qkv_bias else None
-        self.o = w(hid, H * D)
-        self.gate_up = w(2 * inter, hid)
-        self.down = w(hid, inter)
+        self.o = Weight(w(hid, H * D), cfg.pack_weights)
+        self.gate_up = Weight(w(2 * inter, hid), cfg.pack_weights)
+        self.down = Weight(w(hid, inter), cfg.pack_weights)
 
 
 class DecoderModel:
@@ -53,7 +80,8 @@ class DecoderModel:
         self.layers: List[DecoderLayerWeights] = [DecoderLayerWeights(cfg, self.device, gen)
                                                   for _ in range(cfg.num_hidden_layers)]
         self.final_norm = (1.0 + 0.05 * torch.randn(cfg.hidden_size, generator=gen, device=self.device)).to(cfg.dtype)
-        self.lm_head = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=gen, device=self.device) * 0.02).to(cfg.dtype)
+        self.lm_head = Weight((torch.randn(cfg.vocab_size, cfg.hidden_size, generator=gen, device=self.device) * 0.02).to(cfg.dtype),
+                              cfg.pack_weights)
         self.cos_sin_cache = build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings,
                                                  cfg.rope_theta, cfg.dtype, self.device)
         self.attn = attn_impl  # DecodeOnlyAttentionImpl-like: forward(q, k, v, kv_cache, metadata)
@@ -64,12 +92,27 @@ class DecoderModel:
         n = self.lm_head.numel()
         for l in self.layers:
             n += l.qkv.numel() + l.o.numel() + l.gate_up.numel() + l.down.numel()
-        return n * self.lm_head.element_size()
+        return n * self.lm_head.w.element_size()
+
+    def _add_norm(self, x, residual: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """residual += x; return norm(residual) * weight.  `x` is either the projection output
+        [T, hidden] or the fp32 split-K partials [S, T, hidden] of a fused down projection."""
+        if x.dim() == 3:
+            out = torch.empty_like(residual)
+            torch.ops._C_amd.fused_add_rms_norm_splitk(out, residual, x, weight, self.cfg.rms_norm_eps)
+            return out
+        ops.fused_add_rms_norm(x, residual, weight, self.cfg.rms_norm_eps)
+        return x
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor,
                 kv_caches: Optional[List[torch.Tensor]], attn_metadata) -> torch.Tensor:
         cfg = self.cfg
         hidden = F.embedding(input_ids, self.embed)
+        T = hidden.shape[0]
+        # decode-only steps take the fused launches: rope + cache write in one kernel, split-K
+        # partials of the down projection summed inside the next add+norm
+        decode_only = (cfg.fuse_decode_ops and kv_caches is not None and T <= 64 and
+                       attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
         residual = None
         for i, lw in enumerate(self.layers):
             if residual is None:  # qwen2.py:203-208
@@ -78,20 +121,33 @@ class DecoderModel:
                 ops.rms_norm(normed, hidden, lw.input_norm, cfg.rms_norm_eps)
                 hidden = normed
             else:
-                ops.fused_add_rms_norm(hidden, residual, lw.input_norm, cfg.rms_norm_eps)
-            qkv = F.linear(hidden, lw.qkv, lw.qkv_bias)
+                hidden = self._add_norm(hidden, residual, lw.input_norm)
+            qkv = linear(hidden, lw.qkv, lw.qkv_bias)
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)  # strided views
-            ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin_cache, True)
-            attn_out = self.attn.forward(q, k, v, kv_caches[i] if kv_caches is not None else None,
-                                         attn_metadata)
-            hidden = F.linear(attn_out, lw.o)
-            ops.fused_add_rms_norm(hidden, residual, lw.post_norm, cfg.rms_norm_eps)
-            gate_up = F.linear(hidden, lw.gate_up)
-            act = torch.empty(gate_up.shape[0], cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
+            fused = False
+            if decode_only:
+                key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
+                fused = torch.ops._C_amd.rotary_embedding_and_cache(
+                    positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
+                    attn_metadata.slot_mapping)
+            if fused:
+                attn_out = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata)
+            else:
+                ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin_cache, True)
+                attn_out = self.attn.forward(q, k, v, kv_caches[i] if kv_caches is not None else None,
+                                             attn_metadata)
+            hidden = linear(attn_out, lw.o)
+            hidden = self._add_norm(hidden, residual, lw.post_norm)
+            gate_up = linear(hidden, lw.gate_up)
+            act = torch.empty(T, cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
             ops.silu_and_mul(act, gate_up)
-            hidden = F.linear(act, lw.down)
-        ops.fused_add_rms_norm(hidden, residual, self.final_norm, cfg.rms_norm_eps)
-        return hidden
+            if decode_only and lw.down.packed is not None:
+                # [S, T, hidden] fp32 split-K partial sums; the next add+norm adds them up
+                hidden = torch.ops._C_amd.skinny_linear_packed_partials(act, lw.down.packed, lw.down.N,
+                                                                        lw.down.K, False)
+            else:
+                hidden = linear(act, lw.down)
+        return self._add_norm(hidden, residual, self.final_norm)
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
-        return F.linear(hidden, self.lm_head)
+        return linear(hidden, self.lm_head)

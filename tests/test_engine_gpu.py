@@ -35,7 +35,7 @@ def dense_reference_logits(model, token_ids):
     h = None
     for lw in model.layers:
         h = rms(res, lw.input_norm)
-        qkv = h @ lw.qkv.float().T
+        qkv = h @ lw.qkv.w.float().T
         q, k, v = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
         q, k, v = rope(q.view(T, H, D)), rope(k.view(T, KVH, D)), v.view(T, KVH, D)
         k = k.repeat_interleave(H // KVH, dim=1)
@@ -43,12 +43,12 @@ def dense_reference_logits(model, token_ids):
         att = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(D)
         att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool, device=x.device).tril(), float("-inf"))
         o = torch.einsum("hqk,khd->qhd", att.softmax(-1), v).reshape(T, H * D)
-        res = res + o @ lw.o.float().T
+        res = res + o @ lw.o.w.float().T
         h2 = rms(res, lw.post_norm)
-        gu = h2 @ lw.gate_up.float().T
+        gu = h2 @ lw.gate_up.w.float().T
         a, b = gu.chunk(2, dim=-1)
-        res = res + (F.silu(a) * b) @ lw.down.float().T
-    return rms(res, model.final_norm) @ model.lm_head.float().T
+        res = res + (F.silu(a) * b) @ lw.down.w.float().T
+    return rms(res, model.final_norm) @ model.lm_head.w.float().T
 
 
 def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8):

@@ -1,0 +1,94 @@
+"""The weight-streaming decode GEMM (extension op, csrc/skinny_gemm.hip) against torch: fp32
+matmul of the same bf16/f16 operands; tolerance = output rounding + accumulation-order noise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [  # M, N, K
+    (32, 6144, 4096), (32, 4096, 4096), (32, 28672, 4096), (32, 4096, 14336), (32, 128256, 4096),
+    (1, 4096, 4096), (7, 1024, 512), (16, 512, 256), (17, 4096, 4096), (33, 2048, 4096), (64, 4096, 14336),
+    (5, 48, 64), (32, 16, 32), (3, 4096, 11008), (32, 1536, 8960),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_skinny_linear_matches_fp32_matmul(ops, dtype, M, N, K, use_bias):
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype)
+    b = (torch.randn(N, generator=g, device=DEV) * 0.5).to(dtype) if use_bias else None
+    y = torch.ops._C_amd.skinny_linear(x, w, b)
+    if N % 16 == 0 and K % 32 == 0:
+        # the packed-weight path computes the same sums in the same order: bit-identical
+        yp = torch.ops._C_amd.skinny_linear_packed(x, torch.ops._C_amd.pack_weight(w), b, N, K)
+        assert torch.equal(y.view(torch.int16), yp.view(torch.int16))
+    ref = x.float() @ w.float().T
+    if b is not None:
+        ref = ref + b.float()
+    assert y.shape == (M, N) and y.dtype == dtype
+    err = (y.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9) * scale + 1e-3, (err, scale)
+
+
+def test_strided_rows_and_fallback(ops):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    big = (torch.randn(8, 3 * 512, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    x = big[:, 512:1024]  # row stride 1536, as a split of a fused projection
+    w = (torch.randn(256, 512, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    y = torch.ops._C_amd.skinny_linear(x, w, None)
+    assert torch.allclose(y.float(), x.float() @ w.float().T, atol=2e-2, rtol=2e-2)
+    # outside the envelope (M > 64, odd N): falls back to the library GEMM, same result
+    x2 = (torch.randn(100, 512, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    assert torch.allclose(torch.ops._C_amd.skinny_linear(x2, w, None).float(), x2.float() @ w.float().T, atol=2e-2, rtol=2e-2)
+    w3 = (torch.randn(50, 512, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    assert torch.allclose(torch.ops._C_amd.skinny_linear(x, w3, None).float(), x.float() @ w3.float().T, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_decode_ops_are_bit_identical_to_the_unfused_sequence(ops, dtype):
+    """The three fused launches (rope + cache write; split-K sum inside add+norm; optionally SwiGLU
+    inside the down projection) keep the rounding points of the operators they replace: results are bit-equal."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    T, H, KVH, D, BS, NB, hid, inter = 9, 8, 2, 128, 16, 12, 1024, 14336
+    for neox in (True, False):
+        qkv = (torch.randn(T, (H + 2 * KVH) * D, generator=g, device=DEV)).to(dtype)
+        inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+        fr = torch.outer(torch.arange(512).float(), inv)
+        cache = torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(DEV)
+        pos = torch.randint(0, 512, (T,), generator=g, device=DEV)
+        slots = torch.randperm(NB * BS, generator=g, device=DEV)[:T].to(torch.int64)
+        slots[2] = -1
+        kc0 = torch.randn(NB, KVH, D // 8, BS, 8, generator=g, device=DEV).to(dtype)
+        vc0 = torch.randn(NB, KVH, D, BS, generator=g, device=DEV).to(dtype)
+        a, b = qkv.clone(), qkv.clone()
+        kc_a, vc_a, kc_b, vc_b = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+        qa, ka, va = a.split([H * D, KVH * D, KVH * D], dim=-1)
+        ops.rotary_embedding(pos, qa, ka, D, cache, neox)
+        ops.reshape_and_cache(ka.view(T, KVH, D), va.view(T, KVH, D), kc_a, vc_a, slots, "auto", 1.0, 1.0)
+        qb, kb, vb = b.split([H * D, KVH * D, KVH * D], dim=-1)
+        assert torch.ops._C_amd.rotary_embedding_and_cache(pos, qb, kb, vb, D, cache, neox, kc_b, vc_b, slots)
+        for x, y in ((a, b), (kc_a, kc_b), (vc_a, vc_b)):
+            assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    # SwiGLU + down projection + add + norm
+    gate_up = (torch.randn(T, 2 * inter, generator=g, device=DEV)).to(dtype)
+    w = (torch.randn(hid, inter, generator=g, device=DEV) * 0.02).to(dtype)
+    wp = torch.ops._C_amd.pack_weight(w)
+    res = torch.randn(T, hid, generator=g, device=DEV).to(dtype)
+    nw = (1 + 0.1 * torch.randn(hid, generator=g, device=DEV)).to(dtype)
+    act = torch.empty(T, inter, dtype=dtype, device=DEV)
+    ops.silu_and_mul(act, gate_up)
+    y = torch.ops._C_amd.skinny_linear_packed(act, wp, None, hid, inter)
+    res_a = res.clone()
+    ops.fused_add_rms_norm(y, res_a, nw, 1e-5)
+    for swiglu, x in ((True, gate_up), (False, act)):
+        partials = torch.ops._C_amd.skinny_linear_packed_partials(x, wp, hid, inter, swiglu)
+        assert partials.shape == (4, T, hid) and partials.dtype == torch.float32
+        out_b, res_b = torch.empty_like(res), res.clone()
+        torch.ops._C_amd.fused_add_rms_norm_splitk(out_b, res_b, partials, nw, 1e-5)
+        assert torch.equal(res_a.view(torch.int16), res_b.view(torch.int16))
+        assert torch.equal(y.view(torch.int16), out_b.view(torch.int16))
