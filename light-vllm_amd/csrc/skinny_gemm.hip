@@ -52,7 +52,7 @@ constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load r
 #define LVLLM_GEMM_AUX 2  // nt: weights are read once per launch
 #endif
 #ifndef LVLLM_GEMM_NT
-#define LVLLM_GEMM_NT 8   // partial slabs (n-tiles x m-tiles) accumulated between two wave meetings
+#define LVLLM_GEMM_NT 2   // partial slabs (n-tiles x m-tiles) accumulated between two wave meetings
 #endif
 
 template <typename T, int MT, int KSTEPS, bool PACKED, int NT>
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     float* __restrict__ partial,           // [ksplit, M, N]    (ksplit > 1)
     const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
     const typename T::store_t* __restrict__ bias, const int M, const int N, const int K,
-    const int64_t ldx, const int steps_per_wave, const int ntiles, const int act) {
+    const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles) {
   using S = typename T::store_t;
   constexpr int HALF = KSTEPS / 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -75,39 +75,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   int nvalid = total_steps - step0;                                     // k-steps that exist
   nvalid = nvalid < 0 ? 0 : (nvalid > steps_per_wave ? steps_per_wave : nvalid);
 
-  // ---- X fragments: X[m = 16 mt + c][k = 32 (step0 + s) + 8 g ..], kept for the whole launch ----
-  g_u32x4_t xf[MT][KSTEPS];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mt * 16 + c;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
-      if (m < M && s < nvalid) {
-        const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
-        g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
-        if (act == 1) {
-          // fused SwiGLU gate: the row holds [gate (K) | up (K)]; X = T(T(silu(gate)) * up), the
-          // roundings of silu_and_mul (activation.hip), so the fused path is bit-identical
-          const g_u32x4_t u = *reinterpret_cast<const g_u32x4_t*>(src + K);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-              const S gs = (S)((v[q] >> (16 * hlf)) & 0xffffu), us = (S)((u[q] >> (16 * hlf)) & 0xffffu);
-              const float gf = T::to_float(gs);
-              const S a = T::from_float(gf / (1.0f + expf(-gf)));
-              out |= (uint32_t)T::from_float(T::to_float(a) * T::to_float(us)) << (16 * hlf);
-            }
-            v[q] = out;
-          }
-        }
-        xf[mt][s] = v;
-      }
-    }
-  }
-
+  g_u32x4_t xf[MT][KSTEPS];  // filled after the first weight loads have been issued (below)
   __amdgpu_buffer_rsrc_t wr =
       __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)N * K * 2), 0x00020000);
   // byte offset of this lane inside a 16-row tile at k-step step0, the byte stride between
@@ -141,6 +109,47 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const int ngroups = (my_tiles + NT - 1) / NT;
 
+  // Output staging.  A global store inside the streaming loop costs far more than its bytes:
+  // vmcnt retires in issue order, so every load issued after a store waits for that store's
+  // acknowledgement (measured: 2.4 us per wave meeting, 12 % of the kernel).  The summed tiles are
+  // therefore parked in LDS (fp32, 1 KiB per (tile, m-tile)) and written out in one burst when the
+  // stage is full or the workgroup is done -- no stores while weights are streaming.
+  g_f32x4_t* stage = red + (size_t)2 * kGemmWaves * NT * MT * 64;  // [stage_tiles][MT][64]
+  int stage_base = 0;  // first local tile held in the stage
+
+  auto store_slab = [&](const int i, const int mt, g_f32x4_t sum) __attribute__((always_inline)) {
+    // lane (g, c): rows n = n0 + 4g + r of column m = 16 mt + c
+    const int t = blockIdx.x + i * gridDim.x;
+    const int n0 = 16 * t + 4 * g;
+    const int m = mt * 16 + c;
+    if (m < M && n0 < N) {
+      if (partial != nullptr) {
+        float* dst = partial + ((int64_t)blockIdx.y * M + m) * N + n0;
+        *reinterpret_cast<g_f32x4_t*>(dst) = sum;
+      } else {
+        if (bias != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n0 + r]);
+        }
+        uint2 o;
+        o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
+        o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
+        *reinterpret_cast<uint2*>(y + (int64_t)m * N + n0) = o;
+      }
+    }
+  };
+
+  auto flush_stage = [&](const int end_tile) __attribute__((always_inline)) {
+    __syncthreads();  // every reducer's slab is in the stage
+    const int nslabs = (end_tile - stage_base) * MT;
+    for (int sl = wave; sl < nslabs; sl += kGemmWaves) {
+      const int i = stage_base + sl / MT, mt = sl % MT;
+      store_slab(i, mt, stage[(size_t)sl * 64 + lane]);
+    }
+    stage_base = end_tile;
+    __syncthreads();  // the stage may be overwritten again
+  };
+
   auto finish_group = [&](const int grp) __attribute__((always_inline)) {
 #ifdef LVLLM_GEMM_NOREDUCE  // timing experiment only (wrong results): no cross-wave reduction
     if (wave == 0 && lane == 0 && acc[0][0][0] == 12345.f) y[grp] = 0;
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
       for (int mt = 0; mt < MT; ++mt) acc[j][mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
     return;
 #endif
+    if ((grp + 1) * NT - stage_base > stage_tiles) flush_stage(grp * NT);  // uniform: make room first
     // LDS buffer (grp & 1): [wave][slab = j * MT + mt][lane]
     g_f32x4_t* buf = red + (size_t)(grp & 1) * kGemmWaves * NT * MT * 64;
 #pragma unroll
@@ -170,25 +180,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         const g_f32x4_t v = buf[(w2 * NT * MT + slab) * 64 + lane];
         sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
       }
-      // lane (g, c): rows n = n0 + 4g + r of column m = 16 mt + c
-      const int t = blockIdx.x + i * gridDim.x;
-      const int n0 = 16 * t + 4 * g;
-      const int m = mt * 16 + c;
-      if (m < M && n0 < N) {
-        if (partial != nullptr) {
-          float* dst = partial + ((int64_t)blockIdx.y * M + m) * N + n0;
-          *reinterpret_cast<g_f32x4_t*>(dst) = sum;
-        } else {
-          if (bias != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n0 + r]);
-          }
-          uint2 o;
-          o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
-          o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
-          *reinterpret_cast<uint2*>(y + (int64_t)m * N + n0) = o;
-        }
-      }
+      stage[((size_t)(i - stage_base) * MT + mt) * 64 + lane] = sum;
     }
   };
 
@@ -201,20 +193,59 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         ac[mt] = gemm_mfma<T>(a[s], h == 0 ? xf[mt][s] : xf[mt][HALF + s], ac[mt]);
   };
 
-  // units: (n-tile, half of the wave's k-steps); two register sets, one unit always in flight
+  // units: (n-tile, half of the wave's k-steps); two register sets.  Each set is refilled right
+  // after it is consumed, so 8-16 KiB per wave stay in flight, 16 KiB across a wave meeting
+  // (the meeting otherwise drains the memory pipeline: measured 2.4 us per meeting).
   g_u32x4_t a0[HALF], a1[HALF];
   load_unit(a0, 0, 0);
+  load_unit(a1, 0, 1);
+  // the first weight loads (HBM) are in flight before the activations (L2) are requested
+  // ---- X fragments: X[m = 16 mt + c][k = 32 (step0 + s) + 8 g ..], kept for the whole launch ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + c;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
+      if (m < M && s < nvalid) {
+        const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
+        g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
+        if (act == 1) {
+          // fused SwiGLU gate: the row holds [gate (K) | up (K)]; X = T(T(silu(gate)) * up), the
+          // roundings of silu_and_mul (activation.hip), so the fused path is bit-identical
+          const g_u32x4_t u = *reinterpret_cast<const g_u32x4_t*>(src + K);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+              const S gs = (S)((v[q] >> (16 * hlf)) & 0xffffu), us = (S)((u[q] >> (16 * hlf)) & 0xffffu);
+              const float gf = T::to_float(gs);
+              const S a = T::from_float(gf / (1.0f + expf(-gf)));
+              out |= (uint32_t)T::from_float(T::to_float(a) * T::to_float(us)) << (16 * hlf);
+            }
+            v[q] = out;
+          }
+        }
+        xf[mt][s] = v;
+      }
+    }
+  }
+
   for (int grp = 0; grp < ngroups; ++grp) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int i = grp * NT + j;  // tiles past my_tiles load nothing (out-of-range offsets)
-      load_unit(a1, i, 1);
       compute_unit(a0, 0, acc[j]);
       load_unit(a0, i + 1, 0);
       compute_unit(a1, 1, acc[j]);
+      load_unit(a1, i + 1, 1);
     }
     finish_group(grp);
   }
+#ifndef LVLLM_GEMM_NOREDUCE
+  flush_stage(my_tiles);  // all weights have been streamed: now the stores
+#endif
 }
 
 // out[m, n] = T(sum_s partial[s, m, n] + bias[n])
@@ -247,7 +278,14 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
                           bool packed, int act, hipStream_t stream) {
   using S = typename T::store_t;
   constexpr int NT = LVLLM_GEMM_NT / MT > 0 ? LVLLM_GEMM_NT / MT : 1;  // NT * MT slabs per meeting
-  const size_t smem = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
+  const size_t red_bytes = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
+  // output stage: as many tiles as the workgroup owns, capped by what is left of the 160 KiB LDS
+  const int tiles_per_wg = (ntiles + groups - 1) / groups;
+  int stage_tiles = ((tiles_per_wg + NT - 1) / NT) * NT;
+  const int cap = (int)((160 * 1024 - red_bytes) / ((size_t)MT * 1024) / NT) * NT;
+  if (stage_tiles > cap) stage_tiles = cap;
+  if (stage_tiles < NT) stage_tiles = NT;
+  const size_t smem = red_bytes + (size_t)stage_tiles * MT * 64 * sizeof(g_f32x4_t);
   auto kp = skinny_gemm_kernel<T, MT, KSTEPS, true, NT>;
   auto ku = skinny_gemm_kernel<T, MT, KSTEPS, false, NT>;
   if (smem > 64 * 1024) {
@@ -256,10 +294,10 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
   }
   if (packed)
     hipLaunchKernelGGL(kp, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
-                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act);
+                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act, stage_tiles);
   else
     hipLaunchKernelGGL(ku, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
-                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act);
+                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act, stage_tiles);
 }
 
 // W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
