@@ -201,6 +201,27 @@ int lvllm_rotary_embedding_and_cache(
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, void* stream);
 
+/* Causal varlen attention of prompt chunks over the paged cache: prefill, chunked prefill and
+ * prefix-cache hits.  Replaces the reference's third-party call
+ *   flash_attn_varlen_func(q, key_cache, value_cache, cu_seqlens_q=query_start_loc,
+ *                          cu_seqlens_k=seq_start_loc, causal=True, block_table=...)
+ * (light_vllm/decoding/backends/attention/backends/flash_attn.py:538-555; same job as the Triton
+ * context_attention_fwd, ops/prefix_prefill.py).  Sequence i owns query tokens
+ * query_start_loc[i] .. query_start_loc[i+1]; seq_lens[i] counts the whole context INCLUDING those
+ * tokens, whose K/V must already be in the cache (reshape_and_cache runs first, flash_attn.py:488-500).
+ * Query t of the chunk sits at position seq_len - query_len + t and sees keys 0 .. that position
+ * (the last sliding_window of them when sliding_window > 0); softcap > 0 applies
+ * cap * tanh(logit / cap).  16-bit dtypes, head sizes of paged_attention, block_size 16 or 32;
+ * key_cache / value_cache in the paged_attention layouts.  query [T, num_heads, head_size] with token
+ * stride q_stride, out likewise with out_stride (elements). */
+int lvllm_paged_prefill_attention(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
+    int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

@@ -63,6 +63,20 @@ def paged_attention_v2(out: torch.Tensor, exp_sum: torch.Tensor, max_logits: tor
                           blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step)
 
 
+def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                            block_tables: torch.Tensor, seq_lens: torch.Tensor,
+                            query_start_loc: torch.Tensor, max_query_len: int, block_size: int,
+                            alibi_slopes: Optional[torch.Tensor] = None, sliding_window: int = 0,
+                            softcap: float = 0.0, kv_cache_dtype: str = "auto") -> None:
+    """Causal varlen attention of prompt chunks over the paged cache: the job of
+    flash_attn_varlen_func(..., block_table=...) at flash_attn.py:538-555 of the reference."""
+    torch.ops._C_amd.paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, scale,
+                                             block_tables, seq_lens, query_start_loc, max_query_len,
+                                             block_size, alibi_slopes, sliding_window, softcap,
+                                             kv_cache_dtype)
+
+
 def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
                      cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
     _C.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)

@@ -158,6 +158,11 @@ class PagedAttnMetadataBuilder:
         self.sliding_window = input_builder.sliding_window
         self.block_size = input_builder.block_size
         self.use_v2_block_manager = input_builder.scheduler_config.use_v2_block_manager
+        # Plain prompts get their block table too (the reference leaves it empty and sends them
+        # to the dense flash-attn call, flash_attn.py:518-536): the HIP prefill kernel reads the
+        # chunk's K/V back from the paged cache, so one code path serves prompts, chunks and
+        # prefix hits.  Off with a sliding window (v1 tables are rings there).
+        self.prompt_block_tables = getattr(input_builder, "prompt_block_tables", self.sliding_window is None)
         self.slot_mapping: List[int] = []
         self.prefill_seq_lens: List[int] = []
         self.context_lens: List[int] = []
@@ -191,7 +196,7 @@ class PagedAttnMetadataBuilder:
             block_table: List[int] = []
             if prefix_cache_hit:
                 block_table = block_tables[seq_id]
-            elif (chunked_prefill_enabled or not is_prompt) and block_tables is not None:
+            elif (chunked_prefill_enabled or not is_prompt or self.prompt_block_tables) and block_tables is not None:
                 block_table = block_tables[seq_id][-curr_sw_blocks:] if curr_sw_blocks else block_tables[seq_id]
             self.block_tables.append(block_table)
             start_idx = compute_slot_mapping_start_idx(is_prompt, query_len, context_len,
@@ -245,8 +250,8 @@ class PagedAttnImpl:
                  logits_soft_cap: Optional[float] = None, decode_version: Optional[str] = None) -> None:
         if blocksparse_params is not None:
             raise ValueError("PagedAttn (HIP) does not support block-sparse attention.")
-        if logits_soft_cap is not None:
-            raise ValueError("PagedAttn (HIP) does not support logits soft cap.")
+        if logits_soft_cap:
+            raise ValueError("PagedAttn (HIP) decode does not support logits soft cap.")
         if head_size not in PagedAttention.get_supported_head_sizes():
             raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
                              f"Supported head sizes are: {PagedAttention.get_supported_head_sizes()}.")
@@ -261,6 +266,7 @@ class PagedAttnImpl:
         assert self.num_heads % self.num_kv_heads == 0
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
         self.decode_version = decode_version  # None: heuristic; "v1" | "v2": forced
+        self.use_hip_prefill = True  # False: torch SDPA per sequence (kept for A/B tests)
         self._scratch: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
     def _v2_scratch(self, num_seqs: int, max_seq_len: int, like: torch.Tensor):
@@ -336,8 +342,23 @@ class PagedAttnImpl:
                                       force_version="v1" if use_v1 else "v2", scratch=scratch, output=out)
         return out.view(num_tokens, hidden_size)
 
-    # ---- prompt attention (torch SDPA; not this round's hot path) ----
+    # ---- prompt attention ----
     def _prefill(self, q, k, v, key_cache, value_cache, meta: PagedAttnMetadata, out) -> None:
+        """With a cache: one launch of the HIP varlen kernel over the paged cache (the chunk's own
+        K/V were written just before).  Without one (the memory-profiling run, kv_cache None,
+        flash_attn.py:518-536): torch SDPA on the dense prompt."""
+        if (self.use_hip_prefill and key_cache is not None and q.dtype in (torch.float16, torch.bfloat16)
+                and value_cache.shape[3] in (16, 32) and meta.block_tables.numel() > 0
+                and self.sliding_window is None):
+            alibi = self.alibi_slopes
+            if alibi is not None and alibi.device != q.device:
+                alibi = self.alibi_slopes = alibi.to(q.device)
+            PagedAttention.forward_prefix(q, k, v, key_cache, value_cache, meta.block_tables,
+                                          meta.query_start_loc, meta.seq_lens_tensor,
+                                          meta.context_lens_tensor, meta.max_query_len, alibi,
+                                          self.sliding_window, scale=self.scale,
+                                          kv_cache_dtype=self.kv_cache_dtype, output=out)
+            return
         qs = 0
         G = self.num_queries_per_kv
         for i in range(meta.num_prefills):

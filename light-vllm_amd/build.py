@@ -31,6 +31,7 @@ HIP_SOURCES = [
     "attention_bf16.hip",
     "attention_f16.hip",
     "skinny_gemm.hip",
+    "prefill_attention.hip",
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,304 @@
+// Causal varlen attention of prompt chunks over the PAGED cache (prefill, chunked prefill,
+// prefix-cache hits) for MI355X (gfx950 / CDNA4).
+//
+// WHAT (the call it replaces: light_vllm/decoding/backends/attention/backends/flash_attn.py:538-555,
+// flash_attn_varlen_func(q, key_cache, value_cache, cu_seqlens_q, cu_seqlens_k, causal=True,
+// block_table=...); the orphaned Triton twin is ops/prefix_prefill.py context_attention_fwd):
+//   sequence i owns query tokens query_start_loc[i] .. query_start_loc[i+1]; its context is
+//   seq_lens[i] tokens long and ENDS with those query tokens (their K/V were written to the
+//   cache by reshape_and_cache before this call).  Query token t (0-based inside the chunk)
+//   sits at position ctx + t, ctx = seq_len - query_len, and attends to keys 0 .. ctx + t
+//   (bottom-right aligned causal mask), optionally only the last `sliding_window` of them.
+//   fp32 logits / softmax / accumulation, probabilities rounded to T before P.V.
+//
+// HOW: the decode kernel's operand trick carries over unchanged -- the paged K layout is the
+// MFMA A-operand layout, V pieces feed the 16x16x16 MFMA, P never moves between lanes
+// (attention_mfma.h) -- but the 16 MFMA columns are now (query token, head of the GQA group)
+// pairs, NB column blocks per wave, and the waves of a workgroup split the QUERIES (no LDS, no
+// barriers, no merge): each wave walks the key tiles its own queries can see.  K/V tiles are
+// re-read by the 4 waves of a workgroup and by neighbouring workgroups out of L1/L2; HBM sees
+// each block about once per kv head.  Per wave and key tile: NB*(NS+NDT) MFMAs against
+// NS+NDT wave loads, so the kernel is MFMA/VALU-bound, not HBM-bound, for chunks >= 64 tokens.
+//   * accumulators are rescaled lazily: only when some column's running max grew in this tile
+//     (a wave-uniform branch; after the first tiles it is rarely taken);
+//   * exp2 with log2(e) folded into the scale;
+//   * the heaviest query tiles (end of the chunk) are launched first.
+#pragma once
+#include <float.h>
+
+#include "attention_mfma.h"
+
+namespace lvllm {
+
+struct PrefillParams {
+  void* out;                       // [num_tokens, num_heads, D]
+  const void* q;                   // [num_tokens, num_heads, D] (token stride q_stride)
+  const void* k_cache;             // [num_blocks, KVH, D/x, BS, x]
+  const void* v_cache;             // [num_blocks, KVH, D, BS]
+  const int32_t* block_tables;     // [num_seqs, max_num_blocks_per_seq]
+  const int32_t* seq_lens;         // [num_seqs] context length INCLUDING the chunk
+  const int32_t* query_start_loc;  // [num_seqs + 1]
+  const float* alibi_slopes;       // [num_heads] or null
+  int num_heads, num_kv_heads, max_num_blocks_per_seq;
+  int gp_shift;        // log2 of the GQA group size rounded up to a power of two (<= 16)
+  int sliding_window;  // <= 0: none; else a query at position p sees keys p-w+1 .. p
+  float scale;
+  float softcap;  // <= 0: none; else logits = cap * tanh(logits / cap)
+  int64_t q_stride, out_stride, kv_block_stride, kv_head_stride;
+};
+
+// Column layout of one 16-column MFMA block: column c = (query token c / GP, head c % GP) with
+// GP = 1 << gp_shift = the GQA group size rounded up to a power of two (<= 16).
+template <typename T, int D, int BS, int NB>
+__global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const PrefillParams p) {
+  using S = typename T::store_t;
+  static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
+  static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
+  constexpr int NS = (D + 31) / 32;
+  constexpr int NDT = (D + 15) / 16;
+  constexpr int kHeadBytes = D * BS * 2;
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr float kMasked = -FLT_MAX;
+  constexpr float kMInit = -1e30f;  // > kMasked: exp2(kMasked - m) == 0 even before any key is seen
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+
+  const int GP = 1 << p.gp_shift;
+  const int TQB = 16 >> p.gp_shift;  // query tokens per column block
+  const int TQW = NB * TQB;          // per wave
+  const int TQWG = 4 * TQW;          // per workgroup
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 15) >> 4;
+  const int kvh = blockIdx.x / HG;
+  const int hg = blockIdx.x - kvh * HG;
+  const int head0 = kvh * G + hg * 16;
+  const int nh = min(GP, G - hg * 16);
+  const int seq = blockIdx.y;
+  const int qtile = gridDim.z - 1 - blockIdx.z;  // heaviest first
+
+  const int qbeg = p.query_start_loc[seq];
+  const int qlen = p.query_start_loc[seq + 1] - qbeg;
+  const int seq_len = p.seq_lens[seq];
+  const int ctx = seq_len - qlen;
+  const int t_first = qtile * TQWG + wave * TQW;  // first query token (inside the chunk) of this wave
+  if (t_first >= qlen || ctx < 0) return;
+  const int nq = min(TQW, qlen - t_first);        // live query tokens of this wave
+
+  // keys this wave needs: [klo, khi)
+  const int khi = ctx + t_first + nq;  // last query's position + 1  (<= seq_len)
+  const int klo = p.sliding_window > 0 ? max(0, ctx + t_first - p.sliding_window + 1) : 0;
+  const int tile0 = klo >> 4;
+  const int ntiles = ((khi + 15) >> 4) - tile0;
+
+  const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
+  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const int64_t bsb = p.kv_block_stride * 2;
+  const int koff = (g * BS + c) * 16;
+  const int voff = (c * BS + 4 * g) * 2;
+
+  // column c of block b: query token t_first + b*TQB + c/GP, head head0 + c%GP
+  const int cq = c >> p.gp_shift, ch = c & (GP - 1);
+  const bool head_ok = ch < nh;
+
+  // ---- Q fragments ----
+  u32x4_t qf[NB][NS];
+  int qpos[NB];  // absolute position of this lane's column in block b (masked columns: -1)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int t = b * TQB + cq;
+    const bool ok = head_ok && t < nq;
+    qpos[b] = ok ? ctx + t_first + t : -1;
+    const S* qrow = (const S*)p.q + (int64_t)(qbeg + t_first + t) * p.q_stride + (int64_t)(head0 + ch) * D;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int d8 = 4 * j + g;
+      qf[b][j] = u32x4_t{0, 0, 0, 0};
+      if (ok && d8 * 8 < D) qf[b][j] = *reinterpret_cast<const u32x4_t*>(qrow + d8 * 8);
+    }
+  }
+  const float alibi = (p.alibi_slopes != nullptr && head_ok) ? p.alibi_slopes[head0 + ch] * kLog2e : 0.f;
+  const float qk_scale = p.scale * kLog2e;
+  const bool use_alibi = p.alibi_slopes != nullptr;
+  const bool use_cap = p.softcap > 0.f;
+  const int window = p.sliding_window > 0 ? p.sliding_window : 0x3fffffff;
+
+  const int last_block = p.max_num_blocks_per_seq - 1;
+  auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
+    const int blk = ((tile0 + j) << 4) / BS;
+    return block_table[min(blk, last_block)];
+  };
+
+  float m_run[NB], l_run[NB];
+  f32x4_t acc[NB][NDT];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    m_run[b] = kMInit;
+    l_run[b] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) acc[b][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto load_tile = [&](u32x4_t (&k)[NS], u32x2_t (&v)[NDT], const int j, const int bn32)
+                       __attribute__((always_inline)) {
+    const bool valid = j < ntiles;
+    const int64_t bn = bn32;
+    const int tok_base = (tile0 + j) << 4;
+    const int off = (BS == 32) ? (tok_base & 16) : 0;
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+#pragma unroll
+    for (int jj = 0; jj < NS; ++jj)
+      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, 0);
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
+  };
+
+  auto compute_tile = [&](const u32x4_t (&k)[NS], const u32x2_t (&v)[NDT], const int j)
+                          __attribute__((always_inline)) {
+    const int tok0 = ((tile0 + j) << 4) + 4 * g;  // this lane's 4 key tokens
+    // V beyond the sequence may hold anything (NaN included): zero it (only the last tile can)
+    u32x2_t vz[NDT];
+    {
+      uint32_t mx = 0xffffffffu, my = 0xffffffffu;
+      if (tok0 + 0 >= seq_len) mx &= 0xffff0000u;
+      if (tok0 + 1 >= seq_len) mx &= 0x0000ffffu;
+      if (tok0 + 2 >= seq_len) my &= 0xffff0000u;
+      if (tok0 + 3 >= seq_len) my &= 0x0000ffffu;
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        vz[t].x = v[t].x & mx;
+        vz[t].y = v[t].y & my;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) s = mfma_qk<T>(k[jj], qf[b][jj], s);
+      float x[4];
+      float m_loc = kMasked;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = s[r] * qk_scale;
+        if (use_cap) y = p.softcap * kLog2e * tanhf(s[r] * p.scale / p.softcap);
+        if (use_alibi) y += alibi * (float)(tok0 + r - qpos[b]);
+        const int dist = qpos[b] - (tok0 + r);  // >= 0: visible under the causal mask
+        y = (dist >= 0 && dist < window) ? y : kMasked;
+        x[r] = y;
+        m_loc = fmaxf(m_loc, y);
+      }
+      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16));
+      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32));
+      const float m_new = fmaxf(m_run[b], m_loc);
+      const bool grew = m_new > m_run[b];
+      if (__builtin_amdgcn_ballot_w64(grew) != 0) {  // wave-uniform: rescale only when needed
+        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+        l_run[b] *= alpha;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t) acc[b][t] *= alpha;
+        m_run[b] = m_new;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
+        psum += x[r];
+      }
+      l_run[b] += psum;
+      u32x2_t pb;
+      pb.x = pack2<T>(x[0], x[1]);
+      pb.y = pack2<T>(x[2], x[3]);
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) acc[b][t] = mfma_pv<T>(vz[t], pb, acc[b][t]);
+    }
+  };
+
+  {
+    u32x4_t k0[NS], k1[NS];
+    u32x2_t v0[NDT], v1[NDT];
+    int bn0 = block_number(0), bn1 = block_number(1);
+    load_tile(k0, v0, 0, bn0);
+    bn0 = block_number(2);
+    for (int j = 0; j < ntiles; j += 2) {
+      load_tile(k1, v1, j + 1, bn1);
+      bn1 = block_number(j + 3);
+      compute_tile(k0, v0, j);
+      load_tile(k0, v0, j + 2, bn0);
+      bn0 = block_number(j + 4);
+      compute_tile(k1, v1, j + 1);
+    }
+  }
+
+  // ---- normalise and store: lane (g, c) holds d = 16t + 4g .. +3 of its column ----
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float l = l_run[b];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? __fdividef(1.f, l) : 0.f;
+    if (qpos[b] >= 0) {
+      const int t = b * TQB + cq;
+      S* orow = (S*)p.out + (int64_t)(qbeg + t_first + t) * p.out_stride + (int64_t)(head0 + ch) * D;
+#pragma unroll
+      for (int tt = 0; tt < NDT; ++tt) {
+        const int d = 16 * tt + 4 * g;
+        if (d < D) {
+          u32x2_t o;
+          o.x = pack2<T>(acc[b][tt][0] * inv, acc[b][tt][1] * inv);
+          o.y = pack2<T>(acc[b][tt][2] * inv, acc[b][tt][3] * inv);
+          *reinterpret_cast<u32x2_t*>(orow + d) = o;
+        }
+      }
+    }
+  }
+}
+
+#ifndef LVLLM_PREFILL_NB
+#define LVLLM_PREFILL_NB 2
+#endif
+
+template <typename T, int D, int BS>
+static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
+  constexpr int NB = D > 128 ? 1 : LVLLM_PREFILL_NB;  // accumulators: NB * D/4 VGPRs per lane
+  PrefillParams p = p0;
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 15) / 16;
+  p.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : 4;
+  const int tqwg = 4 * NB * (16 >> p.gp_shift);
+  const int qtiles = (max_query_len + tqwg - 1) / tqwg;
+  hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB>),
+                     dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
+  return 0;
+}
+
+template <typename T, int D>
+static int launch_prefill_bs(const PrefillParams& p, int block_size, int num_seqs, int max_query_len,
+                             hipStream_t stream) {
+  switch (block_size) {
+    case 16: return launch_prefill_gp<T, D, 16>(p, num_seqs, max_query_len, stream);
+    case 32: return launch_prefill_gp<T, D, 32>(p, num_seqs, max_query_len, stream);
+    default: LV_CHECK(false, "unsupported block size " + std::to_string(block_size));
+  }
+  return 0;
+}
+
+template <typename T>
+int launch_prefill_hs(const PrefillParams& p, int head_size, int block_size, int num_seqs,
+                      int max_query_len, hipStream_t stream) {
+  switch (head_size) {
+#define LV_HS(D_) \
+  case D_: return launch_prefill_bs<T, D_>(p, block_size, num_seqs, max_query_len, stream);
+    LV_HS(64) LV_HS(80) LV_HS(96) LV_HS(112) LV_HS(120) LV_HS(128) LV_HS(192) LV_HS(256)
+#undef LV_HS
+    default: LV_CHECK(false, "unsupported head size " + std::to_string(head_size));
+  }
+  return 0;
+}
+
+}  // namespace lvllm

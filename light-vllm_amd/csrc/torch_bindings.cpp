@@ -344,6 +344,36 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
   return true;
 }
 
+void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, const torch::Tensor& key_cache,
+                             const torch::Tensor& value_cache, int64_t num_kv_heads, double scale,
+                             const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
+                             const torch::Tensor& query_start_loc, int64_t max_query_len, int64_t block_size,
+                             const c10::optional<torch::Tensor>& alibi_slopes, int64_t sliding_window,
+                             double softcap, const std::string& kv_cache_dtype) {
+  LV_CHECK_DEVICE(query);
+  LV_CHECK_DEVICE(out);
+  TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "paged_prefill_attention: query/out must be [T, H, D]");
+  TORCH_CHECK(query.stride(2) == 1 && query.stride(1) == query.size(2) && out.stride(2) == 1 &&
+                  out.stride(1) == out.size(2),
+              "paged_prefill_attention: heads of a token must be contiguous");
+  TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt &&
+                  query_start_loc.scalar_type() == at::kInt,
+              "paged_prefill_attention: block_tables / seq_lens / query_start_loc must be int32");
+  TORCH_CHECK(block_tables.dim() == 2 && block_tables.is_contiguous());
+  const int64_t num_seqs = seq_lens.numel();
+  TORCH_CHECK(query_start_loc.numel() == num_seqs + 1 && block_tables.size(0) >= num_seqs);
+  TORCH_CHECK(value_cache.size(3) == block_size, "paged_prefill_attention: block_size does not match the cache");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
+  const float* alibi = alibi_slopes.has_value() ? alibi_slopes->data_ptr<float>() : nullptr;
+  check(lvllm_paged_prefill_attention(
+      out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs,
+      (int)query.size(1), (int)query.size(2), (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(),
+      seq_lens.data_ptr<int32_t>(), query_start_loc.data_ptr<int32_t>(), (int)max_query_len, (int)block_size,
+      (int)block_tables.size(1), alibi, (int)sliding_window, (float)softcap, query.stride(0), out.stride(0),
+      key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_prefill_attention"),
+      kv_dtype_code(kv_cache_dtype), current_stream(query)));
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -455,6 +485,11 @@ TORCH_LIBRARY(_C_amd, amd) {
           "int head_size, Tensor cos_sin_cache, bool is_neox, Tensor! key_cache, Tensor! value_cache, "
           "Tensor slot_mapping) -> bool");
   amd.impl("rotary_embedding_and_cache", torch::kCUDA, &rotary_embedding_and_cache);
+  amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
+          "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "
+          "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
+          "str kv_cache_dtype) -> ()");
+  amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
 }
 
 TORCH_LIBRARY(_C_cuda_utils, cuda_utils) {

@@ -60,3 +60,4 @@ class SchedulerConfig:
     scheduling: str = "sync"          # sync | simple_async | async | double_buffer
     max_num_on_the_fly: int = 2       # light_vllm/decoding/config.py:149-155
     preemption_mode: Optional[str] = None  # None | "swap" | "recompute"
+    chunked_prefill_enabled: bool = False  # decoding/config.py: prompts are cut to the token budget

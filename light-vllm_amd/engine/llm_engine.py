@@ -136,9 +136,10 @@ class LLMEngine:
             num_gpu, auto_cpu = self.worker.determine_num_available_blocks()
             num_cpu = auto_cpu if num_cpu is None else num_cpu
         self.worker.initialize_cache(num_gpu, num_cpu or 0)
-        self.scheduler = DecodingScheduler(scheduler_config, cache_config)
+        chunked = scheduler_config.chunked_prefill_enabled
+        self.scheduler = DecodingScheduler(scheduler_config, cache_config, chunked_prefill_enabled=chunked)
         self.input_builder = ModelInputBuilder(scheduler_config, cache_config, self.attn_backend,
-                                               cache_config.sliding_window)
+                                               cache_config.sliding_window, chunked_prefill_enabled=chunked)
         self.eos_token_id = eos_token_id
         self.seq_counter = 0
         self.groups: Dict[str, SequenceGroup] = {}

@@ -121,6 +121,31 @@ class PagedAttention:
         return output
 
     @staticmethod
+    def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                       key_cache: torch.Tensor, value_cache: torch.Tensor, block_tables: torch.Tensor,
+                       query_start_loc: torch.Tensor, seq_lens_tensor: torch.Tensor,
+                       context_lens: Optional[torch.Tensor], max_query_len: int,
+                       alibi_slopes: Optional[torch.Tensor], sliding_window: Optional[int],
+                       scale: Optional[float] = None, softcap: float = 0.0,
+                       kv_cache_dtype: str = "auto", output: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Prompt chunks against the paged cache (paged_attn.py:194-225 of the reference, which
+        runs the Triton context_attention_fwd; the live backend calls flash_attn_varlen_func with
+        block_table, flash_attn.py:538-555).  query [T, H, D]; `key`/`value` of the chunk must
+        already be in the cache (write_to_paged_cache runs first in both reference backends), so
+        they are not read here; `context_lens` is implied by seq_lens - query lengths."""
+        del key, value, context_lens
+        if output is None:
+            output = torch.empty_like(query)
+        num_kv_heads = key_cache.shape[1]
+        if scale is None:
+            scale = float(query.shape[-1]) ** -0.5  # context_attention_fwd's own default
+        ops.paged_prefill_attention(output, query, key_cache, value_cache, num_kv_heads, scale,
+                                    block_tables, seq_lens_tensor, query_start_loc, max_query_len,
+                                    value_cache.shape[3], alibi_slopes, sliding_window or 0, softcap,
+                                    kv_cache_dtype)
+        return output
+
+    @staticmethod
     def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
                     src_to_dst: torch.Tensor) -> None:
         ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)

@@ -79,6 +79,20 @@ def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, val
         _l(key_cache.stride(0)), _l(key_cache.stride(1)), _i(_DT[query.dtype]))
 
 
+def paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                            seq_lens, query_start_loc, block_size, alibi_slopes=None,
+                            sliding_window=0, softcap=0.0):
+    """query/out [T, H, D]; see oracle_paged_prefill_attention (flash_attn.py:538-555)."""
+    assert block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32
+    assert query_start_loc.dtype == torch.int32 and out.stride(1) == out.size(2)
+    lib().oracle_paged_prefill_attention(
+        _p(out), _p(query), _p(key_cache), _p(value_cache), _i(seq_lens.numel()), _i(query.size(1)),
+        _i(query.size(2)), _i(num_kv_heads), _f(scale), _p(block_tables), _p(seq_lens),
+        _p(query_start_loc), _i(block_size), _i(block_tables.size(1)), _p(alibi_slopes),
+        _i(sliding_window), _f(softcap), _l(query.stride(0)), _l(out.stride(0)),
+        _l(key_cache.stride(0)), _l(key_cache.stride(1)), _i(_DT[query.dtype]))
+
+
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):
     assert slot_mapping.dtype == torch.int64
     lib().oracle_reshape_and_cache(

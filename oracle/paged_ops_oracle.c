@@ -212,6 +212,95 @@ void oracle_paged_attention_v1(void* out, const void* query, const void* key_cac
   }
 }
 
+/* ---------------------------------------------------------------------------------
+ * Causal varlen attention of prompt chunks over the paged cache (prefill / chunked prefill /
+ * prefix hits).  The reference delegates this to the third-party vllm-flash-attn 2.6.1
+ * (requirements.txt:32, not under /root/reference) through
+ *   flash_attn_varlen_func(q, key_cache, value_cache, cu_seqlens_q, cu_seqlens_k, causal=True,
+ *                          window_size, alibi_slopes, block_table, softcap)
+ * light_vllm/decoding/backends/attention/backends/flash_attn.py:538-555.  Restated from the
+ * published FlashAttention-2 algorithm with the in-tree definition of the same function as
+ * anchor (scaled_dot_product_attention, prefill_only/backends/attention/backends/torch_naive.py:125-149):
+ *   logits = scale * q.k (fp32)  [softcap: cap * tanh(logits / cap)]  + alibi * (key - query position)
+ *   causal mask aligned to the bottom-right corner: query t of a chunk of L tokens in a context of S
+ *   sits at position S - L + t and sees keys 0 .. position (the last `window` of them if window > 0)
+ *   P = exp(logits - max) rounded to T for the P.V product, fp32 accumulation, divided by the
+ *   fp32 sum of the unrounded exponentials, result rounded to T.
+ * ------------------------------------------------------------------------------- */
+void oracle_paged_prefill_attention(void* out, const void* query, const void* key_cache,
+                                    const void* value_cache, int num_seqs, int num_heads,
+                                    int head_size, int num_kv_heads, float scale,
+                                    const int32_t* block_tables, const int32_t* seq_lens,
+                                    const int32_t* query_start_loc, int block_size,
+                                    int max_num_blocks_per_seq, const float* alibi_slopes,
+                                    int sliding_window, float softcap, int64_t q_stride,
+                                    int64_t out_stride, int64_t kv_block_stride,
+                                    int64_t kv_head_stride, int dt) {
+  const int x = 16 / esize(dt);
+  const int G = num_heads / num_kv_heads;
+  int max_len = 1;
+  for (int s = 0; s < num_seqs; ++s)
+    if (seq_lens[s] > max_len) max_len = seq_lens[s];
+  const int num_tokens = query_start_loc[num_seqs];
+  /* token -> sequence */
+  int* seq_of = (int*)malloc(sizeof(int) * (size_t)(num_tokens > 0 ? num_tokens : 1));
+  for (int s = 0; s < num_seqs; ++s)
+    for (int t = query_start_loc[s]; t < query_start_loc[s + 1]; ++t) seq_of[t] = s;
+#pragma omp parallel
+  {
+    float* logits = (float*)malloc(sizeof(float) * (size_t)max_len);
+    float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+#pragma omp for collapse(2) schedule(dynamic, 4)
+    for (int tok = 0; tok < num_tokens; ++tok)
+      for (int h = 0; h < num_heads; ++h) {
+        const int s = seq_of[tok];
+        const int qlen = query_start_loc[s + 1] - query_start_loc[s];
+        const int pos = seq_lens[s] - qlen + (tok - query_start_loc[s]);
+        const int32_t* bt = block_tables + (int64_t)s * max_num_blocks_per_seq;
+        const int kvh = h / G;
+        const int64_t q_off = (int64_t)tok * q_stride + (int64_t)h * head_size;
+        int k0 = 0;
+        if (sliding_window > 0 && pos - sliding_window + 1 > 0) k0 = pos - sliding_window + 1;
+        const int n = pos + 1 - k0;
+        float mx = -FLT_MAX;
+        for (int i = 0; i < n; ++i) {
+          const int key = k0 + i;
+          const int64_t kb = (int64_t)bt[key / block_size] * kv_block_stride + (int64_t)kvh * kv_head_stride;
+          const int off = key % block_size;
+          float dot = 0.f;
+          for (int d = 0; d < head_size; ++d)
+            dot += ld(query, dt, q_off + d) *
+                   ld(key_cache, dt, kb + (int64_t)(d / x) * block_size * x + (int64_t)off * x + (d % x));
+          float qk = scale * dot;
+          if (softcap > 0.f) qk = softcap * tanhf(qk / softcap);
+          if (alibi_slopes) qk += alibi_slopes[h] * (float)(key - pos);
+          logits[i] = qk;
+          mx = fmaxf(mx, qk);
+        }
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) {
+          const float e = expf(logits[i] - mx);
+          sum += e;
+          logits[i] = rnd(e, dt);
+        }
+        for (int d = 0; d < head_size; ++d) acc[d] = 0.f;
+        for (int i = 0; i < n; ++i) {
+          const int key = k0 + i;
+          const int64_t vb = (int64_t)bt[key / block_size] * kv_block_stride + (int64_t)kvh * kv_head_stride +
+                             key % block_size;
+          const float pr = logits[i];
+          for (int d = 0; d < head_size; ++d) acc[d] += pr * ld(value_cache, dt, vb + (int64_t)d * block_size);
+        }
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        for (int d = 0; d < head_size; ++d)
+          st(out, dt, (int64_t)tok * out_stride + (int64_t)h * head_size + d, acc[d] * inv);
+      }
+    free(logits);
+    free(acc);
+  }
+  free(seq_of);
+}
+
 /* paged_attention_v2 + reduce: csrc/attention/attention_kernels.cu:529-669, 848-997.
  * tmp_out/exp_sums/max_logits are filled exactly where the GPU kernel fills them
  * (every partition that holds tokens, also when there is only one). */

@@ -79,3 +79,61 @@ def v2_scratch(num_seqs, num_heads, head_size, max_seq_len, dtype, device="cpu")
     exp_sums = torch.zeros(num_seqs, num_heads, P, dtype=torch.float32, device=device)
     max_logits = torch.zeros_like(exp_sums)
     return exp_sums, max_logits, tmp_out
+
+
+def make_prefill_inputs(num_heads, num_kv_heads, head_size, block_size, seq_lens, query_lens,
+                        dtype=torch.bfloat16, seed=0, garbage=None):
+    """Prompt chunks over a paged cache: sequence i has seq_lens[i] tokens in the cache, the last
+    query_lens[i] of which are the chunk being computed.  Adds query [T, H, D], query_start_loc,
+    max_query_len to make_paged_inputs' dict.  `garbage`: value written into the cache slots past
+    each sequence's end (NaN tests)."""
+    inp = make_paged_inputs(len(seq_lens), num_heads, num_kv_heads, head_size, block_size, seq_lens,
+                            dtype=dtype, seed=seed)
+    assert all(0 <= q <= s for q, s in zip(query_lens, seq_lens))
+    g = torch.Generator().manual_seed(seed + 1000)
+    T = sum(query_lens)
+    inp["query"] = (torch.randn(T, num_heads, head_size, generator=g) * 0.5).to(dtype)
+    qsl = [0]
+    for q in query_lens:
+        qsl.append(qsl[-1] + q)
+    inp["query_start_loc"] = torch.tensor(qsl, dtype=torch.int32)
+    inp["query_lens"] = list(query_lens)
+    inp["max_query_len"] = max(query_lens) if query_lens else 0
+    if garbage is not None:
+        for s, n in enumerate(seq_lens):
+            nb = inp["block_tables"].shape[1]
+            for t in range(n, nb * block_size):
+                b = int(inp["block_tables"][s, t // block_size])
+                inp["key_cache"][b, :, :, t % block_size, :] = garbage
+                inp["value_cache"][b, :, :, t % block_size] = garbage
+    return inp
+
+
+def dense_prefill_fp64(inp, alibi_slopes=None, sliding_window=0, softcap=0.0):
+    """Independent fp64 statement of causal varlen attention, bottom-right aligned:
+    query t of a chunk of L tokens in a context of S tokens sits at position S - L + t."""
+    q = inp["query"]
+    T, H, D = q.shape
+    KVH = inp["num_kv_heads"]
+    out = torch.zeros(T, H, D, dtype=torch.float64)
+    qsl = inp["query_start_loc"].tolist()
+    for s, S in enumerate(inp["seq_lens"].tolist()):
+        L = qsl[s + 1] - qsl[s]
+        if L == 0:
+            continue
+        k, v = inp["k_dense"][s].double(), inp["v_dense"][s].double()
+        pos = torch.arange(S - L, S)
+        keys = torch.arange(S)
+        mask = keys[None, :] <= pos[:, None]
+        if sliding_window > 0:
+            mask &= keys[None, :] > pos[:, None] - sliding_window
+        for h in range(H):
+            kv = h // (H // KVH)
+            logits = (q[qsl[s]:qsl[s + 1], h].double() @ k[:, kv].T) * inp["scale"]
+            if softcap > 0:
+                logits = softcap * torch.tanh(logits / softcap)
+            if alibi_slopes is not None:
+                logits = logits + alibi_slopes[h].double() * (keys[None, :] - pos[:, None]).double()
+            logits = logits.masked_fill(~mask, float("-inf"))
+            out[qsl[s]:qsl[s + 1], h] = torch.softmax(logits, dim=1) @ v[:, kv]
+    return out

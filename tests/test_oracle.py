@@ -163,3 +163,81 @@ def test_oracle_v2_scratch_semantics():
     merged = (tmp[0] * (w / w.sum(-1, keepdim=True)).unsqueeze(-1)).sum(1)
     assert torch.allclose(merged, o1[0], rtol=1e-4, atol=1e-6)
     assert torch.equal(o2[1], tmp[1, :, 0])  # single partition: copied through
+
+
+# ---- prefill (next row §8f-1): the oracle's varlen causal attention over the paged cache ----
+def _sdpa_reference(inp, alibi=None, window=0):
+    """torch.nn.functional.scaled_dot_product_attention in fp32 on the gathered dense K/V: the
+    function the reference's in-tree prefill backends evaluate (torch_naive.py:125-149 restates
+    it, torch_sdpa.py calls it), with the bottom-right causal mask of a chunk over its context."""
+    from helpers import dense_prefill_fp64  # noqa: F401  (same mask convention)
+    q = inp["query"].float()
+    T, H, D = q.shape
+    KVH = inp["num_kv_heads"]
+    out = torch.zeros(T, H, D)
+    qsl = inp["query_start_loc"].tolist()
+    for s, S in enumerate(inp["seq_lens"].tolist()):
+        L = qsl[s + 1] - qsl[s]
+        if L == 0:
+            continue
+        k = inp["k_dense"][s].float().repeat_interleave(H // KVH, dim=1).transpose(0, 1)
+        v = inp["v_dense"][s].float().repeat_interleave(H // KVH, dim=1).transpose(0, 1)
+        pos = torch.arange(S - L, S)[:, None]
+        keys = torch.arange(S)[None, :]
+        mask = keys <= pos
+        if window:
+            mask &= keys > pos - window
+        bias = torch.zeros(H, L, S)
+        if alibi is not None:
+            bias += alibi[:, None, None] * (keys - pos).float()[None]
+        bias = bias.masked_fill(~mask[None], float("-inf"))
+        o = torch.nn.functional.scaled_dot_product_attention(
+            q[qsl[s]:qsl[s + 1]].transpose(0, 1)[None], k[None], v[None], attn_mask=bias[None],
+            scale=inp["scale"])[0]
+        out[qsl[s]:qsl[s + 1]] = o.transpose(0, 1)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["prompts", "chunks", "window", "alibi"])
+def test_prefill_oracle_vs_torch_sdpa(case, dtype):
+    from helpers import make_prefill_inputs
+    H, KVH, D, BS = 8, 2, 64, 16
+    if case == "prompts":
+        seq, ql = [37, 64, 5, 1], [37, 64, 5, 1]
+    else:
+        seq, ql = [37, 90, 17, 48, 33], [37, 10, 1, 16, 0]
+    inp = make_prefill_inputs(H, KVH, D, BS, seq, ql, dtype=dtype, seed=11)
+    alibi = torch.tensor([0.5 ** (i + 1) for i in range(H)]) if case == "alibi" else None
+    window = 24 if case == "window" else 0
+    out = torch.full_like(inp["query"], float("nan"))
+    oracle.paged_prefill_attention(out, inp["query"], inp["key_cache"], inp["value_cache"], KVH,
+                                   inp["scale"], inp["block_tables"], inp["seq_lens"],
+                                   inp["query_start_loc"], BS, alibi_slopes=alibi, sliding_window=window)
+    want = _sdpa_reference(inp, alibi, window)
+    # T-rounded probabilities and output: 2^-8 relative for bf16, 2^-11 for f16, at row scale
+    tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(1.0, float(want.abs().max()))
+    assert torch.isfinite(out).all()
+    assert float((out.float() - want).abs().max()) <= tol
+
+
+def test_prefill_oracle_softcap_and_decode_equivalence():
+    """softcap follows cap*tanh(x/cap); a chunk of one token equals paged_attention_v1 of the
+    same sequence up to the 1e-6 in the decode normaliser."""
+    from helpers import dense_prefill_fp64, make_prefill_inputs
+    H, KVH, D, BS = 4, 4, 64, 16
+    inp = make_prefill_inputs(H, KVH, D, BS, [50, 81], [1, 1], dtype=torch.float16, seed=5)
+    a = torch.zeros_like(inp["query"])
+    oracle.paged_prefill_attention(a, inp["query"], inp["key_cache"], inp["value_cache"], KVH, inp["scale"],
+                                   inp["block_tables"], inp["seq_lens"], inp["query_start_loc"], BS)
+    b = torch.zeros_like(inp["query"])
+    oracle.paged_attention_v1(b, inp["query"], inp["key_cache"], inp["value_cache"], KVH, inp["scale"],
+                              inp["block_tables"], inp["seq_lens"], BS, 81)
+    assert float((a.float() - b.float()).abs().max()) <= 2e-3
+    c = torch.zeros_like(inp["query"])
+    oracle.paged_prefill_attention(c, inp["query"], inp["key_cache"], inp["value_cache"], KVH, 4.0,
+                                   inp["block_tables"], inp["seq_lens"], inp["query_start_loc"], BS,
+                                   softcap=2.0)
+    inp["scale"] = 4.0
+    want = dense_prefill_fp64(inp, softcap=2.0)
+    assert float((c.double() - want).abs().max()) <= 2e-3

@@ -1,0 +1,190 @@
+"""Parity of the HIP prefill kernel (torch.ops._C_amd.paged_prefill_attention -> C-ABI
+lvllm_paged_prefill_attention -> prefill_mfma.h) against the CPU oracle and an independent fp64
+dense computation: prompts, chunked prefill over a cached context, prefix hits, ragged batches.
+
+Bar (same as paged_attention): max-abs <= 2e-2 * max|out| and cosine >= 0.999 per
+(token, head) against the oracle and against fp64.
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import dense_prefill_fp64, make_prefill_inputs
+from oracle import oracle
+from test_ops_gpu import check_attention, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_hip(ops, inp, alibi=None, window=0, softcap=0.0, out=None):
+    d = to_dev(inp)
+    if out is None:
+        out = torch.full_like(d["query"], float("nan"))
+    ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], inp["num_kv_heads"],
+                                inp["scale"], d["block_tables"], d["seq_lens"], d["query_start_loc"],
+                                inp["max_query_len"], inp["block_size"],
+                                alibi.to(DEV) if alibi is not None else None, window, softcap, "auto")
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle(inp, alibi=None, window=0, softcap=0.0):
+    out = torch.zeros_like(inp["query"])
+    oracle.paged_prefill_attention(out, inp["query"], inp["key_cache"], inp["value_cache"],
+                                   inp["num_kv_heads"], inp["scale"], inp["block_tables"], inp["seq_lens"],
+                                   inp["query_start_loc"], inp["block_size"], alibi_slopes=alibi,
+                                   sliding_window=window, softcap=softcap)
+    return out
+
+
+RAGGED = dict(seq=[37, 200, 5, 1, 129, 64, 48], ql=[37, 40, 5, 1, 129, 0, 17])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("H,KVH", [(8, 8), (8, 4), (8, 2), (14, 2), (8, 1), (16, 1), (20, 1)])
+def test_prefill_gqa_groups(ops, dtype, block_size, H, KVH):
+    inp = make_prefill_inputs(H, KVH, 64, block_size, RAGGED["seq"], RAGGED["ql"], dtype=dtype, seed=H + KVH)
+    out = run_hip(ops, inp)
+    assert torch.isfinite(out).all()
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+@pytest.mark.parametrize("head_size", [64, 80, 96, 112, 120, 128, 192, 256])
+def test_prefill_head_sizes(ops, head_size):
+    inp = make_prefill_inputs(8, 2, head_size, 16, [150, 33, 70], [150, 33, 19], dtype=torch.bfloat16, seed=head_size)
+    out = run_hip(ops, inp)
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+@pytest.mark.parametrize("case", ["window", "alibi", "softcap", "window+alibi"])
+def test_prefill_masks_and_biases(ops, case):
+    H = 8
+    inp = make_prefill_inputs(H, 2, 128, 16, [300, 90, 17, 64], [300, 10, 1, 48], dtype=torch.float16, seed=3)
+    alibi = torch.tensor([0.5 ** (i + 1) for i in range(H)]) if "alibi" in case else None
+    window = 50 if "window" in case else 0
+    softcap = 1.5 if case == "softcap" else 0.0
+    if softcap:
+        inp["scale"] = 1.0
+    out = run_hip(ops, inp, alibi, window, softcap)
+    check_attention(out, run_oracle(inp, alibi, window, softcap), dense_prefill_fp64(inp, alibi, window, softcap))
+
+
+def test_prefill_garbage_beyond_the_sequence_is_ignored(ops):
+    """Cache slots past seq_len (rest of the last block, padding blocks) may hold NaN."""
+    inp = make_prefill_inputs(8, 2, 128, 16, [35, 70, 17], [35, 21, 1], dtype=torch.bfloat16, seed=9,
+                              garbage=float("nan"))
+    out = run_hip(ops, inp)
+    assert torch.isfinite(out).all()
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+def test_prefill_late_spike_forces_rescale(ops):
+    """A key near the end of the context with a much larger logit: the lazy accumulator
+    rescale must fire for the columns that see it and only for those."""
+    inp = make_prefill_inputs(4, 1, 128, 16, [400], [64], dtype=torch.bfloat16, seed=21)
+    # make key 390 align with every query of head 0
+    s = 0
+    b = int(inp["block_tables"][s, 390 // 16])
+    k = torch.ones(128, dtype=torch.bfloat16) * 1.5
+    inp["key_cache"][b, 0, :, 390 % 16, :] = k.view(16, 8)
+    inp["k_dense"][s][390, 0] = k
+    inp["query"][:, 0] = 1.0
+    out = run_hip(ops, inp)
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+def test_prefill_chunks_compose_to_the_whole_prompt(ops):
+    """Chunked prefill: computing a 300-token prompt in chunks of 128/128/44 against the same
+    cache gives, row for row, the bits of the single-chunk run (each query's key walk is the same
+    sequence of tiles whichever chunk it is in)."""
+    inp = make_prefill_inputs(8, 2, 128, 16, [300], [300], dtype=torch.bfloat16, seed=4)
+    whole = run_hip(ops, inp)
+    pieces = []
+    done = 0
+    for n in (128, 128, 44):
+        part = dict(inp)
+        part["query"] = inp["query"][done:done + n].contiguous()
+        part["seq_lens"] = torch.tensor([done + n], dtype=torch.int32)
+        part["query_start_loc"] = torch.tensor([0, n], dtype=torch.int32)
+        part["max_query_len"] = n
+        pieces.append(run_hip(ops, part))
+        done += n
+    got = torch.cat(pieces)
+    assert torch.equal(got.view(torch.int16), whole.view(torch.int16))
+
+
+def test_prefill_single_token_chunks_match_decode(ops):
+    """query_len 1 everywhere: the kernel computes what paged_attention_v1 computes."""
+    inp = make_prefill_inputs(32, 8, 128, 16, [100, 257, 16, 1], [1, 1, 1, 1], dtype=torch.bfloat16, seed=8)
+    out = run_hip(ops, inp)
+    d = to_dev(inp)
+    dec = torch.zeros_like(d["query"])
+    ops.paged_attention_v1(dec, d["query"], d["key_cache"], d["value_cache"], 8, inp["scale"], d["block_tables"],
+                           d["seq_lens"], 16, 257, None, "auto", 1.0, 1.0)
+    check_attention(out, dec.cpu(), None, tol=5e-3)
+
+
+def test_prefill_strided_query_and_output(ops):
+    """query as a view of the fused qkv projection, output into a slice of a wider buffer."""
+    H, KVH, D = 8, 2, 128
+    inp = make_prefill_inputs(H, KVH, D, 16, [90, 40], [50, 40], dtype=torch.bfloat16, seed=12)
+    T = inp["query"].shape[0]
+    qkv = torch.zeros(T, (H + 2 * KVH) * D, dtype=torch.bfloat16)
+    qkv[:, :H * D] = inp["query"].view(T, H * D)
+    d = to_dev(inp)
+    q_view = qkv.to(DEV)[:, :H * D].view(T, H, D)
+    wide = torch.zeros(T, 2 * H * D, dtype=torch.bfloat16, device=DEV)
+    out_view = wide[:, :H * D].view(T, H, D)
+    ops.paged_prefill_attention(out_view, q_view, d["key_cache"], d["value_cache"], KVH, inp["scale"],
+                                d["block_tables"], d["seq_lens"], d["query_start_loc"], inp["max_query_len"], 16,
+                                None, 0, 0.0, "auto")
+    torch.cuda.synchronize()
+    assert float(wide[:, H * D:].abs().max()) == 0.0
+    check_attention(out_view, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+def test_prefill_argument_errors(ops):
+    inp = make_prefill_inputs(8, 2, 128, 16, [20], [20], dtype=torch.bfloat16)
+    d = to_dev(inp)
+    out = torch.zeros_like(d["query"])
+    with pytest.raises(RuntimeError, match="int32"):
+        ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], 2, 1.0,
+                                    d["block_tables"].long(), d["seq_lens"], d["query_start_loc"], 20, 16,
+                                    None, 0, 0.0, "auto")
+    with pytest.raises(RuntimeError, match="fp8"):
+        ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], 2, 1.0,
+                                    d["block_tables"], d["seq_lens"], d["query_start_loc"], 20, 16,
+                                    None, 0, 0.0, "fp8")
+    with pytest.raises(RuntimeError, match="float16 or bfloat16"):
+        ops.paged_prefill_attention(out.float(), d["query"].float(), d["key_cache"], d["value_cache"], 2, 1.0,
+                                    d["block_tables"], d["seq_lens"], d["query_start_loc"], 20, 16,
+                                    None, 0, 0.0, "auto")
+
+
+def test_prefill_long_prompt_properties(ops):
+    """Config-3 sized (one 4096-token prompt, Llama-3-8B heads): too big for the scalar oracle in
+    seconds, so check sampled rows against fp64 and block-permutation invariance bit for bit."""
+    H, KVH, D, BS, S = 32, 8, 128, 16, 4096
+    inp = make_prefill_inputs(H, KVH, D, BS, [S], [S], dtype=torch.bfloat16, seed=77)
+    out = run_hip(ops, inp).cpu()
+    # sampled rows vs fp64
+    k, v = inp["k_dense"][0].double(), inp["v_dense"][0].double()
+    for t in (0, 1, 15, 16, 17, 1023, 2048, 4095):
+        for h in (0, 5, 31):
+            logits = (k[:t + 1, h // 4] @ inp["query"][t, h].double()) * inp["scale"]
+            want = torch.softmax(logits, 0) @ v[:t + 1, h // 4]
+            assert float((out[t, h].double() - want).abs().max()) <= 2e-2 * max(float(want.abs().max()), 1e-3)
+    # same data under another physical block placement: identical bits
+    nb = inp["key_cache"].shape[0]
+    perm = torch.randperm(nb, generator=torch.Generator().manual_seed(1))
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb)
+    inp2 = dict(inp)
+    inp2["key_cache"] = inp["key_cache"][perm]
+    inp2["value_cache"] = inp["value_cache"][perm]
+    inp2["block_tables"] = inv[inp["block_tables"].long()].to(torch.int32)
+    out2 = run_hip(ops, inp2).cpu()
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
