@@ -49,7 +49,9 @@ struct PrefillParams {
 
 // Column layout of one 16-column MFMA block: column c = (query token c / GP, head c % GP) with
 // GP = 1 << gp_shift = the GQA group size rounded up to a power of two (<= 16).
-template <typename T, int D, int BS, int NB>
+// EXTRAS = ALiBi / soft cap / sliding window present (every tile is masked and biased per element);
+// the plain causal instantiation masks only the tiles that straddle the diagonal.
+template <typename T, int D, int BS, int NB, bool EXTRAS>
 __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const PrefillParams p) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
@@ -141,30 +143,46 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
     for (int t = 0; t < NDT; ++t) acc[b][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  auto load_tile = [&](u32x4_t (&k)[NS], u32x2_t (&v)[NDT], const int j, const int bn32)
-                       __attribute__((always_inline)) {
-    const bool valid = j < ntiles;
+  // ---- unit of work: a PAIR of 16-token tiles (A, B) = 32 keys --------------------------------
+  // S_A, S_B = K.Q^T per tile; one softmax step over the 32 keys; O^T += V^T.P^T with the
+  // K=32 MFMA, whose k-slot 8g+e of lane (g, c) is (tile e>>2, token 4g + (e&3)) on BOTH operands:
+  // A operand = {V_A piece, V_B piece} as loaded, B operand = {P_A, P_B} as computed.
+  const int npairs = (ntiles + 1) >> 1;
+  auto tile_rsrc = [&](const char* base, const int j, const int bn32) __attribute__((always_inline)) {
     const int64_t bn = bn32;
-    const int tok_base = (tile0 + j) << 4;
-    const int off = (BS == 32) ? (tok_base & 16) : 0;
-    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + bn * bsb), 0, j < ntiles ? kHeadBytes : 0,
+                                             kSrdFlags);
+  };
+  auto tile_off = [&](const int j) __attribute__((always_inline)) -> int {
+    return (BS == 32) ? (((tile0 + j) << 4) & 16) : 0;  // second half of a 32-token block
+  };
+  auto load_k = [&](u32x4_t (&k)[NS], const int j, const int bn32) __attribute__((always_inline)) {
+    __amdgpu_buffer_rsrc_t kr = tile_rsrc(kbytes, j, bn32);
+    const int off = tile_off(j);
 #pragma unroll
     for (int jj = 0; jj < NS; ++jj)
       k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, 0);
+  };
+  auto load_v = [&](u32x2_t (&v)[NDT], const int j, const int bn32) __attribute__((always_inline)) {
+    __amdgpu_buffer_rsrc_t vr = tile_rsrc(vbytes, j, bn32);
+    const int off = tile_off(j);
 #pragma unroll
     for (int t = 0; t < NDT; ++t)
       v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
   };
-
-  auto compute_tile = [&](const u32x4_t (&k)[NS], const u32x2_t (&v)[NDT], const int j)
-                          __attribute__((always_inline)) {
-    const int tok0 = ((tile0 + j) << 4) + 4 * g;  // this lane's 4 key tokens
+  // butterfly max over the 4 lane groups g (rows of 16 lanes) without LDS: the gfx950 row swaps.
+  // (inline asm: hipcc folds the builtin form of swap(x, x) + max away.)
+  auto group_max = [&](float x) __attribute__((always_inline)) -> float {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    b = a;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
+  };
+  auto zero_tail = [&](u32x2_t (&v)[NDT], const int tile_base) __attribute__((always_inline)) {
     // V beyond the sequence may hold anything (NaN included): zero it (only the last tile can)
-    u32x2_t vz[NDT];
-    {
+    if (tile_base + 16 > seq_len) {
+      const int tok0 = tile_base + 4 * g;
       uint32_t mx = 0xffffffffu, my = 0xffffffffu;
       if (tok0 + 0 >= seq_len) mx &= 0xffff0000u;
       if (tok0 + 1 >= seq_len) mx &= 0x0000ffffu;
@@ -172,67 +190,105 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
       if (tok0 + 3 >= seq_len) my &= 0x0000ffffu;
 #pragma unroll
       for (int t = 0; t < NDT; ++t) {
-        vz[t].x = v[t].x & mx;
-        vz[t].y = v[t].y & my;
+        v[t].x &= mx;
+        v[t].y &= my;
       }
     }
+  };
+
+  const int q_first_pos = ctx + t_first;  // position of the wave's first query
+  // exponent = y * kf - m * kf: the plain path keeps y = raw q.k and folds scale*log2(e) into
+  // the FMA; with extras y is already the biased logit in log2 units
+  const float kf = EXTRAS ? 1.f : qk_scale;
+
+  u32x4_t kA[NS], kB[NS];
+  u32x2_t vA[NDT], vB[NDT];
+  {
+    const int bnA = block_number(0), bnB = block_number(1);
+    load_k(kA, 0, bnA);
+    load_k(kB, 1, bnB);
+    load_v(vA, 0, bnA);
+    load_v(vB, 1, bnB);
+  }
+  int bnA = block_number(2), bnB = block_number(3);
+  for (int jp = 0; jp < npairs; ++jp) {
+    const int j = 2 * jp;
+    const int base = (tile0 + j) << 4;
+    // ---- S = K.Q^T for both tiles and all column blocks, then the K registers are free ----
+    f32x4_t sA[NB], sB[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      sA[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      sB[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jj = 0; jj < NS; ++jj) s = mfma_qk<T>(k[jj], qf[b][jj], s);
-      float x[4];
-      float m_loc = kMasked;
+      for (int jj = 0; jj < NS; ++jj) sA[b] = mfma_qk<T>(kA[jj], qf[b][jj], sA[b]);
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) sB[b] = mfma_qk<T>(kB[jj], qf[b][jj], sB[b]);
+    }
+    load_k(kA, j + 2, bnA);
+    load_k(kB, j + 3, bnB);
+    zero_tail(vA, base);
+    zero_tail(vB, base + 16);
+    const bool need_mask = EXTRAS || base + 31 > q_first_pos;
+    u32x4_t pb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float y[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float y = s[r] * qk_scale;
-        if (use_cap) y = p.softcap * kLog2e * tanhf(s[r] * p.scale / p.softcap);
-        if (use_alibi) y += alibi * (float)(tok0 + r - qpos[b]);
-        const int dist = qpos[b] - (tok0 + r);  // >= 0: visible under the causal mask
-        y = (dist >= 0 && dist < window) ? y : kMasked;
-        x[r] = y;
-        m_loc = fmaxf(m_loc, y);
+        y[r] = sA[b][r];
+        y[4 + r] = sB[b][r];
       }
-      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16));
-      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32));
+      if constexpr (EXTRAS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int tok = base + ((e >> 2) << 4) + 4 * g + (e & 3);
+          float z = y[e] * qk_scale;
+          if (use_cap) z = p.softcap * kLog2e * tanhf(y[e] * p.scale / p.softcap);
+          if (use_alibi) z += alibi * (float)(tok - qpos[b]);
+          y[e] = z;
+        }
+      }
+      if (need_mask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int tok = base + ((e >> 2) << 4) + 4 * g + (e & 3);
+          const int dist = qpos[b] - tok;  // >= 0: visible under the causal mask
+          const bool vis = EXTRAS ? (dist >= 0 && dist < window) : dist >= 0;
+          y[e] = vis ? y[e] : kMasked;
+        }
+      }
+      float m_loc = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+      m_loc = group_max(m_loc);
       const float m_new = fmaxf(m_run[b], m_loc);
-      const bool grew = m_new > m_run[b];
-      if (__builtin_amdgcn_ballot_w64(grew) != 0) {  // wave-uniform: rescale only when needed
-        const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run[b]) != 0) {  // wave-uniform: rescale only when needed
+        const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * kf);
         l_run[b] *= alpha;
 #pragma unroll
         for (int t = 0; t < NDT; ++t) acc[b][t] *= alpha;
         m_run[b] = m_new;
       }
+      const float mk = m_new * kf;
       float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
-        psum += x[r];
+      for (int e = 0; e < 8; ++e) {
+        y[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(y[e], kf, -mk));
+        psum += y[e];
       }
       l_run[b] += psum;
-      u32x2_t pb;
-      pb.x = pack2<T>(x[0], x[1]);
-      pb.y = pack2<T>(x[2], x[3]);
+      pb[b] = u32x4_t{pack2<T>(y[0], y[1]), pack2<T>(y[2], y[3]), pack2<T>(y[4], y[5]), pack2<T>(y[6], y[7])};
+    }
+    // ---- O^T += V^T.P^T, contraction over the 32 keys of the pair ----
 #pragma unroll
-      for (int t = 0; t < NDT; ++t) acc[b][t] = mfma_pv<T>(vz[t], pb, acc[b][t]);
+    for (int t = 0; t < NDT; ++t) {
+      const u32x4_t va = u32x4_t{vA[t].x, vA[t].y, vB[t].x, vB[t].y};
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b][t] = mfma_qk<T>(va, pb[b], acc[b][t]);
     }
-  };
-
-  {
-    u32x4_t k0[NS], k1[NS];
-    u32x2_t v0[NDT], v1[NDT];
-    int bn0 = block_number(0), bn1 = block_number(1);
-    load_tile(k0, v0, 0, bn0);
-    bn0 = block_number(2);
-    for (int j = 0; j < ntiles; j += 2) {
-      load_tile(k1, v1, j + 1, bn1);
-      bn1 = block_number(j + 3);
-      compute_tile(k0, v0, j);
-      load_tile(k0, v0, j + 2, bn0);
-      bn0 = block_number(j + 4);
-      compute_tile(k1, v1, j + 1);
-    }
+    load_v(vA, j + 2, bnA);
+    load_v(vB, j + 3, bnB);
+    bnA = block_number(j + 4);
+    bnB = block_number(j + 5);
   }
 
   // ---- normalise and store: lane (g, c) holds d = 16t + 4g .. +3 of its column ----
@@ -272,8 +328,13 @@ static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_quer
   p.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : 4;
   const int tqwg = 4 * NB * (16 >> p.gp_shift);
   const int qtiles = (max_query_len + tqwg - 1) / tqwg;
-  hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB>),
-                     dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
+  const bool extras = p.alibi_slopes != nullptr || p.softcap > 0.f || p.sliding_window > 0;
+  if (extras)
+    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, true>),
+                       dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, false>),
+                       dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
   return 0;
 }
 
