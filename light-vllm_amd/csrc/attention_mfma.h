@@ -76,9 +76,39 @@ __device__ __forceinline__ f32x4_t mfma_pv<F16>(u32x2_t a, u32x2_t b, f32x4_t c)
                                                __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
 }
 
+// two fp32 -> one dword of two T (round to nearest even): a single v_cvt_pk_{bf16,f16}_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <typename T>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)T::from_float(lo) | ((uint32_t)T::from_float(hi) << 16);
+__device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+template <>
+__device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+
+// max without the canonicalising v_max x,x,x that fmaxf() costs on values the compiler cannot
+// prove quiet (MFMA results, selects).  max2() is v_med3_f32(a, b, +inf): a target intrinsic, so
+// the compiler still sees a vector instruction reading its operands and inserts the wait
+// states an MFMA result needs before a vector read.  vmax()/vmax3() are inline asm, which the
+// hazard recogniser does not look into: they may only consume results of ordinary vector
+// instructions, NEVER an MFMA accumulator directly.
+__device__ __forceinline__ float max2(float a, float b) {
+  return __builtin_amdgcn_fmed3f(a, b, __builtin_inff());
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 // gfx9-family raw buffer descriptor word 3 (32-bit data format, no swizzle)

@@ -26,7 +26,16 @@
 #pragma once
 #include <float.h>
 
+#include <type_traits>
+
 #include "attention_mfma.h"
+
+#ifndef LVLLM_PREFILL_EXP
+#define LVLLM_PREFILL_EXP 0
+#endif
+#ifndef LVLLM_PREFILL_SCHED
+#define LVLLM_PREFILL_SCHED 1
+#endif
 
 namespace lvllm {
 
@@ -163,12 +172,21 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
     for (int jj = 0; jj < NS; ++jj)
       k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, 0);
   };
-  auto load_v = [&](u32x2_t (&v)[NDT], const int j, const int bn32) __attribute__((always_inline)) {
+  // V pieces of the pair land directly in the 4-register MFMA operand: .xy = tile A, .zw = tile B
+  auto load_v = [&](u32x4_t (&v)[NDT], const int half, const int j, const int bn32) __attribute__((always_inline)) {
     __amdgpu_buffer_rsrc_t vr = tile_rsrc(vbytes, j, bn32);
     const int off = tile_off(j);
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
-      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
+    for (int t = 0; t < NDT; ++t) {
+      const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, 0);
+      if (half == 0) {
+        v[t].x = x.x;
+        v[t].y = x.y;
+      } else {
+        v[t].z = x.x;
+        v[t].w = x.y;
+      }
+    }
   };
   // butterfly max over the 4 lane groups g (rows of 16 lanes) without LDS: the gfx950 row swaps.
   // (inline asm: hipcc folds the builtin form of swap(x, x) + max away.)
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
     return a;
   };
-  auto zero_tail = [&](u32x2_t (&v)[NDT], const int tile_base) __attribute__((always_inline)) {
+  auto zero_tail = [&](u32x4_t (&v)[NDT], const int half, const int tile_base) __attribute__((always_inline)) {
     // V beyond the sequence may hold anything (NaN included): zero it (only the last tile can)
     if (tile_base + 16 > seq_len) {
       const int tok0 = tile_base + 4 * g;
@@ -190,8 +208,13 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
       if (tok0 + 3 >= seq_len) my &= 0x0000ffffu;
 #pragma unroll
       for (int t = 0; t < NDT; ++t) {
-        v[t].x &= mx;
-        v[t].y &= my;
+        if (half == 0) {
+          v[t].x &= mx;
+          v[t].y &= my;
+        } else {
+          v[t].z &= mx;
+          v[t].w &= my;
+        }
       }
     }
   };
@@ -202,18 +225,25 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
   const float kf = EXTRAS ? 1.f : qk_scale;
 
   u32x4_t kA[NS], kB[NS];
-  u32x2_t vA[NDT], vB[NDT];
+  u32x4_t vv[NDT];
   {
     const int bnA = block_number(0), bnB = block_number(1);
     load_k(kA, 0, bnA);
     load_k(kB, 1, bnB);
-    load_v(vA, 0, bnA);
-    load_v(vB, 1, bnB);
+    load_v(vv, 0, 0, bnA);
+    load_v(vv, 1, 1, bnB);
   }
   int bnA = block_number(2), bnB = block_number(3);
-  for (int jp = 0; jp < npairs; ++jp) {
+  // One pair.  MASKED is a compile-time tag: the pairs wholly at or before the wave's first query
+  // (all but the last one or two) run a copy of the body with no mask and no branch but the rescale.
+  auto pair_step = [&](const int jp, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool need_mask = decltype(masked_tag)::value;
     const int j = 2 * jp;
     const int base = (tile0 + j) << 4;
+    if constexpr (need_mask) {
+      zero_tail(vv, 0, base);
+      zero_tail(vv, 1, base + 16);
+    }
     // ---- S = K.Q^T for both tiles and all column blocks, then the K registers are free ----
     f32x4_t sA[NB], sB[NB];
 #pragma unroll
@@ -225,70 +255,110 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 #pragma unroll
       for (int jj = 0; jj < NS; ++jj) sB[b] = mfma_qk<T>(kB[jj], qf[b][jj], sB[b]);
     }
+#if LVLLM_PREFILL_EXP < 2  // diagnosis builds: 1 = no V stream, 2 = no K stream either (wrong results)
     load_k(kA, j + 2, bnA);
     load_k(kB, j + 3, bnB);
-    zero_tail(vA, base);
-    zero_tail(vB, base + 16);
-    const bool need_mask = EXTRAS || base + 31 > q_first_pos;
-    u32x4_t pb[NB];
+#endif
+    // (1) logits, masks and the new running max of every column block
+    float y[NB][8];
+    float m_new[NB];
+    bool grew = false;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      float y[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        y[r] = sA[b][r];
-        y[4 + r] = sB[b][r];
+        y[b][r] = sA[b][r];
+        y[b][4 + r] = sB[b][r];
       }
       if constexpr (EXTRAS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int tok = base + ((e >> 2) << 4) + 4 * g + (e & 3);
-          float z = y[e] * qk_scale;
-          if (use_cap) z = p.softcap * kLog2e * tanhf(y[e] * p.scale / p.softcap);
+          float z = y[b][e] * qk_scale;
+          if (use_cap) z = p.softcap * kLog2e * tanhf(y[b][e] * p.scale / p.softcap);
           if (use_alibi) z += alibi * (float)(tok - qpos[b]);
-          y[e] = z;
+          y[b][e] = z;
         }
       }
-      if (need_mask) {
+      if constexpr (need_mask) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int tok = base + ((e >> 2) << 4) + 4 * g + (e & 3);
           const int dist = qpos[b] - tok;  // >= 0: visible under the causal mask
           const bool vis = EXTRAS ? (dist >= 0 && dist < window) : dist >= 0;
-          y[e] = vis ? y[e] : kMasked;
+          y[b][e] = vis ? y[b][e] : kMasked;
         }
       }
-      float m_loc = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+      // plain fmaxf: this file is built with -fno-honor-nans (build.py), so no canonicalising
+      // v_max x,x,x; the compiler sees MFMA results being read and inserts the wait states
+      float m_loc = fmaxf(fmaxf(fmaxf(y[b][0], y[b][1]), fmaxf(y[b][2], y[b][3])),
+                          fmaxf(fmaxf(y[b][4], y[b][5]), fmaxf(y[b][6], y[b][7])));
       m_loc = group_max(m_loc);
-      const float m_new = fmaxf(m_run[b], m_loc);
-      if (__builtin_amdgcn_ballot_w64(m_new > m_run[b]) != 0) {  // wave-uniform: rescale only when needed
-        const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * kf);
+      m_new[b] = fmaxf(m_run[b], m_loc);
+      grew |= m_new[b] > m_run[b];
+    }
+    // (2) one wave-uniform branch: rescale the accumulators only when some running max grew
+    if (__builtin_amdgcn_ballot_w64(grew) != 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new[b]) * kf);
         l_run[b] *= alpha;
 #pragma unroll
         for (int t = 0; t < NDT; ++t) acc[b][t] *= alpha;
-        m_run[b] = m_new;
+        m_run[b] = m_new[b];
       }
-      const float mk = m_new * kf;
+    }
+    // (3) one straight-line region.  Issue order (an MFMA leaves half of its 16 cycles to the
+    // vector pipe, and a wave issues in order, so the interleaving has to be in the program):
+    //   exponentials of block 0 | P.V MFMAs of block b-1 interleaved with the exponentials of
+    //   block b | P.V MFMAs of the last block
+    auto exponentials = [&](const int b) __attribute__((always_inline)) -> u32x4_t {
+      const float mk = m_new[b] * kf;
       float psum = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        y[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(y[e], kf, -mk));
-        psum += y[e];
+        y[b][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(y[b][e], kf, -mk));
+        psum += y[b][e];
       }
       l_run[b] += psum;
-      pb[b] = u32x4_t{pack2<T>(y[0], y[1]), pack2<T>(y[2], y[3]), pack2<T>(y[4], y[5]), pack2<T>(y[6], y[7])};
-    }
-    // ---- O^T += V^T.P^T, contraction over the 32 keys of the pair ----
+      return u32x4_t{pack2<T>(y[b][0], y[b][1]), pack2<T>(y[b][2], y[b][3]), pack2<T>(y[b][4], y[b][5]),
+                     pack2<T>(y[b][6], y[b][7])};
+    };
+    u32x4_t pb = exponentials(0);
 #pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-      const u32x4_t va = u32x4_t{vA[t].x, vA[t].y, vB[t].x, vB[t].y};
+    for (int b = 1; b < NB; ++b) {
+#if LVLLM_PREFILL_SCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[b][t] = mfma_qk<T>(va, pb[b], acc[b][t]);
+      for (int t = 0; t < NDT; ++t) acc[b - 1][t] = mfma_qk<T>(vv[t], pb, acc[b - 1][t]);
+      pb = exponentials(b);
+#if LVLLM_PREFILL_SCHED
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, (28 + NDT - 1) / NDT, 0);
+      }
+#endif
     }
-    load_v(vA, j + 2, bnA);
-    load_v(vB, j + 3, bnB);
+#if LVLLM_PREFILL_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) acc[NB - 1][t] = mfma_qk<T>(vv[t], pb, acc[NB - 1][t]);
+#if LVLLM_PREFILL_EXP < 1
+    load_v(vv, 0, j + 2, bnA);
+    load_v(vv, 1, j + 3, bnB);
+#endif
     bnA = block_number(j + 4);
     bnB = block_number(j + 5);
+  };
+  {
+    // pairs whose last key (base + 31) is at or before the wave's first query need no mask
+    const int n_plain = EXTRAS ? 0 : min(npairs, max(0, (q_first_pos + 1 - (tile0 << 4)) >> 5));
+    int jp = 0;
+    for (; jp < n_plain; ++jp) pair_step(jp, std::false_type{});
+    for (; jp < npairs; ++jp) pair_step(jp, std::true_type{});
   }
 
   // ---- normalise and store: lane (g, c) holds d = 16t + 4g .. +3 of its column ----
