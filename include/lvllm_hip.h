@@ -210,7 +210,8 @@ int lvllm_rotary_embedding_and_cache(
  * query_start_loc[i] .. query_start_loc[i+1]; seq_lens[i] counts the whole context INCLUDING those
  * tokens, whose K/V must already be in the cache (reshape_and_cache runs first, flash_attn.py:488-500).
  * Query t of the chunk sits at position seq_len - query_len + t and sees keys 0 .. that position
- * (the last sliding_window of them when sliding_window > 0); softcap > 0 applies
+ * (the last sliding_window of them when sliding_window > 0) when causal != 0, every key of its
+ * sequence when causal == 0 (encoder attention; no ALiBi / window there); softcap > 0 applies
  * cap * tanh(logit / cap).  16-bit dtypes, head sizes of paged_attention, block_size 16 or 32;
  * key_cache / value_cache in the paged_attention layouts.  query [T, num_heads, head_size] with token
  * stride q_stride, out likewise with out_stride (elements). */
@@ -219,8 +220,25 @@ int lvllm_paged_prefill_attention(
     int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
     const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
     int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
-    int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, void* stream);
+
+/* Dense varlen attention without a KV cache: the encode-only / prefill-only path
+ * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
+ * cu_seqlens, causal=...); in-tree definition torch_naive.py:65-149).  query [T, num_heads, D],
+ * key/value [T, num_kv_heads, D] (token strides in elements), cu_seqlens int32 [num_seqs + 1] on the
+ * device, causal = 1 for AttentionType.DECODER, 0 for ENCODER.  Runs in three launches: block
+ * placement + slot mapping from cu_seqlens, reshape_and_cache of key/value into paged tiles in
+ * `workspace`, lvllm_paged_prefill_attention over them -- no host synchronisation.
+ * workspace: at least lvllm_varlen_attention_workspace_bytes(...) bytes, 256-byte aligned. */
+int64_t lvllm_varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len,
+                                               int num_kv_heads, int head_size);
+int lvllm_varlen_attention(
+    void* out, const void* query, const void* key, const void* value, const int32_t* cu_seqlens,
+    int num_tokens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads, int head_size,
+    float scale, int causal, const float* alibi_slopes, int sliding_window, float softcap,
+    int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t out_stride, int dtype,
+    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);

@@ -68,13 +68,34 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
                             block_tables: torch.Tensor, seq_lens: torch.Tensor,
                             query_start_loc: torch.Tensor, max_query_len: int, block_size: int,
                             alibi_slopes: Optional[torch.Tensor] = None, sliding_window: int = 0,
-                            softcap: float = 0.0, kv_cache_dtype: str = "auto") -> None:
+                            softcap: float = 0.0, kv_cache_dtype: str = "auto", causal: bool = True) -> None:
     """Causal varlen attention of prompt chunks over the paged cache: the job of
     flash_attn_varlen_func(..., block_table=...) at flash_attn.py:538-555 of the reference."""
     torch.ops._C_amd.paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, scale,
                                              block_tables, seq_lens, query_start_loc, max_query_len,
                                              block_size, alibi_slopes, sliding_window, softcap,
-                                             kv_cache_dtype)
+                                             kv_cache_dtype, causal)
+
+
+_VARLEN_WS = {}
+
+
+def varlen_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                     cu_seqlens: torch.Tensor, max_seq_len: int, scale: float, causal: bool,
+                     alibi_slopes: Optional[torch.Tensor] = None, sliding_window: int = 0,
+                     softcap: float = 0.0, workspace: Optional[torch.Tensor] = None) -> None:
+    """Dense varlen attention without a KV cache: the prefill-only backends' job
+    (flash_attn_varlen_func(q, k, v, cu_seqlens, causal=...), torch_naive.py:65-149).
+    query [T, H, D], key/value [T, KVH, D], cu_seqlens int32 [num_seqs + 1] on the device."""
+    need = torch.ops._C_amd.varlen_attention_workspace_bytes(query.shape[0], cu_seqlens.numel() - 1,
+                                                             max_seq_len, key.shape[1], query.shape[2])
+    if workspace is None:
+        workspace = _VARLEN_WS.get(query.device)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=query.device)
+            _VARLEN_WS[query.device] = workspace
+    torch.ops._C_amd.varlen_attention(out, query, key, value, cu_seqlens, max_seq_len, scale, causal,
+                                      alibi_slopes, sliding_window, softcap, workspace)
 
 
 def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,

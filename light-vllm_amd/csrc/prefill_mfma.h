@@ -50,7 +50,8 @@ struct PrefillParams {
   const float* alibi_slopes;       // [num_heads] or null
   int num_heads, num_kv_heads, max_num_blocks_per_seq;
   int gp_shift;        // log2 of the GQA group size rounded up to a power of two (<= 16)
-  int sliding_window;  // <= 0: none; else a query at position p sees keys p-w+1 .. p
+  int causal;          // 1: bottom-right aligned causal mask; 0: every query sees the whole context
+  int sliding_window;  // <= 0: none; else a query at position p sees keys p-w+1 .. p (causal only)
   float scale;
   float softcap;  // <= 0: none; else logits = cap * tanh(logits / cap)
   int64_t q_stride, out_stride, kv_block_stride, kv_head_stride;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
   const int nq = min(TQW, qlen - t_first);        // live query tokens of this wave
 
   // keys this wave needs: [klo, khi)
-  const int khi = ctx + t_first + nq;  // last query's position + 1  (<= seq_len)
+  const int khi = p.causal ? ctx + t_first + nq : seq_len;  // causal: last query's position + 1
   const int klo = p.sliding_window > 0 ? max(0, ctx + t_first - p.sliding_window + 1) : 0;
   const int tile0 = klo >> 4;
   const int ntiles = ((khi + 15) >> 4) - tile0;
@@ -116,12 +117,14 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 
   // ---- Q fragments ----
   u32x4_t qf[NB][NS];
-  int qpos[NB];  // absolute position of this lane's column in block b (masked columns: -1)
+  int qpos[NB];  // absolute position of this lane's column in block b (dead columns: -1)
+  int vlast[NB];  // last key this column may see: its own position (causal) or the last key
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int t = b * TQB + cq;
     const bool ok = head_ok && t < nq;
     qpos[b] = ok ? ctx + t_first + t : -1;
+    vlast[b] = ok ? (p.causal ? ctx + t_first + t : seq_len - 1) : -1;
     const S* qrow = (const S*)p.q + (int64_t)(qbeg + t_first + t) * p.q_stride + (int64_t)(head0 + ch) * D;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
     }
   };
 
-  const int q_first_pos = ctx + t_first;  // position of the wave's first query
+  // every live column of the wave sees all keys up to this one
+  const int q_first_pos = p.causal ? ctx + t_first : seq_len - 1;
   // exponent = y * kf - m * kf: the plain path keeps y = raw q.k and folds scale*log2(e) into
   // the FMA; with extras y is already the biased logit in log2 units
   const float kf = EXTRAS ? 1.f : qk_scale;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int tok = base + ((e >> 2) << 4) + 4 * g + (e & 3);
-          const int dist = qpos[b] - tok;  // >= 0: visible under the causal mask
+          const int dist = vlast[b] - tok;  // >= 0: visible
           const bool vis = EXTRAS ? (dist >= 0 && dist < window) : dist >= 0;
           y[b][e] = vis ? y[b][e] : kMasked;
         }

@@ -349,7 +349,7 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
                              const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
                              const torch::Tensor& query_start_loc, int64_t max_query_len, int64_t block_size,
                              const c10::optional<torch::Tensor>& alibi_slopes, int64_t sliding_window,
-                             double softcap, const std::string& kv_cache_dtype) {
+                             double softcap, const std::string& kv_cache_dtype, bool causal) {
   LV_CHECK_DEVICE(query);
   LV_CHECK_DEVICE(out);
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "paged_prefill_attention: query/out must be [T, H, D]");
@@ -369,9 +369,43 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
       out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs,
       (int)query.size(1), (int)query.size(2), (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(),
       seq_lens.data_ptr<int32_t>(), query_start_loc.data_ptr<int32_t>(), (int)max_query_len, (int)block_size,
-      (int)block_tables.size(1), alibi, (int)sliding_window, (float)softcap, query.stride(0), out.stride(0),
+      (int)block_tables.size(1), alibi, causal ? 1 : 0, (int)sliding_window, (float)softcap, query.stride(0),
+      out.stride(0),
       key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_prefill_attention"),
       kv_dtype_code(kv_cache_dtype), current_stream(query)));
+}
+
+int64_t varlen_attention_workspace_bytes(int64_t num_tokens, int64_t num_seqs, int64_t max_seq_len,
+                                         int64_t num_kv_heads, int64_t head_size) {
+  return lvllm_varlen_attention_workspace_bytes((int)num_tokens, (int)num_seqs, (int)max_seq_len,
+                                                (int)num_kv_heads, (int)head_size);
+}
+
+void varlen_attention(torch::Tensor& out, const torch::Tensor& query, const torch::Tensor& key,
+                      const torch::Tensor& value, const torch::Tensor& cu_seqlens, int64_t max_seq_len,
+                      double scale, bool causal, const c10::optional<torch::Tensor>& alibi_slopes,
+                      int64_t sliding_window, double softcap, torch::Tensor& workspace) {
+  LV_CHECK_DEVICE(query);
+  LV_CHECK_DEVICE(key);
+  LV_CHECK_DEVICE(value);
+  LV_CHECK_DEVICE(out);
+  LV_CHECK_DEVICE(workspace);
+  TORCH_CHECK(query.dim() == 3 && key.dim() == 3 && value.dim() == 3 && out.dim() == 3,
+              "varlen_attention: query/key/value/out must be [T, heads, D]");
+  for (const torch::Tensor* t : {&query, &key, &value, (const torch::Tensor*)&out})
+    TORCH_CHECK(t->stride(2) == 1 && t->stride(1) == t->size(2), "varlen_attention: heads of a token must be contiguous");
+  TORCH_CHECK(cu_seqlens.scalar_type() == at::kInt && cu_seqlens.is_cuda() && cu_seqlens.is_contiguous(),
+              "varlen_attention: cu_seqlens must be a contiguous int32 device tensor");
+  TORCH_CHECK(key.scalar_type() == query.scalar_type() && value.scalar_type() == query.scalar_type());
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
+  const float* alibi = alibi_slopes.has_value() ? alibi_slopes->data_ptr<float>() : nullptr;
+  check(lvllm_varlen_attention(out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+                               cu_seqlens.data_ptr<int32_t>(), (int)query.size(0), (int)cu_seqlens.numel() - 1,
+                               (int)max_seq_len, (int)query.size(1), (int)key.size(1), (int)query.size(2),
+                               (float)scale, causal ? 1 : 0, alibi, (int)sliding_window, (float)softcap,
+                               query.stride(0), key.stride(0), value.stride(0), out.stride(0),
+                               dtype_code(query, "varlen_attention"), workspace.data_ptr(),
+                               (int64_t)workspace.nbytes(), current_stream(query)));
 }
 
 torch::Tensor pack_weight(const torch::Tensor& w) {
@@ -488,8 +522,14 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
           "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
-          "str kv_cache_dtype) -> ()");
+          "str kv_cache_dtype, bool causal=True) -> ()");
   amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
+  amd.def("varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads, "
+          "int head_size) -> int", &varlen_attention_workspace_bytes);
+  amd.def("varlen_attention(Tensor! out, Tensor query, Tensor key, Tensor value, Tensor cu_seqlens, "
+          "int max_seq_len, float scale, bool causal, Tensor? alibi_slopes, int sliding_window, "
+          "float softcap, Tensor! workspace) -> ()");
+  amd.impl("varlen_attention", torch::kCUDA, &varlen_attention);
 }
 
 TORCH_LIBRARY(_C_cuda_utils, cuda_utils) {

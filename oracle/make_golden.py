@@ -161,10 +161,55 @@ def make_op_vectors():
     print("ops_elementwise.npz")
 
 
+def make_prefill_only_vectors():
+    """Golden vectors of the prefill-only (no KV cache) attention path, produced by the reference's
+    own in-tree backend PrefillOnlyTorchNaiveBackendImpl.forward (prefill_only/backends/attention/
+    backends/torch_naive.py:64-124) on the shapes of its test
+    (tests/prefill_only/attention/test_basic_correctness.py:25-57): SEQ_LENS primes, D = 64,
+    H in {8, 16}, KVH in {1, 2, 4, 8}, DECODER (causal) and ENCODER.  Inputs are torch.rand values
+    rounded to bf16 (exactly representable in every dtype under test); the reference runs in fp32."""
+    import numpy as np
+    import torch
+    from oracle import ref_block_manager
+    ref_block_manager.load()  # registers the light_vllm namespace + stubs
+    from light_vllm.backends.attention.abstract import AttentionType
+    from light_vllm.prefill_only.backends.attention.backends.abstract import \
+        PrefillOnlyAttentionMetadata
+    from light_vllm.prefill_only.backends.attention.backends.torch_naive import \
+        PrefillOnlyTorchNaiveBackendImpl
+    SEQ_LENS = [1, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29]
+    out = {}
+    cases = []
+    g = torch.Generator().manual_seed(2024)
+    for H, KVH, n_seqs in [(8, 1, 8), (8, 2, 7), (8, 8, 3), (16, 4, 10), (16, 8, 5)]:
+        D = 64
+        seq_lens = SEQ_LENS[:n_seqs]
+        T = sum(seq_lens)
+        q = torch.rand(T, H * D, generator=g).to(torch.bfloat16).float()
+        k = torch.rand(T, KVH * D, generator=g).to(torch.bfloat16).float()
+        v = torch.rand(T, KVH * D, generator=g).to(torch.bfloat16).float()
+        impl = PrefillOnlyTorchNaiveBackendImpl(H, D, D ** -0.5, KVH, None, None, "auto")
+        # (the reference's metadata builder pins memory, which needs a GPU; forward reads seq_lens only)
+        md = PrefillOnlyAttentionMetadata(max_seq_len=max(seq_lens), seq_lens=seq_lens, seq_start_loc=None)
+        tag = f"h{H}_kvh{KVH}_n{n_seqs}"
+        bits = lambda t: t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)  # exact: values are bf16
+        out[f"{tag}_q"], out[f"{tag}_k"], out[f"{tag}_v"] = bits(q), bits(k), bits(v)
+        out[f"{tag}_seq_lens"] = np.array(seq_lens, dtype=np.int32)
+        for name, at in (("decoder", AttentionType.DECODER), ("encoder", AttentionType.ENCODER)):
+            o = impl.forward(q, k, v, None, md, attn_type=at)
+            out[f"{tag}_{name}"] = o.numpy()
+        cases.append(tag)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLDEN, "prefill_only_attn.npz"), **out)
+    print("prefill_only_attn.npz", len(cases), "cases")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    what = sys.argv[1:] or ["block_manager", "ops"]
+    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only"]
     if "block_manager" in what:
         make_block_manager_traces()
     if "ops" in what:
         make_op_vectors()
+    if "prefill_only" in what:
+        make_prefill_only_vectors()

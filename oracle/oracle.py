@@ -93,6 +93,17 @@ def paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, sc
         _l(key_cache.stride(0)), _l(key_cache.stride(1)), _i(_DT[query.dtype]))
 
 
+def varlen_attention(out, query, key, value, cu_seqlens, scale, causal):
+    """query/out [T, H, D], key/value [T, KVH, D], cu_seqlens int32 [num_seqs + 1]
+    (torch_naive.py:65-149 of the reference's prefill_only backends)."""
+    assert cu_seqlens.dtype == torch.int32 and out.stride(1) == out.size(2)
+    lib().oracle_varlen_attention(
+        _p(out), _p(query), _p(key), _p(value), _p(cu_seqlens), _i(cu_seqlens.numel() - 1),
+        _i(query.size(1)), _i(key.size(1)), _i(query.size(2)), _f(scale), _i(1 if causal else 0),
+        _l(query.stride(0)), _l(key.stride(0)), _l(value.stride(0)), _l(out.stride(0)),
+        _i(_DT[query.dtype]))
+
+
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):
     assert slot_mapping.dtype == torch.int64
     lib().oracle_reshape_and_cache(

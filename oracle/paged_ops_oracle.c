@@ -301,6 +301,67 @@ void oracle_paged_prefill_attention(void* out, const void* query, const void* ke
   free(seq_of);
 }
 
+/* ---------------------------------------------------------------------------------
+ * Dense varlen attention without a KV cache: the prefill-only / encode-only backends
+ * (light_vllm/prefill_only/backends/attention/backends/torch_naive.py:65-149 is the in-tree
+ * definition; flash_attn.py there calls the third-party flash_attn_varlen_func).
+ *   query [T, H, D], key/value [T, KVH, D], sequences cut by cu_seqlens;
+ *   key/value heads repeated H/KVH times (:98-100); causal (DECODER) masks keys after the query
+ *   (:135-140, both inside the same sequence), ENCODER sees the whole sequence;
+ *   attn = softmax(q.k * scale + bias) @ v (:147-149).
+ * Rounding as the GPU kernel: fp32 logits, P = exp(x - max) rounded to T for P.V, fp32
+ * accumulation, divided by the fp32 sum, rounded to T.
+ * ------------------------------------------------------------------------------- */
+void oracle_varlen_attention(void* out, const void* query, const void* key, const void* value,
+                             const int32_t* cu_seqlens, int num_seqs, int num_heads,
+                             int num_kv_heads, int head_size, float scale, int causal,
+                             int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                             int64_t out_stride, int dt) {
+  const int G = num_heads / num_kv_heads;
+  int max_len = 1;
+  for (int s = 0; s < num_seqs; ++s)
+    if (cu_seqlens[s + 1] - cu_seqlens[s] > max_len) max_len = cu_seqlens[s + 1] - cu_seqlens[s];
+#pragma omp parallel
+  {
+    float* logits = (float*)malloc(sizeof(float) * (size_t)max_len);
+    float* acc = (float*)malloc(sizeof(float) * (size_t)head_size);
+#pragma omp for collapse(2) schedule(dynamic, 1)
+    for (int s = 0; s < num_seqs; ++s)
+      for (int h = 0; h < num_heads; ++h) {
+        const int beg = cu_seqlens[s], len = cu_seqlens[s + 1] - cu_seqlens[s];
+        const int kvh = h / G;
+        for (int i = 0; i < len; ++i) {
+          const int n = causal ? i + 1 : len;
+          const int64_t q_off = (int64_t)(beg + i) * q_stride + (int64_t)h * head_size;
+          float mx = -FLT_MAX;
+          for (int j = 0; j < n; ++j) {
+            const int64_t k_off = (int64_t)(beg + j) * k_stride + (int64_t)kvh * head_size;
+            float dot = 0.f;
+            for (int d = 0; d < head_size; ++d) dot += ld(query, dt, q_off + d) * ld(key, dt, k_off + d);
+            logits[j] = scale * dot;
+            mx = fmaxf(mx, logits[j]);
+          }
+          float sum = 0.f;
+          for (int j = 0; j < n; ++j) {
+            const float e = expf(logits[j] - mx);
+            sum += e;
+            logits[j] = rnd(e, dt);
+          }
+          for (int d = 0; d < head_size; ++d) acc[d] = 0.f;
+          for (int j = 0; j < n; ++j) {
+            const int64_t v_off = (int64_t)(beg + j) * v_stride + (int64_t)kvh * head_size;
+            for (int d = 0; d < head_size; ++d) acc[d] += logits[j] * ld(value, dt, v_off + d);
+          }
+          const float inv = sum > 0.f ? 1.f / sum : 0.f;
+          for (int d = 0; d < head_size; ++d)
+            st(out, dt, (int64_t)(beg + i) * out_stride + (int64_t)h * head_size + d, acc[d] * inv);
+        }
+      }
+    free(logits);
+    free(acc);
+  }
+}
+
 /* paged_attention_v2 + reduce: csrc/attention/attention_kernels.cu:529-669, 848-997.
  * tmp_out/exp_sums/max_logits are filled exactly where the GPU kernel fills them
  * (every partition that holds tokens, also when there is only one). */

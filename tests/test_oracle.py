@@ -241,3 +241,36 @@ def test_prefill_oracle_softcap_and_decode_equivalence():
     inp["scale"] = 4.0
     want = dense_prefill_fp64(inp, softcap=2.0)
     assert float((c.double() - want).abs().max()) <= 2e-3
+
+
+# ---- prefill-only (no KV cache) attention: golden vectors from the reference's own backend ----
+def _load_prefill_only_cases():
+    z = np.load(os.path.join(GOLDEN, "prefill_only_attn.npz"))
+    for tag in z["cases"]:
+        tag = str(tag)
+        H, KVH = int(tag.split("_")[0][1:]), int(tag.split("_")[1][3:])
+        bf = lambda a: torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+        yield dict(tag=tag, H=H, KVH=KVH, q=bf(z[f"{tag}_q"]), k=bf(z[f"{tag}_k"]), v=bf(z[f"{tag}_v"]),
+                   seq_lens=z[f"{tag}_seq_lens"].tolist(), decoder=torch.from_numpy(z[f"{tag}_decoder"]),
+                   encoder=torch.from_numpy(z[f"{tag}_encoder"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_varlen_oracle_vs_reference_torch_naive_golden(dtype):
+    """oracle_varlen_attention against PrefillOnlyTorchNaiveBackendImpl.forward outputs recorded by
+    oracle/make_golden.py (fp32 run of the reference on bf16-exact inputs)."""
+    n = 0
+    for c in _load_prefill_only_cases():
+        H, KVH, D = c["H"], c["KVH"], 64
+        q = c["q"].to(dtype).view(-1, H, D)
+        k = c["k"].to(dtype).view(-1, KVH, D)
+        v = c["v"].to(dtype).view(-1, KVH, D)
+        cu = torch.tensor([0] + list(np.cumsum(c["seq_lens"])), dtype=torch.int32)
+        for name, causal in (("decoder", True), ("encoder", False)):
+            out = torch.full_like(q, float("nan"))
+            oracle.varlen_attention(out, q, k, v, cu, D ** -0.5, causal)
+            want = c[name].view(-1, H, D)
+            tol = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
+            assert float((out.float() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (c["tag"], name)
+            n += 1
+    assert n == 10

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def run_hip(ops, inp, alibi=None, window=0, softcap=0.0, out=None):
+def run_hip(ops, inp, alibi=None, window=0, softcap=0.0, out=None, causal=True):
     d = to_dev(inp)
     if out is None:
         out = torch.full_like(d["query"], float("nan"))
     ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], inp["num_kv_heads"],
                                 inp["scale"], d["block_tables"], d["seq_lens"], d["query_start_loc"],
                                 inp["max_query_len"], inp["block_size"],
-                                alibi.to(DEV) if alibi is not None else None, window, softcap, "auto")
+                                alibi.to(DEV) if alibi is not None else None, window, softcap, "auto", causal)
     torch.cuda.synchronize()
     return out
 
@@ -188,3 +188,22 @@ def test_prefill_long_prompt_properties(ops):
     inp2["block_tables"] = inv[inp["block_tables"].long()].to(torch.int32)
     out2 = run_hip(ops, inp2).cpu()
     assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+
+
+@pytest.mark.parametrize("block_size", [16, 32])
+def test_prefill_non_causal_sees_the_whole_context(ops, block_size):
+    """causal=False (encoder attention over a paged context): every query attends to all
+    seq_len keys, also those after it; NaN garbage past seq_len stays masked."""
+    inp = make_prefill_inputs(8, 2, 64, block_size, [37, 200, 5, 129], [37, 40, 5, 129], dtype=torch.bfloat16,
+                              seed=6, garbage=float("nan"))
+    out = run_hip(ops, inp, causal=False).cpu()
+    assert torch.isfinite(out).all()
+    q = inp["query"]
+    qsl = inp["query_start_loc"].tolist()
+    want = torch.zeros(q.shape, dtype=torch.float64)
+    for s, S in enumerate(inp["seq_lens"].tolist()):
+        k, v = inp["k_dense"][s].double(), inp["v_dense"][s].double()
+        for h in range(8):
+            logits = (q[qsl[s]:qsl[s + 1], h].double() @ k[:, h // 4].T) * inp["scale"]
+            want[qsl[s]:qsl[s + 1], h] = torch.softmax(logits, dim=1) @ v[:, h // 4]
+    check_attention(out, want)
