@@ -227,9 +227,10 @@ int lvllm_paged_prefill_attention(
  * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
  * cu_seqlens, causal=...); in-tree definition torch_naive.py:65-149).  query [T, num_heads, D],
  * key/value [T, num_kv_heads, D] (token strides in elements), cu_seqlens int32 [num_seqs + 1] on the
- * device, causal = 1 for AttentionType.DECODER, 0 for ENCODER.  Runs in three launches: block
- * placement + slot mapping from cu_seqlens, reshape_and_cache of key/value into paged tiles in
- * `workspace`, lvllm_paged_prefill_attention over them -- no host synchronisation.
+ * device, causal = 1 for AttentionType.DECODER, 0 for ENCODER.  Two launches, no host
+ * synchronisation: key/value are packed into paged tiles in `workspace` (sequence s owns the blocks
+ * cu_seqlens[s] / 16 + s ...), then lvllm_paged_prefill_attention runs over them with
+ * block_tables = seq_lens = NULL, which selects that arithmetic placement.
  * workspace: at least lvllm_varlen_attention_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t lvllm_varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len,
                                                int num_kv_heads, int head_size);

@@ -1,4 +1,6 @@
 // Host entry of lvllm_paged_prefill_attention (kernel: prefill_mfma.h).
+#include <algorithm>
+
 #include "../../include/lvllm_hip.h"
 #include "prefill_mfma.h"
 
@@ -49,44 +51,61 @@ extern "C" int lvllm_paged_prefill_attention(
 // ---- dense varlen attention: pack K/V into paged tiles in the workspace, then the kernel above ----
 namespace lvllm {
 
-constexpr int kVarlenBS = 32;  // block size of the scratch tiles
+constexpr int kVarlenBS = 16;  // block size of the scratch tiles (16: every K/V tile load of the kernel is one contiguous KiB)
 
-// One workgroup.  Phase 1: every sequence takes ceil(len / BS) consecutive scratch blocks from a
-// shared counter (any disjoint placement is as good as any other: results do not depend on it).
-// Phase 2: slot of every token.  Block tables are padded with the sequence's first block.
-__global__ __launch_bounds__(1024) void varlen_setup_kernel(const int32_t* __restrict__ cu_seqlens,
-                                                            int num_seqs, int num_tokens,
-                                                            int max_blocks_per_seq,
-                                                            int32_t* __restrict__ block_tables,
-                                                            int32_t* __restrict__ seq_lens,
-                                                            int64_t* __restrict__ slot_mapping) {
-  __shared__ int next_block;
-  if (threadIdx.x == 0) next_block = 0;
-  __syncthreads();
-  for (int s = threadIdx.x; s < num_seqs; s += blockDim.x) {
-    const int len = cu_seqlens[s + 1] - cu_seqlens[s];
-    const int nblk = (len + kVarlenBS - 1) / kVarlenBS;
-    const int first = atomicAdd(&next_block, nblk);
-    seq_lens[s] = len;
-    int32_t* row = block_tables + (int64_t)s * max_blocks_per_seq;
-    for (int i = 0; i < max_blocks_per_seq; ++i) row[i] = first + (i < nblk ? i : 0);
+// Sequence s owns the scratch blocks cu_seqlens[s] / BS + s + i, i < ceil(len_s / BS): consecutive
+// sequences never overlap (floor((a + len) / BS) - floor(a / BS) + 1 >= ceil(len / BS)) and the
+// total is at most T / BS + num_seqs, so the placement needs neither a scan nor a table.
+//
+// grid (block of the longest sequence, kv head, sequence), 256 threads: one (block, head)
+// tile of K and of V per workgroup.  K chunks [tok][d8] -> [d8][tok][8] move as 16 bytes, written
+// in destination order (the tile is BS*D*2 contiguous bytes).  V is a true transpose [tok][d] ->
+// [d][tok]: through LDS, so that both the reads and the writes are 16-byte and contiguous (a
+// direct scatter of 2-byte elements ran at a fifth of this speed).
+__global__ __launch_bounds__(256) void varlen_pack_kernel(
+    const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, uint16_t* __restrict__ key_cache,
+    uint16_t* __restrict__ value_cache, const int32_t* __restrict__ cu_seqlens, const int num_kv_heads,
+    const int head_size, const int64_t key_stride, const int64_t value_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t vt[];  // [head_size][kVarlenBS + 8] (padded rows)
+  constexpr int ROW = kVarlenBS + 8;
+  const int seq = blockIdx.z, head = blockIdx.y, blk = blockIdx.x;
+  const int beg = cu_seqlens[seq];
+  const int len = cu_seqlens[seq + 1] - beg;
+  const int tok0 = blk * kVarlenBS;
+  if (tok0 >= len) return;
+  const int chunks_per_head = head_size >> 3;
+  const int64_t block = beg / kVarlenBS + seq + blk;
+  uint16_t* ktile = key_cache + (block * num_kv_heads + head) * (int64_t)head_size * kVarlenBS;
+  uint16_t* vtile = value_cache + (block * num_kv_heads + head) * (int64_t)head_size * kVarlenBS;
+  const int nchunks = chunks_per_head * kVarlenBS;
+  // K: destination order (d8, tok)
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) {
+    const int d8 = i / kVarlenBS, tok = i - d8 * kVarlenBS;
+    uint4 kv = uint4{0, 0, 0, 0};
+    if (tok0 + tok < len)
+      kv = *reinterpret_cast<const uint4*>(key + (int64_t)(beg + tok0 + tok) * key_stride + head * head_size + d8 * 8);
+    *reinterpret_cast<uint4*>(ktile + (int64_t)i * 8) = kv;
+  }
+  // V: source order (tok, d8) into LDS transposed ...
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) {
+    const int tok = i / chunks_per_head, d8 = i - tok * chunks_per_head;
+    uint4 vv = uint4{0, 0, 0, 0};
+    if (tok0 + tok < len)
+      vv = *reinterpret_cast<const uint4*>(value + (int64_t)(beg + tok0 + tok) * value_stride + head * head_size + d8 * 8);
+    const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[(d8 * 8 + e) * ROW + tok] = ve[e];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < num_tokens; t += blockDim.x) {
-    int lo = 0, hi = num_seqs;  // last s with cu_seqlens[s] <= t
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (cu_seqlens[mid] <= t) lo = mid; else hi = mid;
-    }
-    const int pos = t - cu_seqlens[lo];
-    const int len = cu_seqlens[lo + 1] - cu_seqlens[lo];
-    const int first = block_tables[(int64_t)lo * max_blocks_per_seq];
-    slot_mapping[t] = pos < len ? (int64_t)(first + pos / kVarlenBS) * kVarlenBS + pos % kVarlenBS : -1;
+  // ... and out in destination order (d, 8 tokens)
+  for (int i = threadIdx.x; i < nchunks; i += blockDim.x) {
+    const int d = i / (kVarlenBS / 8), t8 = i - d * (kVarlenBS / 8);
+    *reinterpret_cast<uint4*>(vtile + (int64_t)i * 8) = *reinterpret_cast<const uint4*>(vt + d * ROW + t8 * 8);
   }
 }
 
 struct VarlenLayout {
-  int64_t cache_elems, off_v, off_tables, off_lens, off_slots, total;
+  int64_t cache_elems, off_v, total;
   int max_blocks_per_seq, num_blocks;
 };
 static VarlenLayout varlen_layout(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads,
@@ -94,15 +113,11 @@ static VarlenLayout varlen_layout(int num_tokens, int num_seqs, int max_seq_len,
   VarlenLayout L{};
   L.max_blocks_per_seq = (max_seq_len + kVarlenBS - 1) / kVarlenBS;
   if (L.max_blocks_per_seq < 1) L.max_blocks_per_seq = 1;
-  // sum of ceil(len_i / BS) <= T / BS + num_seqs
   L.num_blocks = num_tokens / kVarlenBS + num_seqs + 1;
   L.cache_elems = (int64_t)L.num_blocks * kVarlenBS * num_kv_heads * head_size;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
   L.off_v = up(L.cache_elems * 2);
-  L.off_tables = L.off_v + up(L.cache_elems * 2);
-  L.off_lens = L.off_tables + up((int64_t)num_seqs * L.max_blocks_per_seq * 4);
-  L.off_slots = L.off_lens + up((int64_t)num_seqs * 4);
-  L.total = L.off_slots + up((int64_t)num_tokens * 8);
+  L.total = L.off_v + up(L.cache_elems * 2);
   return L;
 }
 
@@ -121,28 +136,28 @@ extern "C" int lvllm_varlen_attention(
     void* workspace, int64_t workspace_bytes, void* stream) {
   LV_CHECK(num_tokens >= 0 && num_seqs >= 0 && max_seq_len >= 0, "negative sizes");
   LV_CHECK(dtype == LVLLM_F16 || dtype == LVLLM_BF16, "dtype must be float16 or bfloat16");
+  LV_CHECK(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+           "num_heads must be a positive multiple of num_kv_heads");
   LV_CHECK(head_size % 8 == 0, "head_size must be a multiple of 8");
-  if (num_tokens == 0 || num_seqs == 0) return 0;
+  LV_CHECK((((uintptr_t)key | (uintptr_t)value) & 15) == 0 && (k_stride * 2) % 16 == 0 && (v_stride * 2) % 16 == 0,
+           "key/value must be 16-byte aligned");
+  if (num_tokens == 0 || num_seqs == 0 || max_seq_len == 0) return 0;
   const VarlenLayout L = varlen_layout(num_tokens, num_seqs, max_seq_len, num_kv_heads, head_size);
   LV_CHECK(workspace != nullptr && workspace_bytes >= L.total && ((uintptr_t)workspace & 255) == 0,
            "workspace too small or misaligned (lvllm_varlen_attention_workspace_bytes)");
   char* ws = (char*)workspace;
   void* k_cache = ws;
   void* v_cache = ws + L.off_v;
-  int32_t* tables = (int32_t*)(ws + L.off_tables);
-  int32_t* lens = (int32_t*)(ws + L.off_lens);
-  int64_t* slots = (int64_t*)(ws + L.off_slots);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(varlen_setup_kernel, dim3(1), dim3(1024), 0, s, cu_seqlens, num_seqs, num_tokens,
-                     L.max_blocks_per_seq, tables, lens, slots);
+  const size_t smem = (size_t)head_size * (kVarlenBS + 8) * 2;
+  hipLaunchKernelGGL(varlen_pack_kernel, dim3(L.max_blocks_per_seq, num_kv_heads, num_seqs), dim3(256), smem, s,
+                     (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache,
+                     cu_seqlens, num_kv_heads, head_size, k_stride, v_stride);
   LV_LAUNCH_CHECK();
-  if (int rc = lvllm_reshape_and_cache(key, value, k_cache, v_cache, slots, num_tokens, num_kv_heads,
-                                       head_size, kVarlenBS, 8, k_stride, v_stride, dtype,
-                                       LVLLM_KV_AUTO, 1.f, 1.f, stream))
-    return rc;
   const int64_t head_stride = (int64_t)head_size * kVarlenBS;
+  // block_tables = seq_lens = nullptr: arithmetic placement, context == chunk
   return lvllm_paged_prefill_attention(
-      out, query, k_cache, v_cache, num_seqs, num_heads, head_size, num_kv_heads, scale, tables, lens,
+      out, query, k_cache, v_cache, num_seqs, num_heads, head_size, num_kv_heads, scale, nullptr, nullptr,
       cu_seqlens, max_seq_len, kVarlenBS, L.max_blocks_per_seq, alibi_slopes, causal, sliding_window,
       softcap, q_stride, out_stride, head_stride * num_kv_heads, head_stride, dtype, LVLLM_KV_AUTO, stream);
 }

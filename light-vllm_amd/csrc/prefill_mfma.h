@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 
   const int qbeg = p.query_start_loc[seq];
   const int qlen = p.query_start_loc[seq + 1] - qbeg;
-  const int seq_len = p.seq_lens[seq];
+  const int seq_len = p.seq_lens != nullptr ? p.seq_lens[seq] : qlen;  // no cache: the chunk is the context
   const int ctx = seq_len - qlen;
   const int t_first = qtile * TQWG + wave * TQW;  // first query token (inside the chunk) of this wave
   if (t_first >= qlen || ctx < 0) return;
@@ -140,9 +140,13 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
   const int window = p.sliding_window > 0 ? p.sliding_window : 0x3fffffff;
 
   const int last_block = p.max_num_blocks_per_seq - 1;
+  // block_tables == nullptr: the dense path's scratch tiles, placed arithmetically -- sequence s
+  // owns blocks cu_seqlens[s] / BS + s ..., which never overlap (prefill_attention.hip)
+  const bool arithmetic_blocks = p.block_tables == nullptr;
+  const int first_block = qbeg / BS + seq;
   auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
-    const int blk = ((tile0 + j) << 4) / BS;
-    return block_table[min(blk, last_block)];
+    const int blk = min(((tile0 + j) << 4) / BS, last_block);
+    return arithmetic_blocks ? first_block + blk : block_table[blk];
   };
 
   float m_run[NB], l_run[NB];

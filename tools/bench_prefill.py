@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--sdpa", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="lvllm_varlen_attention on dense q/k/v (no cache)")
+    ap.add_argument("--encoder", action="store_true", help="with --dense: bidirectional attention")
     a = ap.parse_args()
     dev = "cuda:0"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
@@ -59,6 +61,16 @@ def main():
         ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
         return ts[len(ts) // 2], ts[0]
 
+    if a.dense:
+        assert a.ctx == 0
+        kd = (torch.randn(B * a.qlen, KVH, D, device=dev) * 0.5).to(dt)
+        vd = (torch.randn(B * a.qlen, KVH, D, device=dev) * 0.5).to(dt)
+        if a.encoder:
+            flops = 4.0 * D * B * a.qlen * a.qlen * H
+
+        def hip():  # noqa: F811
+            ops.varlen_attention(out, q, kd, vd, qsl, a.qlen, scale, not a.encoder)
+
     med, mn = time(hip, a.iters)
     print(f"hip prefill: seqs {B} ctx {a.ctx} qlen {a.qlen} H {H} KVH {KVH} D {D}: median {med:.1f} us min {mn:.1f} us "
           f"-> {flops / med / 1e6:.1f} TFLOP/s ({flops / med / 1e6 / 2500 * 100:.1f}% of 2.5 PFLOP/s bf16 dense)")
@@ -67,7 +79,8 @@ def main():
         kd = (torch.randn(B, H, S, D, device=dev) * 0.5).to(dt)
         vd = (torch.randn(B, H, S, D, device=dev) * 0.5).to(dt)
         if a.ctx == 0:
-            fn = lambda: torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, is_causal=True, scale=scale)
+            fn = lambda: torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, is_causal=not a.encoder,
+                                                                           scale=scale)
         else:
             mask = torch.ones(a.qlen, S, dtype=torch.bool, device=dev).tril(diagonal=a.ctx)
             fn = lambda: torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, attn_mask=mask, scale=scale)
