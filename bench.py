@@ -6,10 +6,11 @@ dominant hot-path kernel (paged_attention_v2's partition pass) and a CPU baselin
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 A "step" is one engine step: the scheduler admits one batch of 32 decoding sequences (two such
-batches alternate, `max_num_on_the_fly=2`, so host scheduling overlaps the other batch's
-forward pass), the block manager appends one slot per sequence, the step's inputs are built,
-and the captured HIP graph of the 32-layer decode forward (+ lm_head + greedy argmax) is
-replayed.  Every rank is an independent replica with its own weights, KV cache and scheduler
+batches are in flight, `max_num_on_the_fly=2`, the reference's default for async scheduling; each
+runs on its own stream as in the reference's async_execute_loop, core/executor.py:62-93, so host
+scheduling and one step's launch gaps / kernel ramps overlap the other step's kernels), the
+block manager appends one slot per sequence, the step's inputs are built, and the captured HIP
+graph of the 32-layer decode forward (+ lm_head + greedy argmax) is replayed.  Every rank is an independent replica with its own weights, KV cache and scheduler
 (replicas only, no collective on the data path); `value` is the sum over ranks.
 
 Output: ONE JSON line on rank 0 (contract in the task description; roofline / cpu_baseline
@@ -40,6 +41,8 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
+    ap.add_argument("--on-the-fly", type=int, default=2,
+                    help="steps in flight with async scheduling (reference default: 2)")
     ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--library-gemm", action="store_true", help="dense projections through hipBLASLt (F.linear)")
@@ -176,7 +179,7 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     B, ctx = a.batch_size, a.context
-    on_the_fly = 2 if a.scheduling == "async" else 1
+    on_the_fly = max(1, a.on_the_fly) if a.scheduling == "async" else 1
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
@@ -250,7 +253,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
                                    f"decode bs={B} per step, context {ctx}..{int(ctx_now)}, block_size 16, "
-                                   f"{a.scheduling} scheduling ({on_the_fly} batches in flight), "
+                                   f"{a.scheduling} scheduling ({on_the_fly} batches in flight, one stream each), "
                                    f"attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "
                                    "random-init weights, synthetic KV",
                        "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)"},

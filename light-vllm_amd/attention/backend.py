@@ -267,11 +267,13 @@ class PagedAttnImpl:
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
         self.decode_version = decode_version  # None: heuristic; "v1" | "v2": forced
         self.use_hip_prefill = True  # False: torch SDPA per sequence (kept for A/B tests)
-        self._scratch: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._scratch: Dict[Tuple[int, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
     def _v2_scratch(self, num_seqs: int, max_seq_len: int, like: torch.Tensor):
         parts = (max_seq_len + 511) // 512
-        key = (num_seqs, parts)
+        # per stream: steps in flight on different streams (and the graphs captured on them)
+        # must not share scratch
+        key = (num_seqs, parts, torch.cuda.current_stream(like.device).cuda_stream)
         s = self._scratch.get(key)
         if s is None or s[2].device != like.device or s[2].dtype != like.dtype:
             tmp = torch.empty(num_seqs, self.num_heads, parts, self.head_size, dtype=like.dtype, device=like.device)

@@ -59,7 +59,9 @@ class DecodeGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
+        # thread_local: another stream may be replaying (and its waiter thread synchronising an
+        # event) while this thread captures
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
             self.hidden, self.next_tokens = self._step()
         torch.cuda.synchronize()
 

@@ -46,7 +46,7 @@ class Worker:
 
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, attn_backend,
                  device: str, use_hip_graph: bool = True, decode_version: Optional[str] = None,
-                 max_model_len: int = 8192, seed: int = 0):
+                 max_model_len: int = 8192, seed: int = 0, num_slots: int = 1):
         self.device = torch.device(device)
         self.model_config = model_config
         self.cache_config = cache_config
@@ -60,7 +60,10 @@ class Worker:
         self.cache_engine: Optional[CacheEngine] = None
         self.use_hip_graph = use_hip_graph
         self.max_model_len = max_model_len
-        self.graphs: Optional[DecodeGraphPool] = None
+        # one graph pool (own static input buffers) per execution slot: steps in flight on
+        # different streams must not share them
+        self.num_slots = max(1, num_slots)
+        self.graph_pools: Optional[List[DecodeGraphPool]] = None
         # tests: keep the logits of the sampled rows of the last eager step
         self.capture_logits = False
         self.last_logits: Optional[torch.Tensor] = None
@@ -84,11 +87,12 @@ class Worker:
         self.cache_engine = CacheEngine(self.cache_config, self.model_config, self.attn_backend, self.device)
         if self.use_hip_graph:
             max_blocks = (self.max_model_len + self.cache_config.block_size - 1) // self.cache_config.block_size
-            self.graphs = DecodeGraphPool(self.model, self.cache_engine.gpu_cache, max_blocks,
-                                          self.cache_config.block_size, self.device)
+            self.graph_pools = [DecodeGraphPool(self.model, self.cache_engine.gpu_cache, max_blocks,
+                                                self.cache_config.block_size, self.device)
+                                for _ in range(self.num_slots)]
 
     @torch.inference_mode()
-    def execute(self, execute_input: ExecuteInput) -> ExecuteOutput:
+    def execute(self, execute_input: ExecuteInput, slot: int = 0) -> ExecuteOutput:
         wi, mi = execute_input.worker_input, execute_input.model_input
         ce = self.cache_engine
         if wi.blocks_to_swap_in.numel() > 0:
@@ -100,8 +104,9 @@ class Worker:
         if mi.input_tokens is None:
             return ExecuteOutput(None, [])
         md = mi.attn_metadata
-        if self.graphs is not None and mi.decode_only and md.block_tables.shape[1] <= self.graphs.max_blocks_per_seq:
-            g = self.graphs.get(mi.input_tokens.shape[0])
+        graphs = self.graph_pools[slot] if self.graph_pools is not None else None
+        if graphs is not None and mi.decode_only and md.block_tables.shape[1] <= graphs.max_blocks_per_seq:
+            g = graphs.get(mi.input_tokens.shape[0])
             g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor)
             tokens = g.replay()[:mi.input_tokens.shape[0]]
             if len(mi.sample_indices) != mi.input_tokens.shape[0]:
@@ -129,8 +134,12 @@ class LLMEngine:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.attn_backend = PagedAttnBackend()
+        # steps in flight run on separate streams (a stream per task, core/executor.py:62-93), so
+        # each needs its own graph static buffers
+        self.num_slots = (max(1, scheduler_config.max_num_on_the_fly)
+                          if scheduler_config.scheduling in ("async", "double_buffer") else 1)
         self.worker = Worker(model_config, cache_config, self.attn_backend, device, use_hip_graph,
-                             decode_version, scheduler_config.max_model_len, seed)
+                             decode_version, scheduler_config.max_model_len, seed, num_slots=self.num_slots)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
         if num_gpu is None:
             num_gpu, auto_cpu = self.worker.determine_num_available_blocks()
@@ -145,7 +154,13 @@ class LLMEngine:
         self.groups: Dict[str, SequenceGroup] = {}
         self.seq_to_group: Dict[int, SequenceGroup] = {}
         # async machinery (core/executor.py:48-185)
-        self.stream = torch.cuda.Stream(self.device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.num_slots)]
+        self.stream = self.streams[0]
+        self.free_slots: "queue.Queue" = queue.Queue()
+        for i in range(self.num_slots):
+            self.free_slots.put(i)
+        self._done_thread: Optional[threading.Thread] = None
+        self._done_q: "queue.Queue" = queue.Queue()
         self.executor_in: "queue.Queue" = queue.Queue()
         self.executor_out: "queue.Queue" = queue.Queue()
         self.num_on_the_fly = 0
@@ -217,28 +232,53 @@ class LLMEngine:
 
     # ---- asynchronous step (core/llm_engine.py:132-176) ----
     def _execute_loop(self) -> None:
+        """The reference's async_execute_loop (core/executor.py:62-93): every task takes a stream
+        from the pool and is launched without waiting for the previous one, so up to
+        `max_num_on_the_fly` steps overlap on the GPU (one step's launch gaps and kernel
+        ramps are filled by the other's kernels); a helper thread waits for each task's event
+        and hands the result back in submission order."""
         torch.cuda.set_device(self.device)
         while True:
             item = self.executor_in.get()
             if item is None:
+                self._done_q.put(None)
                 return
             sched, ei = item
             try:
+                slot = self.free_slots.get()
                 t0 = time.perf_counter()
-                with torch.cuda.stream(self.stream):
-                    out = self.worker.execute(ei)
+                stream = self.streams[slot]
+                with torch.cuda.stream(stream):
+                    out = self.worker.execute(ei, slot)
                     ev = torch.cuda.Event()
-                    ev.record(self.stream)
-                ev.synchronize()  # results are on the host; the next step may already be queued
-                out.execute_begin_ts, out.execute_end_ts = t0, time.perf_counter()
-                self.executor_out.put((sched, out))
+                    ev.record(stream)
+                out.execute_begin_ts = t0
+                self._done_q.put((slot, ev, sched, out))
             except Exception as e:  # surfaced on the engine thread (core/executor.py:59-60)
+                self.executor_out.put(e)
+
+    def _done_loop(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self._done_q.get()
+            if item is None:
+                return
+            slot, ev, sched, out = item
+            try:
+                ev.synchronize()  # results are on the host
+                out.execute_end_ts = time.perf_counter()
+                self.free_slots.put(slot)
+                self.executor_out.put((sched, out))
+            except Exception as e:
+                self.free_slots.put(slot)
                 self.executor_out.put(e)
 
     def ensure_start_execute_loop(self) -> None:
         if self._thread is None:
             self._thread = threading.Thread(target=self._execute_loop, daemon=True)
+            self._done_thread = threading.Thread(target=self._done_loop, daemon=True)
             self._thread.start()
+            self._done_thread.start()
 
     def async_step(self, schedule_more: bool = True) -> List[RequestOutput]:
         """schedule_more=False only collects a result (used to drain the pipeline)."""
@@ -263,7 +303,9 @@ class LLMEngine:
         if self._thread is not None:
             self.executor_in.put(None)
             self._thread.join(timeout=5)
-            self._thread = None
+            if self._done_thread is not None:
+                self._done_thread.join(timeout=5)
+            self._thread = self._done_thread = None
 
     # ---- synthetic context (benchmarks): mark prompts as computed and fill their KV ----
     def prefill_synthetic(self, seed: int = 0) -> None:
