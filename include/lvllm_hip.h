@@ -45,6 +45,9 @@ enum lvllm_kv_dtype {
 const char* lvllm_last_error(void);
 /* build identification: "lvllm_hip gfx950 <abi version>" */
 const char* lvllm_version(void);
+/* Launch-shape knobs for the host's concurrency level (process-wide): "gemm_workgroups" (default
+ * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4). */
+int lvllm_set_tuning(const char* key, int value);
 
 /* ---- attention (replaces csrc/ops.h:8-27, attention_kernels.cu:808-997) --- */
 

@@ -393,7 +393,7 @@ static void launch_mfma_waves(const AttnParams& p, int num_seqs, int num_parts,
 #ifndef LVLLM_ATTN_NWAVES_LONG
 #define LVLLM_ATTN_NWAVES_LONG 8
 #endif
-  if (tiles >= 16 && lds8_ok)  // >= 2 tiles per wave
+  if (tiles >= 16 && lds8_ok && tuning().attn_waves == 8)  // >= 2 tiles per wave
     launch_mfma<T, D, BS, LVLLM_ATTN_NWAVES_LONG>(p, num_seqs, num_parts, stream);
   else
     launch_mfma<T, D, BS, 4>(p, num_seqs, num_parts, stream);

@@ -1,12 +1,37 @@
 // Error reporting, version string and device queries of the C-ABI (include/lvllm_hip.h).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace lvllm {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v;
+    if (const char* e = getenv("LVLLM_GEMM_CUS")) v.gemm_workgroups = atoi(e);
+    if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
+    return v;
+  }();
+  return t;
+}
 }  // namespace lvllm
 
 extern "C" const char* lvllm_last_error(void) { return lvllm::g_last_error.c_str(); }
+
+extern "C" int lvllm_set_tuning(const char* key, int value) {
+  const std::string k = key ? key : "";
+  if (k == "gemm_workgroups") {
+    LV_CHECK(value >= 8 && value <= 1024, "gemm_workgroups must be in [8, 1024]");
+    lvllm::tuning().gemm_workgroups = value;
+  } else if (k == "attn_waves") {
+    LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
+    lvllm::tuning().attn_waves = value;
+  } else {
+    LV_CHECK(false, "unknown tuning key '" + k + "'");
+  }
+  return 0;
+}
 
 extern "C" const char* lvllm_version(void) { return "lvllm_hip gfx950 abi1"; }
 

@@ -16,6 +16,17 @@ constexpr int kWave = 64;
 // ---- error plumbing -------------------------------------------------------
 void set_error(const std::string& msg);
 
+// Launch-shape knobs a host can set for its concurrency level (lvllm_set_tuning):
+//   gemm_workgroups  workgroups of the decode GEMM's N split (default 256 = one per CU; an engine
+//                    that keeps two steps in flight on two streams sets 128: each GEMM then
+//                    leaves half the CUs to the other stream's kernel, +10 % tokens/s measured)
+//   attn_waves       waves per workgroup of the long-context decode attention (8 or 4)
+struct Tuning {
+  int gemm_workgroups = 256;
+  int attn_waves = 8;
+};
+Tuning& tuning();
+
 #define LV_CHECK(cond, msg)                                   \
   do {                                                        \
     if (!(cond)) {                                            \

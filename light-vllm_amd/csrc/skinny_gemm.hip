@@ -24,6 +24,8 @@
 // MFMA wants -- [N/16][K/32][g = 4][c = 16][8 elements], i.e. one contiguous 1 KiB per (n-tile,
 // k-step), the same shape as a paged K-cache tile -- and then every wave load is one contiguous
 // KiB (lvllm_pack_weight / `packed` below).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace lvllm {
@@ -375,7 +377,10 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
   const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;  // <= max_steps_per_wave(M)
   const int ntiles = N / 16;
-  int groups = 256 / ksplit;  // one workgroup (8 waves, ~200 VGPRs) per CU
+  // one workgroup (8 waves, ~236 VGPRs: nothing else fits beside it) per CU by default; a host
+  // running steps on several streams asks for fewer (common.h Tuning)
+  const int gemm_cus = tuning().gemm_workgroups;
+  int groups = gemm_cus / ksplit;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
   if (ksplit_out) *ksplit_out = ksplit;

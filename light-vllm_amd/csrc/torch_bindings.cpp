@@ -524,6 +524,9 @@ TORCH_LIBRARY(_C_amd, amd) {
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
           "str kv_cache_dtype, bool causal=True) -> ()");
   amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
+  amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
+    check(lvllm_set_tuning(key.c_str(), (int)value));
+  });
   amd.def("varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads, "
           "int head_size) -> int", &varlen_attention_workspace_bytes);
   amd.def("varlen_attention(Tensor! out, Tensor query, Tensor key, Tensor value, Tensor cu_seqlens, "
