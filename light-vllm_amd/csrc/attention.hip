@@ -169,9 +169,15 @@ static int check_common(int num_seqs, int num_heads, int head_size, int num_kv_h
   LV_CHECK(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
            "num_heads must be a positive multiple of num_kv_heads");
   LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
-  LV_CHECK(kv_dtype == LVLLM_KV_AUTO,
-           "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
-  LV_CHECK(k_scale == 1.0f && v_scale == 1.0f, "k_scale/v_scale must be 1.0 with kv_cache_dtype 'auto'");
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
+  if (kv_dtype == LVLLM_KV_AUTO) {
+    LV_CHECK(k_scale == 1.0f && v_scale == 1.0f, "k_scale/v_scale must be 1.0 with kv_cache_dtype 'auto'");
+  } else {
+    LV_CHECK(dtype == LVLLM_F16 || dtype == LVLLM_BF16, "fp8 kv cache needs float16 or bfloat16 queries");
+    LV_CHECK(block_size == 16 || block_size == 32, "fp8 kv cache: block size must be 16 or 32");
+    LV_CHECK(head_size % 16 == 0, "fp8 kv cache: head size must be a multiple of 16");
+    LV_CHECK(k_scale > 0.f && v_scale > 0.f, "fp8 kv cache: scales must be positive");
+  }
   LV_CHECK(blocksparse_vert_stride <= 1, "block-sparse attention is not built in this round");
   LV_CHECK(block_size == 8 || block_size == 16 || block_size == 32,
            "Unsupported block size: " + std::to_string(block_size));
@@ -212,10 +218,13 @@ extern "C" int lvllm_paged_attention_v1(
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = 1;
   p.partitioned = 0; p.scale = scale;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   hipStream_t s = (hipStream_t)stream;
+  const int kvb = p.kv_fp8 ? 1 : 2;
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
-                      (q_stride * 2) % 16 == 0 && (kv_block_stride * 2) % 16 == 0 &&
-                      (kv_head_stride * 2) % 16 == 0 && block_size >= 16;
+                      (q_stride * 2) % 16 == 0 && (kv_block_stride * kvb) % 16 == 0 &&
+                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 16;
+  LV_CHECK(!p.kv_fp8 || vec_ok, "fp8 kv cache: operands must be 16-byte aligned");
   int rc = 0;
   if (dtype == LVLLM_BF16 && vec_ok)
     rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, 1, max_seq_len, s);
@@ -264,10 +273,13 @@ extern "C" int lvllm_paged_attention_v2_phases(
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = max_num_partitions;
   p.partitioned = 1; p.scale = scale;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   hipStream_t s = (hipStream_t)stream;
+  const int kvb = p.kv_fp8 ? 1 : 2;
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
-                      (q_stride * 2) % 16 == 0 && (kv_block_stride * 2) % 16 == 0 &&
-                      (kv_head_stride * 2) % 16 == 0 && block_size >= 16;
+                      (q_stride * 2) % 16 == 0 && (kv_block_stride * kvb) % 16 == 0 &&
+                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 16;
+  LV_CHECK(!p.kv_fp8 || vec_ok, "fp8 kv cache: operands must be 16-byte aligned");
   // How many equal shares each context is cut into.  The reference always cuts at 512
   // tokens; here the cut exists only to fill the GPU: with >= 8 waves per CU from
   // (sequence, kv head) pairs alone there is no cut at all (one pass, no reduce), otherwise

@@ -36,6 +36,8 @@
 #pragma once
 #include <float.h>
 
+#include <type_traits>
+
 #include "attention_params.h"
 #include "common.h"
 
@@ -132,7 +134,26 @@ constexpr int kSrdFlags = 0x00020000;
 #ifndef LVLLM_ATTN_MIN_WAVES_PER_SIMD
 #define LVLLM_ATTN_MIN_WAVES_PER_SIMD 2
 #endif
-template <typename T, int D, int BS, int NWAVES, int NBUF>
+// 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale)
+template <typename T>
+__device__ __forceinline__ u32x2_t dequant4(uint32_t w, float scale, bool scaled) {
+  f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+  f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+  if (scaled) {
+    lo *= scale;
+    hi *= scale;
+  }
+  return u32x2_t{pack2<T>(lo.x, lo.y), pack2<T>(hi.x, hi.y)};
+}
+
+// KV8: fp8 KV cache.  Same tiles, half the bytes: a K tile is NS/2 wave loads of 16 bytes per lane
+// (chunk = 16 head-dim values of one token), each feeding TWO k-slices after conversion; the
+// contraction only needs K and Q to agree on which d sits in which (slice, lane group, element),
+// so Q is loaded with the permutation the fp8 chunks impose: slice 2i+h, group g, element e <->
+// d = 64i + 16g + 8h + e.  A V piece is 4 bytes per lane.  Conversion is v_cvt_pk_f32_fp8 (+ scale)
+// + v_cvt_pk_{bf16,f16}_f32: ~100 vector instructions per tile against ~7 us of HBM time per tile
+// and wave at full bandwidth -- free.
+template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8>
 __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
     const AttnParams p) {
   using S = typename T::store_t;
@@ -142,7 +163,12 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
   constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
   constexpr int DPAD = NDT * 16;
-  constexpr int kHeadBytes = D * BS * 2;  // one kv head's K (or V) bytes inside a block
+  constexpr int KVB = KV8 ? 1 : 2;             // bytes per cache element
+  constexpr int kHeadBytes = D * BS * KVB;     // one kv head's K (or V) bytes inside a block
+  constexpr int NKL = KV8 ? (D + 63) / 64 : NS;  // K wave loads (16 bytes per lane) per tile
+  constexpr int NSQ = KV8 ? 2 * NKL : NS;        // k-slices actually multiplied (fp8: two per load)
+  static_assert(!KV8 || D % 16 == 0, "fp8 cache: head size must be a multiple of x = 16");
+  using vraw_t = typename std::conditional<KV8, uint32_t, u32x2_t>::type;  // V piece as loaded
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
@@ -170,25 +196,27 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   const int nmy = ntiles > wave ? (ntiles - wave + NWAVES - 1) / NWAVES : 0;
 
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
-  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
-  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * 2;
-  const int64_t bsb = p.kv_block_stride * 2;
+  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * KVB;
+  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * KVB;
+  const int64_t bsb = p.kv_block_stride * KVB;
 
   // per-lane byte offsets inside a (block, kv head) region
   const int koff = (g * BS + c) * 16;      // K chunk (d8 = g (+4j), token c)
-  const int voff = (c * BS + 4 * g) * 2;   // V piece (row c (+16t), tokens 4g..4g+3)
+  const int voff = (c * BS + 4 * g) * KVB;  // V piece (row c (+16t), tokens 4g..4g+3)
 
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
-  u32x4_t qf[NS];
+  u32x4_t qf[NSQ];
   {
     const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + c) * D;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      const int d8 = 4 * j + g;
+    for (int j = 0; j < NSQ; ++j) {
+      // bf16/f16 cache: d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8 above)
+      const int d0 = KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g;
       qf[j] = u32x4_t{0, 0, 0, 0};
-      if (c < nh && d8 * 8 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d8 * 8);
+      if (c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
     }
   }
+  const bool k_scaled = KV8 && p.k_scale != 1.f, v_scaled = KV8 && p.v_scale != 1.f;
   const float alibi = (p.alibi_slopes != nullptr && c < nh) ? p.alibi_slopes[head0 + c] : 0.f;
 
   // Physical block number of this wave's j-th tile.  The index is wave-uniform, so
@@ -208,7 +236,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 #pragma unroll
   for (int t = 0; t < NDT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto load_tile = [&](u32x4_t (&k)[NS], u32x2_t (&v)[NDT], const int j, const int bn32)
+  auto load_tile = [&](u32x4_t (&k)[NKL], vraw_t (&v)[NDT], const int j, const int bn32)
                        __attribute__((always_inline)) {
     const int lt = wave + j * NWAVES;
     const bool valid = j < nmy;
@@ -219,21 +247,36 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
         (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
     __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-    // chunks with d8 >= D/8 and rows with d >= D fall outside kHeadBytes -> zeros
+    // chunks past the head size and rows with d >= D fall outside kHeadBytes -> zeros
+    // (a chunk is 16 bytes of one token in both cache types: 8 T or 16 fp8)
 #pragma unroll
-    for (int jj = 0; jj < NS; ++jj)
+    for (int jj = 0; jj < NKL; ++jj)
       k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
-      v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
+    for (int t = 0; t < NDT; ++t) {
+      if constexpr (KV8)
+        v[t] = __builtin_amdgcn_raw_buffer_load_b32(vr, voff + t * (16 * BS), off, LVLLM_ATTN_AUX);
+      else
+        v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
+    }
   };
 
   // One tile: S = K.Q^T (NS MFMAs), online softmax, O^T += V^T.P^T (NDT MFMAs).
-  auto compute_tile = [&](const u32x4_t (&k)[NS], const u32x2_t (&v)[NDT], const int j)
+  auto compute_tile = [&](const u32x4_t (&kraw)[NKL], const vraw_t (&v)[NDT], const int j)
                           __attribute__((always_inline)) {
     f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KV8) {
 #pragma unroll
-    for (int jj = 0; jj < NS; ++jj) s = mfma_qk<T>(k[jj], qf[jj], s);
+      for (int jj = 0; jj < NSQ; ++jj) {
+        const u32x4_t w = kraw[jj >> 1];
+        const u32x2_t a = dequant4<T>((jj & 1) ? w.z : w.x, p.k_scale, k_scaled);
+        const u32x2_t b = dequant4<T>((jj & 1) ? w.w : w.y, p.k_scale, k_scaled);
+        s = mfma_qk<T>(u32x4_t{a.x, a.y, b.x, b.y}, qf[jj], s);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) s = mfma_qk<T>(kraw[jj], qf[jj], s);
+    }
     // lane (g, c): logits of tokens tok0 .. tok0+3 for head c
     const int tok0 = ((tile0 + wave + j * NWAVES) << 4) + 4 * g;
     float x[4];
@@ -272,16 +315,18 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
     for (int t = 0; t < NDT; ++t) {
       acc[t] *= alpha;
       u32x2_t va;
-      va.x = v[t].x & mx;
-      va.y = v[t].y & my;
+      if constexpr (KV8) va = dequant4<T>(v[t], p.v_scale, v_scaled);
+      else va = v[t];
+      va.x &= mx;
+      va.y &= my;
       acc[t] = mfma_pv<T>(va, pb, acc[t]);  // rows: d = 16t + (lane&15); cols: head
     }
   };
 
   // ---- main loop: NBUF register sets rotate; NBUF-1 tiles stay in flight ----
   {
-    u32x4_t k0[NS], k1[NS], k2[NS];
-    u32x2_t v0[NDT], v1[NDT], v2[NDT];
+    u32x4_t k0[NKL], k1[NKL], k2[NKL];
+    vraw_t v0[NDT], v1[NDT], v2[NDT];
     int bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
     load_tile(k0, v0, 0, bn0);
     bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
@@ -374,12 +419,19 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   constexpr int DPAD = ((D + 15) / 16) * 16;
   const size_t smem = (size_t)NWAVES * 16 * 2 * sizeof(float) +
                       (size_t)NWAVES * nh_lds * DPAD * sizeof(float);
-  auto kern = paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF>;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem);
-  hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64),
-                     smem, stream, p);
+  auto launch = [&](auto kern) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64), smem,
+                       stream, p);
+  };
+  if constexpr (D % 16 == 0) {
+    if (p.kv_fp8) {
+      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true>);
+      return;
+    }
+  }
+  launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false>);
 }
 
 template <typename T, int D, int BS>

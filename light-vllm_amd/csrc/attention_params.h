@@ -21,7 +21,11 @@ struct AttnParams {
   int partitioned;  // 0: whole sequence per workgroup (v1)
   int num_splits;   // partitioned: every sequence is cut into at most this many equal shares
   float scale;
-  int64_t q_stride, kv_block_stride, kv_head_stride;
+  int64_t q_stride, kv_block_stride, kv_head_stride;  // kv strides in cache elements
+  // kv_cache_dtype "fp8": the caches hold OCP e4m3fn bytes, layouts with x = 16; a dequantised
+  // element is T(float(fp8) * scale) (csrc/quantization/fp8/nvidia/quant_utils.cuh:295-300)
+  int kv_fp8;
+  float k_scale, v_scale;
 };
 
 

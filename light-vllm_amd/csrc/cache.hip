@@ -67,6 +67,71 @@ __global__ void reshape_and_cache_kernel(
   }
 }
 
+// kv_cache_dtype "fp8": every element becomes e4m3fn(float(x) / scale), saturating at +-448, NaN
+// kept (csrc/cache_kernels.cu:194-202, fp8/nvidia/quant_utils.cuh:458-489).  x = 16: one thread per
+// 16-element chunk of one (token, head) -- a 16-byte K store, 16 V bytes to 16 rows of [.., D, BS].
+template <typename T>
+__global__ void reshape_and_cache_fp8_kernel(
+    const typename T::store_t* __restrict__ key, const typename T::store_t* __restrict__ value,
+    uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
+    const int64_t* __restrict__ slot_mapping, const int64_t num_chunks, const int chunks_per_head,
+    const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
+    const int64_t value_stride, const float k_scale, const float v_scale) {
+  const int chunks_per_token = chunks_per_head * num_heads;
+  auto quant4 = [](float a, float b, float c, float d, float scale) -> uint32_t {
+    auto sat = [scale](float v) {
+      v = v / scale;
+      return fabsf(v) > 448.f ? copysignf(448.f, v) : v;  // NaN compares false and passes through
+    };
+    const float sa = sat(a), sb = sat(b), sc = sat(c), sd = sat(d);
+    uint32_t w = __builtin_amdgcn_cvt_pk_fp8_f32(sa, sb, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(sc, sd, w, true);
+    // NaN -> the one code 0x7f whatever sign the division left on it
+    if (sa != sa) w = (w & 0xffffff00u) | 0x0000007fu;
+    if (sb != sb) w = (w & 0xffff00ffu) | 0x00007f00u;
+    if (sc != sc) w = (w & 0xff00ffffu) | 0x007f0000u;
+    if (sd != sd) w = (w & 0x00ffffffu) | 0x7f000000u;
+    return w;
+  };
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < num_chunks;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t token = idx / chunks_per_token;
+    const int rem = (int)(idx - token * chunks_per_token);
+    const int64_t slot = slot_mapping[token];
+    if (slot < 0) continue;  // padding token
+    const int head = rem / chunks_per_head;
+    const int x_idx = rem - head * chunks_per_head;
+    const int64_t block_idx = slot / block_size;
+    const int64_t block_off = slot % block_size;
+    const typename T::store_t* ksrc = key + token * key_stride + head * head_size + x_idx * 16;
+    const typename T::store_t* vsrc = value + token * value_stride + head * head_size + x_idx * 16;
+    float kf[16], vf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      kf[i] = T::to_float(ksrc[i]);
+      vf[i] = T::to_float(vsrc[i]);
+    }
+    uint4 kq;
+    kq.x = quant4(kf[0], kf[1], kf[2], kf[3], k_scale);
+    kq.y = quant4(kf[4], kf[5], kf[6], kf[7], k_scale);
+    kq.z = quant4(kf[8], kf[9], kf[10], kf[11], k_scale);
+    kq.w = quant4(kf[12], kf[13], kf[14], kf[15], k_scale);
+    uint8_t* kdst = key_cache + ((block_idx * num_heads + head) * chunks_per_head + x_idx) * (int64_t)block_size * 16 +
+                    block_off * 16;
+    *reinterpret_cast<uint4*>(kdst) = kq;
+    uint8_t* vdst = value_cache + ((block_idx * num_heads + head) * head_size + x_idx * 16) * (int64_t)block_size +
+                    block_off;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const uint32_t w = quant4(vf[i], vf[i + 1], vf[i + 2], vf[i + 3], v_scale);
+      vdst[(int64_t)(i + 0) * block_size] = (uint8_t)(w);
+      vdst[(int64_t)(i + 1) * block_size] = (uint8_t)(w >> 8);
+      vdst[(int64_t)(i + 2) * block_size] = (uint8_t)(w >> 16);
+      vdst[(int64_t)(i + 3) * block_size] = (uint8_t)(w >> 24);
+    }
+  }
+}
+
 // Flash layout [NB, BS, H, D]: both K and V rows are contiguous per token.
 template <typename store_t, int X>
 __global__ void reshape_and_cache_flash_kernel(
@@ -131,11 +196,28 @@ extern "C" int lvllm_reshape_and_cache(
     const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
     int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
     int kv_dtype, float k_scale, float v_scale, void* stream) {
-  LV_CHECK(kv_dtype == LVLLM_KV_AUTO, "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
-  (void)k_scale; (void)v_scale;
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
   if (num_tokens == 0) return 0;
   const int esize = dtype == LVLLM_F32 ? 4 : 2;
   LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
+  if (kv_dtype == LVLLM_KV_FP8_E4M3) {
+    LV_CHECK(x == 16, "fp8 key_cache.size(4) must be 16");
+    LV_CHECK(head_size % 16 == 0, "fp8 kv cache: head_size must be a multiple of 16");
+    LV_CHECK(k_scale > 0.f && v_scale > 0.f, "fp8 kv cache: scales must be positive");
+    LV_CHECK(aligned16(key_cache), "fp8 key_cache must be 16-byte aligned");
+    const int chunks_per_head = head_size / 16;
+    const int64_t num_chunks = (int64_t)num_tokens * num_heads * chunks_per_head;
+    const int64_t want = (num_chunks + 255) / 256;
+    const int grid = (int)(want < 4096 ? want : 4096);
+    LV_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+        (reshape_and_cache_fp8_kernel<scalar_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        (const typename scalar_t::store_t*)key, (const typename scalar_t::store_t*)value, (uint8_t*)key_cache,
+        (uint8_t*)value_cache, slot_mapping, num_chunks, chunks_per_head, num_heads, head_size, block_size,
+        key_stride, value_stride, k_scale, v_scale));
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
+  LV_CHECK(k_scale == 1.0f && v_scale == 1.0f, "k_scale/v_scale must be 1.0 with kv_cache_dtype 'auto'");
   LV_CHECK(x == 16 / esize, "key_cache.size(4) must be 16/sizeof(element)");
   LV_CHECK(head_size % x == 0, "head_size must be a multiple of x");
   const int chunks_per_head = head_size / x;

@@ -35,6 +35,17 @@ int kv_dtype_code(const std::string& s) {
   TORCH_CHECK(false, "Unsupported data type of kv cache: ", s);
 }
 
+// "auto": the cache holds the query's element type; "fp8": one byte per element
+void check_cache_dtype(const torch::Tensor& cache, const torch::Tensor& like, int kv_code, const char* op) {
+  if (kv_code == LVLLM_KV_AUTO) {
+    TORCH_CHECK(cache.scalar_type() == like.scalar_type(), op, ": kv_cache_dtype 'auto' needs a cache of dtype ",
+                like.scalar_type(), ", got ", cache.scalar_type());
+  } else {
+    TORCH_CHECK(cache.element_size() == 1, op, ": kv_cache_dtype 'fp8' needs a one-byte cache dtype, got ",
+                cache.scalar_type());
+  }
+}
+
 void* current_stream(const torch::Tensor& t) {
   return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
@@ -55,6 +66,8 @@ void paged_attention_v1(torch::Tensor& out, torch::Tensor& query, torch::Tensor&
   TORCH_CHECK(out.is_contiguous(), "out must be contiguous");
   TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt,
               "block_tables / seq_lens must be int32");
+  check_cache_dtype(key_cache, query, kv_dtype_code(kv_cache_dtype), "paged_attention_v1");
+  check_cache_dtype(value_cache, query, kv_dtype_code(kv_cache_dtype), "paged_attention_v1");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
   const float* alibi = alibi_slopes ? alibi_slopes->data_ptr<float>() : nullptr;
   check(lvllm_paged_attention_v1(
@@ -84,6 +97,8 @@ void paged_attention_v2(torch::Tensor& out, torch::Tensor& exp_sums, torch::Tens
               "block_tables / seq_lens must be int32");
   TORCH_CHECK(exp_sums.scalar_type() == at::kFloat && max_logits.scalar_type() == at::kFloat,
               "exp_sums / max_logits must be float32");
+  check_cache_dtype(key_cache, query, kv_dtype_code(kv_cache_dtype), "paged_attention_v2");
+  check_cache_dtype(value_cache, query, kv_dtype_code(kv_cache_dtype), "paged_attention_v2");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
   const float* alibi = alibi_slopes ? alibi_slopes->data_ptr<float>() : nullptr;
   check(lvllm_paged_attention_v2(
@@ -216,6 +231,8 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value, torch::Tensor& 
   TORCH_CHECK(slot_mapping.scalar_type() == at::kLong, "slot_mapping must be int64");
   TORCH_CHECK(key_cache.is_contiguous() && value_cache.is_contiguous(),
               "key_cache / value_cache must be contiguous");
+  check_cache_dtype(key_cache, key, kv_dtype_code(kv_cache_dtype), "reshape_and_cache");
+  check_cache_dtype(value_cache, key, kv_dtype_code(kv_cache_dtype), "reshape_and_cache");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(key));
   check(lvllm_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
                                 value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),

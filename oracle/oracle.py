@@ -31,6 +31,10 @@ def lib():
         _lib.oracle_f32_to_bf16.argtypes = [ctypes.c_float]
         _lib.oracle_f16_to_f32.restype = ctypes.c_float
         _lib.oracle_f16_to_f32.argtypes = [ctypes.c_uint16]
+        _lib.oracle_f32_to_e4m3.restype = ctypes.c_uint8
+        _lib.oracle_f32_to_e4m3.argtypes = [ctypes.c_float]
+        _lib.oracle_e4m3_to_f32.restype = ctypes.c_float
+        _lib.oracle_e4m3_to_f32.argtypes = [ctypes.c_uint8]
     return _lib
 
 
@@ -102,6 +106,28 @@ def varlen_attention(out, query, key, value, cu_seqlens, scale, causal):
         _i(query.size(1)), _i(key.size(1)), _i(query.size(2)), _f(scale), _i(1 if causal else 0),
         _l(query.stride(0)), _l(key.stride(0)), _l(value.stride(0)), _l(out.stride(0)),
         _i(_DT[query.dtype]))
+
+
+def set_kv_cache_fp8(on, k_scale=1.0, v_scale=1.0):
+    """kv_cache_dtype of the attention oracles: on = the caches hold OCP e4m3fn bytes."""
+    lib().oracle_set_kv_cache_fp8(_i(1 if on else 0), _f(k_scale), _f(v_scale))
+
+
+def reshape_and_cache_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale=1.0, v_scale=1.0):
+    """key_cache uint8 [NB, KVH, D/16, BS, 16], value_cache uint8 [NB, KVH, D, BS]."""
+    assert key_cache.dtype == torch.uint8 and value_cache.dtype == torch.uint8 and key_cache.size(4) == 16
+    lib().oracle_reshape_and_cache_fp8(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping), _i(key.size(0)),
+        _i(key.size(1)), _i(key.size(2)), _i(key_cache.size(3)), _l(key.stride(0)), _l(value.stride(0)),
+        _i(_DT[key.dtype]), _f(k_scale), _f(v_scale))
+
+
+def f32_to_e4m3(x: float) -> int:
+    return int(lib().oracle_f32_to_e4m3(_f(x)))
+
+
+def e4m3_to_f32(v: int) -> float:
+    return float(lib().oracle_e4m3_to_f32(ctypes.c_uint8(v)))
 
 
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):

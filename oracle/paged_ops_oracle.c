@@ -110,6 +110,57 @@ static inline float rnd(float f, int dt) {
 }
 static inline int esize(int dt) { return dt == 0 ? 4 : 2; }
 
+/* ---- fp8 KV cache: OCP e4m3fn, the format of the reference's NVIDIA path (__NV_E4M3 with
+ * __NV_SATFINITE, csrc/quantization/fp8/nvidia/quant_utils.cuh:458-489) and of the gfx950
+ * conversion instructions.  (The reference's ROCm path, fp8/amd/hip_float8.h, is the MI300 fnuz
+ * format; the cache content is private to the kernels, so the hardware format of the target wins.)
+ *   1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities; 0x7f / 0xff = NaN; max 448. ---- */
+static float e4m3_to_f(uint8_t v) {
+  const int sign = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float r;
+  if (e == 15 && m == 7) r = NAN;
+  else if (e == 0) r = ldexpf((float)m, -9);            /* subnormal: m/8 * 2^-6 */
+  else r = ldexpf(1.f + (float)m / 8.f, e - 7);
+  return sign ? -r : r;
+}
+static uint8_t f_to_e4m3(float f) { /* round to nearest even, saturate to +-448, NaN -> 0x7f */
+  uint8_t sign = signbit(f) ? 0x80 : 0;
+  if (isnan(f)) return 0x7f;
+  float a = fabsf(f);
+  if (a >= 448.f) return sign | 0x7e; /* 448 = 1.75 * 2^8 */
+  if (a < ldexpf(1.f, -10)) return sign; /* below half the smallest subnormal (2^-9): rounds to 0; ties at 2^-10 -> even (0) */
+  int e;
+  float fr = frexpf(a, &e); /* a = fr * 2^e, fr in [0.5, 1) */
+  int exp = e - 1;          /* a = (2 fr) * 2^exp, 2 fr in [1, 2) */
+  if (exp < -6) {           /* subnormal: quantum 2^-9 */
+    float q = a * 512.f;    /* in units of 2^-9 */
+    float r = nearbyintf(q);
+    if (r >= 8.f) return sign | 0x08; /* rounds up to the smallest normal 2^-6 */
+    return sign | (uint8_t)r;
+  }
+  float q = ldexpf(a, 3 - exp); /* mantissa with 3 fraction bits: in [8, 16) */
+  float r = nearbyintf(q);
+  if (r >= 16.f) { r = 8.f; exp += 1; }
+  if (exp > 8 || (exp == 8 && r > 14.f)) return sign | 0x7e;
+  return sign | (uint8_t)(((exp + 7) << 3) | ((int)r - 8));
+}
+uint8_t oracle_f32_to_e4m3(float f) { return f_to_e4m3(f); }
+float oracle_e4m3_to_f32(uint8_t v) { return e4m3_to_f(v); }
+
+/* kv_cache_dtype of the attention functions below: 0 = "auto" (cache holds T), 1 = "fp8"/"fp8_e4m3".
+ * A dequantised element is T(float(fp8) * scale) (nvidia/quant_utils.cuh:295-300), then fp32 math. */
+static int g_kv_fp8 = 0;
+static float g_k_scale = 1.f, g_v_scale = 1.f;
+void oracle_set_kv_cache_fp8(int on, float k_scale, float v_scale) {
+  g_kv_fp8 = on;
+  g_k_scale = k_scale;
+  g_v_scale = v_scale;
+}
+static inline float ldkv(const void* cache, int dt, int64_t i, float scale) {
+  if (!g_kv_fp8) return ld(cache, dt, i);
+  return rnd(e4m3_to_f(((const uint8_t*)cache)[i]) * scale, dt);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -140,6 +191,7 @@ static void attend_range(const void* q, int64_t q_off, const void* k_cache, cons
                          float* out_f32, float* out_max, float* out_sum) {
   const int n = t1 - t0;
   float qk_max = -FLT_MAX;
+  if (g_kv_fp8) x = 16; /* 16 / sizeof(cache element), cache_kernels.cu:184-188 */
   for (int i = 0; i < n; ++i) {
     const int tok = t0 + i;
     const int64_t bn = block_table[tok / block_size];
@@ -149,7 +201,7 @@ static void attend_range(const void* q, int64_t q_off, const void* k_cache, cons
     for (int d = 0; d < head_size; ++d) {
       /* key_cache[block][head][d / x][off][d % x], cache_kernels.cu:184-188 */
       const int64_t ki = kb + (int64_t)(d / x) * block_size * x + (int64_t)off * x + (d % x);
-      dot += ld(q, dt, q_off + d) * ld(k_cache, dt, ki);
+      dot += ld(q, dt, q_off + d) * ldkv(k_cache, dt, ki, g_k_scale);
     }
     float qk = scale * dot;
     qk += (alibi_slope != 0.f) ? alibi_slope * (float)(tok - seq_len + 1) : 0.f;
@@ -172,7 +224,7 @@ static void attend_range(const void* q, int64_t q_off, const void* k_cache, cons
     const int64_t vb = bn * kv_block_stride + (int64_t)kv_head * kv_head_stride + off;
     const float p = logits[i];
     for (int d = 0; d < head_size; ++d)
-      out_f32[d] += p * ld(v_cache, dt, vb + (int64_t)d * block_size);
+      out_f32[d] += p * ldkv(v_cache, dt, vb + (int64_t)d * block_size, g_v_scale);
   }
   *out_max = qk_max;
   *out_sum = exp_sum;
@@ -236,7 +288,7 @@ void oracle_paged_prefill_attention(void* out, const void* query, const void* ke
                                     int sliding_window, float softcap, int64_t q_stride,
                                     int64_t out_stride, int64_t kv_block_stride,
                                     int64_t kv_head_stride, int dt) {
-  const int x = 16 / esize(dt);
+  const int x = g_kv_fp8 ? 16 : 16 / esize(dt);
   const int G = num_heads / num_kv_heads;
   int max_len = 1;
   for (int s = 0; s < num_seqs; ++s)
@@ -270,7 +322,7 @@ void oracle_paged_prefill_attention(void* out, const void* query, const void* ke
           float dot = 0.f;
           for (int d = 0; d < head_size; ++d)
             dot += ld(query, dt, q_off + d) *
-                   ld(key_cache, dt, kb + (int64_t)(d / x) * block_size * x + (int64_t)off * x + (d % x));
+                   ldkv(key_cache, dt, kb + (int64_t)(d / x) * block_size * x + (int64_t)off * x + (d % x), g_k_scale);
           float qk = scale * dot;
           if (softcap > 0.f) qk = softcap * tanhf(qk / softcap);
           if (alibi_slopes) qk += alibi_slopes[h] * (float)(key - pos);
@@ -289,7 +341,8 @@ void oracle_paged_prefill_attention(void* out, const void* query, const void* ke
           const int64_t vb = (int64_t)bt[key / block_size] * kv_block_stride + (int64_t)kvh * kv_head_stride +
                              key % block_size;
           const float pr = logits[i];
-          for (int d = 0; d < head_size; ++d) acc[d] += pr * ld(value_cache, dt, vb + (int64_t)d * block_size);
+          for (int d = 0; d < head_size; ++d)
+            acc[d] += pr * ldkv(value_cache, dt, vb + (int64_t)d * block_size, g_v_scale);
         }
         const float inv = sum > 0.f ? 1.f / sum : 0.f;
         for (int d = 0; d < head_size; ++d)
@@ -448,6 +501,32 @@ void oracle_reshape_and_cache(const void* key, const void* value, void* key_cach
                            block_off;
       memcpy((char*)key_cache + kdst * es, (const char*)key + (t * key_stride + i) * es, es);
       memcpy((char*)value_cache + vdst * es, (const char*)value + (t * value_stride + i) * es, es);
+    }
+  }
+}
+
+/* reshape_and_cache with kv_cache_dtype "fp8": csrc/cache_kernels.cu:194-202 -- every element
+ * becomes fp8(float(x) / scale) (nvidia/quant_utils.cuh:458-489); layouts as above with x = 16. */
+void oracle_reshape_and_cache_fp8(const void* key, const void* value, uint8_t* key_cache,
+                                  uint8_t* value_cache, const int64_t* slot_mapping, int num_tokens,
+                                  int num_heads, int head_size, int block_size, int64_t key_stride,
+                                  int64_t value_stride, int dt, float k_scale, float v_scale) {
+  const int x = 16;
+  for (int64_t t = 0; t < num_tokens; ++t) {
+    const int64_t slot = slot_mapping[t];
+    if (slot < 0) continue;
+    const int64_t block_idx = slot / block_size, block_off = slot % block_size;
+    for (int i = 0; i < num_heads * head_size; ++i) {
+      const int head = i / head_size, ho = i % head_size;
+      const int x_idx = ho / x, x_off = ho % x;
+      const int64_t kdst = block_idx * num_heads * (head_size / x) * block_size * x +
+                           (int64_t)head * (head_size / x) * block_size * x +
+                           (int64_t)x_idx * block_size * x + block_off * x + x_off;
+      const int64_t vdst = block_idx * num_heads * head_size * block_size +
+                           (int64_t)head * head_size * block_size + (int64_t)ho * block_size +
+                           block_off;
+      key_cache[kdst] = f_to_e4m3(ld(key, dt, t * key_stride + i) / k_scale);
+      value_cache[vdst] = f_to_e4m3(ld(value, dt, t * value_stride + i) / v_scale);
     }
   }
 }

@@ -137,3 +137,25 @@ def dense_prefill_fp64(inp, alibi_slopes=None, sliding_window=0, softcap=0.0):
             logits = logits.masked_fill(~mask, float("-inf"))
             out[qsl[s]:qsl[s + 1], h] = torch.softmax(logits, dim=1) @ v[:, kv]
     return out
+
+
+def quantize_paged_inputs_fp8(inp, k_scale=1.0, v_scale=1.0):
+    """fp8 (OCP e4m3fn) twin of a make_paged_inputs / make_prefill_inputs dict: caches become uint8
+    with x = 16 ([NB, KVH, D/16, BS, 16] / [NB, KVH, D, BS]), elements e4m3(float(x) / scale) with
+    saturation at +-448; k_dense / v_dense become the values the cache now represents (fp64)."""
+    out = dict(inp)
+    kc, vc = inp["key_cache"], inp["value_cache"]
+    NB, KVH, _, BS, x = kc.shape
+    D = vc.shape[2]
+    assert D % 16 == 0
+    kd = kc.permute(0, 1, 3, 2, 4).reshape(NB, KVH, BS, D).float()  # [NB, KVH, BS, D]
+    q = (kd / k_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    out["key_cache"] = q.view(torch.uint8).view(NB, KVH, BS, D // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
+    out["value_cache"] = (vc.float() / v_scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    out["k_scale"], out["v_scale"] = k_scale, v_scale
+    dt = inp["query"].dtype
+    out["k_dense"] = [((k.float() / k_scale).clamp(-448, 448).to(torch.float8_e4m3fn).float() * k_scale).to(dt)
+                      for k in inp["k_dense"]]
+    out["v_dense"] = [((v.float() / v_scale).clamp(-448, 448).to(torch.float8_e4m3fn).float() * v_scale).to(dt)
+                      for v in inp["v_dense"]]
+    return out

@@ -1,0 +1,186 @@
+"""fp8 (OCP e4m3fn) KV cache: oracle conversions against torch.float8_e4m3fn on the CPU; on the GPU
+reshape_and_cache bit-exact against the oracle and paged_attention_v1/v2 over an fp8 cache against
+the oracle and fp64 (csrc/cache_kernels.cu:194-202, csrc/attention/attention_kernels.cu with
+KV_DTYPE = kFp8E4M3, csrc/quantization/fp8/nvidia/quant_utils.cuh:295-300,458-489)."""
+import math
+
+import pytest
+import torch
+
+from helpers import dense_attention_fp64, make_paged_inputs, quantize_paged_inputs_fp8, v2_scratch
+from oracle import oracle
+
+DEV = "cuda:0"
+
+
+# ------------------------------------------------------------------ CPU: the oracle itself
+def test_e4m3_decode_all_codes_and_encode_vs_torch():
+    codes = torch.arange(256, dtype=torch.uint8)
+    ref = codes.view(torch.float8_e4m3fn).float()
+    for v in range(256):
+        a, b = oracle.e4m3_to_f32(v), float(ref[v])
+        assert (math.isnan(a) and math.isnan(b)) or a == b, v
+    g = torch.Generator().manual_seed(0)
+    xs = torch.cat([torch.randn(6000, generator=g) * 3, torch.randn(2000, generator=g) * 300,
+                    torch.randn(2000, generator=g) * 0.01,
+                    torch.tensor([0.0, -0.0, 448.0, 449.0, 1e9, -1e9, 2.0 ** -9, 2.0 ** -10, 2.0 ** -10 * 1.0001,
+                                  2.0 ** -10 * 3, 464.0, 447.9, 15.5, 17.0, 2.0 ** -11])])
+    want = xs.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)  # SATFINITE + round-to-nearest-even
+    got = [oracle.f32_to_e4m3(x) for x in xs.tolist()]
+    assert got == want.tolist()
+    assert oracle.f32_to_e4m3(float("nan")) & 0x7f == 0x7f
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k_scale,v_scale", [(1.0, 1.0), (0.5, 0.25), (0.37, 1.9)])
+def test_oracle_fp8_cache_write_and_attention(dtype, k_scale, v_scale):
+    """reshape_and_cache(fp8) stores e4m3(x / scale); attention over it equals the fp64 attention
+    over the dequantised values T(fp8 * scale)."""
+    S, H, KVH, D, BS = 3, 4, 2, 64, 16
+    lens = [40, 17, 1]
+    inp = make_paged_inputs(S, H, KVH, D, BS, lens, dtype=dtype, seed=2)
+    # write the dense K/V through the oracle's fp8 reshape_and_cache and compare with the torch-built twin
+    twin = quantize_paged_inputs_fp8(inp, k_scale, v_scale)
+    kc = torch.zeros_like(twin["key_cache"])
+    vc = torch.zeros_like(twin["value_cache"])
+    for s, n in enumerate(lens):
+        tok = torch.arange(n)
+        slots = (inp["block_tables"][s, tok // BS].long() * BS + tok % BS)
+        oracle.reshape_and_cache_fp8(inp["k_dense"][s], inp["v_dense"][s], kc, vc, slots, k_scale, v_scale)
+    used = torch.zeros(kc.shape[0], dtype=torch.bool)
+    for s, n in enumerate(lens):
+        used[inp["block_tables"][s, : (n + BS - 1) // BS].long()] = True
+    # slots past a sequence's end are zero in both; compare whole used blocks
+    assert torch.equal(kc[used], twin["key_cache"][used])
+    assert torch.equal(vc[used], twin["value_cache"][used])
+    out = torch.zeros_like(inp["query"])
+    oracle.set_kv_cache_fp8(True, k_scale, v_scale)
+    try:
+        oracle.paged_attention_v1(out, inp["query"], kc, vc, KVH, inp["scale"], inp["block_tables"],
+                                  inp["seq_lens"], BS, max(lens))
+    finally:
+        oracle.set_kv_cache_fp8(False)
+    want = dense_attention_fp64(twin)
+    tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9) * max(1.0, float(want.abs().max()))
+    assert float((out.double() - want).abs().max()) <= tol
+
+
+# ------------------------------------------------------------------ GPU
+def _run_attn(ops, twin, version, dev=DEV):
+    q = twin["query"].to(dev)
+    out = torch.full_like(q, float("nan"))
+    args = (q, twin["key_cache"].to(dev), twin["value_cache"].to(dev), twin["num_kv_heads"], twin["scale"],
+            twin["block_tables"].to(dev), twin["seq_lens"].to(dev), twin["block_size"], twin["max_seq_len"], None,
+            "fp8", twin["k_scale"], twin["v_scale"])
+    if version == "v1":
+        ops.paged_attention_v1(out, *args)
+    else:
+        es, ml, tmp = v2_scratch(q.shape[0], q.shape[1], q.shape[2], twin["max_seq_len"], q.dtype, dev)
+        ops.paged_attention_v2(out, es, ml, tmp, *args)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def _oracle_attn(twin):
+    out = torch.zeros_like(twin["query"])
+    oracle.set_kv_cache_fp8(True, twin["k_scale"], twin["v_scale"])
+    try:
+        oracle.paged_attention_v1(out, twin["query"], twin["key_cache"], twin["value_cache"], twin["num_kv_heads"],
+                                  twin["scale"], twin["block_tables"], twin["seq_lens"], twin["block_size"],
+                                  twin["max_seq_len"])
+    finally:
+        oracle.set_kv_cache_fp8(False)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("k_scale,v_scale", [(1.0, 1.0), (0.37, 1.9)])
+def test_reshape_and_cache_fp8_bit_exact(ops, dtype, block_size, k_scale, v_scale):
+    g = torch.Generator().manual_seed(5)
+    T, KVH, D, NB = 70, 3, 128, 9
+    key = (torch.randn(T, KVH, D, generator=g) * 3).to(dtype)
+    value = (torch.randn(T, KVH, D, generator=g) * 3).to(dtype)
+    key[0, 0, :6] = torch.tensor([1e4, -1e4, 448.0, 460.0, 0.0, -0.0]).to(dtype)  # saturation, signed zero
+    value[1, 1, :4] = torch.tensor([float("nan"), 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10]).to(dtype)
+    slots = torch.randperm(NB * block_size, generator=g)[:T].to(torch.int64)
+    slots[7] = -1
+    kc = torch.randint(0, 255, (NB, KVH, D // 16, block_size, 16), generator=g, dtype=torch.uint8)
+    vc = torch.randint(0, 255, (NB, KVH, D, block_size), generator=g, dtype=torch.uint8)
+    kc_o, vc_o = kc.clone(), vc.clone()
+    oracle.reshape_and_cache_fp8(key, value, kc_o, vc_o, slots, k_scale, v_scale)
+    kc_d, vc_d = kc.to(DEV), vc.to(DEV)
+    ops.reshape_and_cache(key.to(DEV), value.to(DEV), kc_d, vc_d, slots.to(DEV), "fp8", k_scale, v_scale)
+    torch.cuda.synchronize()
+    assert torch.equal(kc_d.cpu(), kc_o)
+    assert torch.equal(vc_d.cpu(), vc_o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("head_size", [64, 80, 96, 112, 128, 192, 256])
+def test_fp8_attention_head_sizes(ops, version, head_size):
+    from test_ops_gpu import check_attention
+    lens = [530, 100, 17, 1, 0, 64]
+    inp = make_paged_inputs(len(lens), 8, 2, head_size, 16, lens, dtype=torch.bfloat16, seed=head_size)
+    twin = quantize_paged_inputs_fp8(inp, 0.5, 2.0)
+    out = _run_attn(ops, twin, version)
+    assert torch.isfinite(out).all()
+    check_attention(out, _oracle_attn(twin), dense_attention_fp64(twin))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("H,KVH", [(8, 8), (8, 2), (14, 2), (16, 1), (20, 1)])
+def test_fp8_attention_gqa_blocks_dtypes(ops, dtype, block_size, H, KVH):
+    from test_ops_gpu import check_attention
+    lens = [700, 33, 16, 15, 129]
+    inp = make_paged_inputs(len(lens), H, KVH, 128, block_size, lens, dtype=dtype, seed=H + KVH + block_size)
+    twin = quantize_paged_inputs_fp8(inp, 1.0, 1.0)
+    o1 = _run_attn(ops, twin, "v1")
+    o2 = _run_attn(ops, twin, "v2")
+    want = _oracle_attn(twin)
+    check_attention(o1, want, dense_attention_fp64(twin))
+    check_attention(o2, want)
+
+
+@pytest.mark.gpu
+def test_fp8_attention_full_size_vs_bf16_cache(ops):
+    """BASELINE shape (bs 32, 1024 tokens, H32/KVH8/D128): the fp8-cache result equals the bf16-cache
+    kernel run on the dequantised values (same kernel arithmetic after conversion) to 2 ulp at row scale."""
+    from test_ops_gpu import rows_close_in_ulp
+    lens = [1024] * 32
+    inp = make_paged_inputs(32, 32, 8, 128, 16, lens, dtype=torch.bfloat16, seed=1)
+    twin = quantize_paged_inputs_fp8(inp, 1.0, 1.0)
+    o8 = _run_attn(ops, twin, "v1")
+    # bf16 cache holding exactly the dequantised values
+    deq = dict(inp)
+    NB, KVH, _, BS, _ = inp["key_cache"].shape
+    kd = twin["key_cache"].permute(0, 1, 3, 2, 4).reshape(NB, KVH, BS, 128).view(torch.float8_e4m3fn).to(torch.bfloat16)
+    deq["key_cache"] = kd.view(NB, KVH, BS, 16, 8).permute(0, 1, 3, 2, 4).contiguous()
+    deq["value_cache"] = twin["value_cache"].view(torch.float8_e4m3fn).to(torch.bfloat16)
+    q = deq["query"].to(DEV)
+    o16 = torch.zeros_like(q)
+    ops.paged_attention_v1(o16, q, deq["key_cache"].to(DEV), deq["value_cache"].to(DEV), 8, inp["scale"],
+                           inp["block_tables"].to(DEV), inp["seq_lens"].to(DEV), 16, 1024, None, "auto", 1.0, 1.0)
+    torch.cuda.synchronize()
+    assert rows_close_in_ulp(o8, o16.cpu(), 2)
+
+
+@pytest.mark.gpu
+def test_fp8_argument_errors(ops):
+    inp = make_paged_inputs(1, 4, 2, 128, 16, [20], dtype=torch.bfloat16)
+    q = inp["query"].to(DEV)
+    out = torch.zeros_like(q)
+    kc, vc = inp["key_cache"].to(DEV), inp["value_cache"].to(DEV)
+    with pytest.raises(RuntimeError, match="one-byte"):
+        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, inp["block_tables"].to(DEV), inp["seq_lens"].to(DEV), 16, 20,
+                               None, "fp8", 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, inp["block_tables"].to(DEV), inp["seq_lens"].to(DEV), 16, 20,
+                               None, "fp8_e5m2", 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="'auto' needs a cache of dtype"):
+        ops.paged_attention_v1(out, q, kc.view(torch.uint8), vc.view(torch.uint8), 2, 1.0,
+                               inp["block_tables"].to(DEV), inp["seq_lens"].to(DEV), 16, 20, None, "auto", 1.0, 1.0)
