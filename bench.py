@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
+                    help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
     ap.add_argument("--on-the-fly", type=int, default=2,
                     help="steps in flight with async scheduling (reference default: 2)")
     ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
@@ -85,6 +87,8 @@ def kernel_leg(engine, B, iters):
     ml = torch.empty_like(es)
     caches = [PagedAttention.split_kv_cache(kv, KVH, D) for kv in engine.worker.cache_engine.gpu_cache]
     dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[cfg.dtype]
+    kv_fp8 = engine.cache_config.cache_dtype != "auto"  # strides below are in cache elements
+    assert caches[0][0].element_size() == (1 if kv_fp8 else q.element_size())
     vp = ctypes.c_void_p
 
     def launch(i, phases):
@@ -95,7 +99,8 @@ def kernel_leg(engine, B, iters):
                 ctypes.c_int(KVH), ctypes.c_float(D ** -0.5), vp(bt.data_ptr()), vp(sl.data_ptr()),
                 ctypes.c_int(BS), ctypes.c_int(max_len), ctypes.c_int(width), ctypes.c_int(P), vp(0),
                 ctypes.c_int64(q.stride(0)), ctypes.c_int64(kc.stride(0)), ctypes.c_int64(kc.stride(1)),
-                ctypes.c_int(dt), ctypes.c_int(0), ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_int(0),
+                ctypes.c_int(dt), ctypes.c_int(1 if kv_fp8 else 0), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                ctypes.c_int(0),
                 ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(64), ctypes.c_int(0), ctypes.c_int(phases),
                 vp(stream))
         assert rc == 0, lib.lvllm_last_error()
@@ -112,7 +117,8 @@ def kernel_leg(engine, B, iters):
     ts = [a.elapsed_time(b) * 1e-3 for a, b in evs]  # seconds
     avg = sum(ts) / len(ts)
     esz = 2
-    algo_bytes = 2 * sum(lens) * KVH * D * esz + 2 * len(seqs) * H * D * esz + len(seqs) * width * 4 + len(seqs) * 4
+    algo_bytes = (2 * sum(lens) * KVH * D * (1 if kv_fp8 else esz) + 2 * len(seqs) * H * D * esz +
+                  len(seqs) * width * 4 + len(seqs) * 4)
     return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P)
 
 
@@ -189,7 +195,7 @@ def main():
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
     blocks = n_req * ((max_len + bs - 1) // bs + 1) + 64
-    engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0),
+    engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype),
                        SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
                                        max_model_len=max_model_len, scheduling=a.scheduling,
                                        max_num_on_the_fly=on_the_fly),

@@ -349,7 +349,8 @@ class PagedAttnImpl:
         """With a cache: one launch of the HIP varlen kernel over the paged cache (the chunk's own
         K/V were written just before).  Without one (the memory-profiling run, kv_cache None,
         flash_attn.py:518-536): torch SDPA on the dense prompt."""
-        if (self.use_hip_prefill and key_cache is not None and q.dtype in (torch.float16, torch.bfloat16)
+        if (self.use_hip_prefill and key_cache is not None and self.kv_cache_dtype == "auto"
+                and q.dtype in (torch.float16, torch.bfloat16)
                 and value_cache.shape[3] in (16, 32) and meta.block_tables.numel() > 0
                 and self.sliding_window is None):
             alibi = self.alibi_slopes
@@ -378,6 +379,9 @@ class PagedAttnImpl:
                 off = pos % bs
                 kc = key_cache[blk, :, :, off, :].reshape(ctx, self.num_kv_heads, self.head_size)
                 vc = value_cache[blk, :, :, off]
+                if kc.dtype != q.dtype:  # fp8 cache (k_scale = v_scale = 1): dequantise the gathered context
+                    kc = kc.view(torch.float8_e4m3fn).to(q.dtype)
+                    vc = vc.view(torch.float8_e4m3fn).to(q.dtype)
                 ki = torch.cat([kc, ki], dim=0)
                 vi = torch.cat([vc, vi], dim=0)
             ki = ki.transpose(0, 1).repeat_interleave(G, dim=0)  # [H, ctx+qlen, D]

@@ -348,6 +348,8 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
                                 const torch::Tensor& slot_mapping) {
   LV_CHECK_DEVICE(query);
   TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
+  if (key_cache.scalar_type() != query.scalar_type() || value_cache.scalar_type() != query.scalar_type())
+    return false;  // quantised cache: outside the fused kernel's envelope
   const int64_t num_tokens = query.numel() / query.size(-1);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
   const int rc = lvllm_rotary_embedding_and_cache(

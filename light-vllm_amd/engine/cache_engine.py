@@ -26,8 +26,9 @@ class CacheEngine:
         self.block_size = cache_config.block_size
         self.num_gpu_blocks = cache_config.num_gpu_blocks
         self.num_cpu_blocks = cache_config.num_cpu_blocks or 0
-        assert cache_config.cache_dtype == "auto", "fp8 KV cache is not part of this round"
-        self.dtype = model_config.dtype
+        # cache_engine.py:33-36 of the reference: "auto" = the model's dtype, fp8 = one byte per
+        # element (OCP e4m3fn on gfx950; the byte tensor is what the kernels take)
+        self.dtype = self.kv_cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
         self.gpu_cache = self._allocate_kv_cache(self.num_gpu_blocks, self.device)
         self.cpu_cache = self._allocate_kv_cache(self.num_cpu_blocks, torch.device("cpu"))
 
@@ -50,7 +51,16 @@ class CacheEngine:
         self.attn_backend.copy_blocks(self.gpu_cache, src_to_dsts)
 
     @staticmethod
+    def kv_cache_torch_dtype(cache_dtype: str, model_dtype: torch.dtype) -> torch.dtype:
+        if cache_dtype == "auto":
+            return model_dtype
+        if cache_dtype in ("fp8", "fp8_e4m3"):
+            return torch.uint8
+        raise ValueError(f"Unsupported data type of kv cache: {cache_dtype}")
+
+    @staticmethod
     def get_cache_block_size(cache_config: CacheConfig, model_config: ModelConfig) -> int:
         per_layer = cache_config.block_size * model_config.num_key_value_heads * model_config.head_dim
         total = model_config.num_hidden_layers * 2 * per_layer
-        return total * torch.tensor([], dtype=model_config.dtype).element_size()
+        dtype = CacheEngine.kv_cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
+        return total * torch.tensor([], dtype=dtype).element_size()

@@ -347,7 +347,7 @@ class LLMEngine:
                 n = min(8192, T - s0)
                 k = (torch.randn(n, cfg.num_key_value_heads, cfg.head_dim, generator=gen, device=self.device) * 0.5).to(cfg.dtype)
                 v = (torch.randn(n, cfg.num_key_value_heads, cfg.head_dim, generator=gen, device=self.device) * 0.5).to(cfg.dtype)
-                ops.reshape_and_cache(k, v, kc, vc, slots[s0:s0 + n], "auto", 1.0, 1.0)
+                ops.reshape_and_cache(k, v, kc, vc, slots[s0:s0 + n], self.cache_config.cache_dtype, 1.0, 1.0)
         for g in admitted:
             seq = g.seqs[0]
             seq.data.update_num_computed_tokens(seq.get_len())

@@ -51,12 +51,14 @@ def dense_reference_logits(model, token_ids):
     return rms(res, model.final_norm) @ model.lm_head.w.float().T
 
 
-def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048):
+def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048,
+                cache_dtype="auto"):
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
     cfg = ModelConfig.tiny()
-    return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32),
+    return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32,
+                                      cache_dtype=cache_dtype),
                      SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=512,
                                      scheduling=scheduling, max_num_on_the_fly=2,
                                      chunked_prefill_enabled=chunked),
@@ -183,3 +185,24 @@ def test_hip_prefill_agrees_with_sdpa_prefill():
     for k in la:
         x, y = la[k][0], lb[k][0]
         assert torch.allclose(x, y, atol=1e-2 * y.abs().max().item() + 1e-3, rtol=1e-2)
+
+
+def test_fp8_kv_cache_engine_tracks_the_bf16_run():
+    """kv_cache_dtype="fp8": the cache holds e4m3 bytes (half the block bytes), decode reads them
+    through the fp8 attention kernel, graph and eager agree exactly, and the first decode logits
+    stay close to the dense fp32 forward (e4m3 keeps 3 mantissa bits of K and V: looser bar)."""
+    from light_vllm_amd.engine.cache_engine import CacheEngine
+    e = make_engine(graph=False, cache_dtype="fp8")
+    assert e.worker.cache_engine.gpu_cache[0].dtype == torch.uint8
+    assert CacheEngine.get_cache_block_size(e.cache_config, e.model_config) * 2 == \
+        CacheEngine.get_cache_block_size(make_engine(graph=False).cache_config, e.model_config)
+    ps, logits, toks, _ = collect_logits(e, max_tokens=3)
+    for i, p in enumerate(ps):
+        ref = dense_reference_logits(e.worker.model, p + toks[str(i)])
+        for j, row in enumerate(logits[str(i)]):
+            want = ref[len(p) - 1 + j].cpu()
+            scale = want.abs().max().item()
+            assert float((row - want).abs().max()) <= 0.08 * scale + 1e-3, (i, j)
+    eager = run_to_completion(make_engine(graph=False, cache_dtype="fp8"))
+    graph = run_to_completion(make_engine(graph=True, cache_dtype="fp8"))
+    assert eager == graph

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ncaches", type=int, default=10)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--kv", default="auto", choices=["auto", "fp8"])
     a = ap.parse_args()
     dev = "cuda:0"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
@@ -31,8 +32,12 @@ def main():
     torch.manual_seed(0)
     caches = []
     for i in range(a.ncaches):
-        kc = (torch.randn(NB, KVH, D // 8, BS, 8, device=dev) * 0.5).to(dt)
-        vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(dt)
+        if a.kv == "fp8":
+            kc = (torch.randn(NB, KVH, D // 16, BS, 16, device=dev) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
+            vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
+        else:
+            kc = (torch.randn(NB, KVH, D // 8, BS, 8, device=dev) * 0.5).to(dt)
+            vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(dt)
         bt = torch.randperm(NB, device=dev)[: B * nblk].view(B, nblk).to(torch.int32)
         caches.append((kc, vc, bt))
     q = (torch.randn(B, H, D, device=dev) * 0.5).to(dt)
@@ -43,15 +48,16 @@ def main():
     es = torch.zeros(B, H, P, dtype=torch.float32, device=dev)
     ml = torch.zeros_like(es)
     scale = 1 / math.sqrt(D)
-    algo_bytes = 2 * B * L * KVH * D * 2 + 2 * B * H * D * 2 + B * nblk * 4 + B * 4
+    kvb = 1 if a.kv == "fp8" else 2
+    algo_bytes = 2 * B * L * KVH * D * kvb + 2 * B * H * D * 2 + B * nblk * 4 + B * 4
 
     def v1(i):
         kc, vc, bt = caches[i % a.ncaches]
-        ops.paged_attention_v1(out, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, "auto", 1.0, 1.0)
+        ops.paged_attention_v1(out, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, a.kv, 1.0, 1.0)
 
     def v2(i):
         kc, vc, bt = caches[i % a.ncaches]
-        ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, "auto", 1.0, 1.0)
+        ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, a.kv, 1.0, 1.0)
 
     for name, fn in (("v1", v1), ("v2", v2)):
         for i in range(20):
