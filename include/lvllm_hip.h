@@ -36,7 +36,11 @@ enum lvllm_dtype {
 };
 
 /* kv_cache_dtype strings of the reference ("auto" | "fp8" | "fp8_e4m3"),
- * csrc/quantization/fp8/amd/quant_utils.cuh:547-573 */
+ * csrc/quantization/fp8/amd/quant_utils.cuh:547-573.  FP8_E4M3 = OCP e4m3fn bytes (the format of
+ * the reference's NVIDIA path and of gfx950's conversion instructions), caches with x = 16, strides
+ * in bytes; accepted by reshape_and_cache and paged_attention_v1/v2 (16-bit queries, block size
+ * 16 | 32, head size % 16 == 0), a stored element is fp8(float(x) / scale), a read one
+ * T(float(fp8) * scale) (fp8/nvidia/quant_utils.cuh:295-300,458-489). */
 enum lvllm_kv_dtype {
   LVLLM_KV_AUTO = 0,
   LVLLM_KV_FP8_E4M3 = 1,

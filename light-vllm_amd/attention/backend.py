@@ -8,9 +8,9 @@ The reference's decoding selector can only return its flash-attn backend
 kernels -- and whose Metadata / Builder carry the same fields as the flash backend's
 (flash_attn.py:76-365) so the engine's input builder and executors are unchanged.
 
-Prompt (prefill) attention is computed with torch SDPA over the un-paged q/k/v (or over
-K/V gathered from the paged cache when a prefix is already cached): prefill kernels are the
-"next" row of SURVEY.md §8f, outside this round's hot path.
+Prompt (prefill, chunked prefill, prefix hits) attention runs the HIP varlen kernel over the
+paged cache (`PagedAttention.forward_prefix` -> lvllm_paged_prefill_attention); torch SDPA remains
+for the memory-profiling run without a cache, sliding windows and fp8 caches.
 """
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple, Type
