@@ -248,6 +248,14 @@ int lvllm_varlen_attention(
     int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t out_stride, int dtype,
     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* advance_step: csrc/prepare_inputs/advance_step.cu:14-57, torch_bindings.cpp:75-77.  Moves the
+ * first num_queries rows of a decode batch one token forward on the device (tokens <- sampled
+ * ids, seq_lens += 1, positions, slot_mapping through block_tables [num_seqs, stride] int32). */
+int lvllm_advance_step(int num_seqs, int num_queries, int block_size, int64_t* input_tokens,
+                       const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
+                       int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                       void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

@@ -98,6 +98,14 @@ def varlen_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, 
                                       alibi_slopes, sliding_window, softcap, workspace)
 
 
+def advance_step(num_seqs: int, num_queries: int, block_size: int, input_tokens: torch.Tensor,
+                 sampled_token_ids: torch.Tensor, input_positions: torch.Tensor, seq_lens: torch.Tensor,
+                 slot_mapping: torch.Tensor, block_tables: torch.Tensor) -> None:
+    """Advance a decode batch's input tensors one token on the device (_custom_ops.py:167-178)."""
+    return _C.advance_step(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids,
+                           input_positions, seq_lens, slot_mapping, block_tables)
+
+
 def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
                      cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
     _C.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)

@@ -32,6 +32,7 @@ HIP_SOURCES = [
     "attention_f16.hip",
     "skinny_gemm.hip",
     "prefill_attention.hip",
+    "prepare_inputs.hip",
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

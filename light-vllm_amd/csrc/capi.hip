@@ -11,6 +11,7 @@ Tuning& tuning() {
     Tuning v;
     if (const char* e = getenv("LVLLM_GEMM_CUS")) v.gemm_workgroups = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
+    if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     return v;
   }();
   return t;
@@ -27,6 +28,8 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
+  } else if (k == "prefill_lds") {
+    lvllm::tuning().prefill_lds = value != 0;
   } else {
     LV_CHECK(false, "unknown tuning key '" + k + "'");
   }

@@ -21,9 +21,11 @@ void set_error(const std::string& msg);
 //                    that keeps two steps in flight on two streams sets 128: each GEMM then
 //                    leaves half the CUs to the other stream's kernel, +10 % tokens/s measured)
 //   attn_waves       waves per workgroup of the long-context decode attention (8 or 4)
+//   prefill_lds      1 | 0, see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
   int attn_waves = 8;
+  int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
 };
 Tuning& tuning();
 

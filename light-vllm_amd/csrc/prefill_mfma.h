@@ -33,6 +33,9 @@
 #ifndef LVLLM_PREFILL_EXP
 #define LVLLM_PREFILL_EXP 0
 #endif
+#ifndef LVLLM_PREFILL_STAGES
+#define LVLLM_PREFILL_STAGES 3  // LDS stages of the LDSKV variant: copies run STAGES-1 pairs ahead
+#endif
 #ifndef LVLLM_PREFILL_SCHED
 #define LVLLM_PREFILL_SCHED 1
 #endif
@@ -61,7 +64,11 @@ struct PrefillParams {
 // GP = 1 << gp_shift = the GQA group size rounded up to a power of two (<= 16).
 // EXTRAS = ALiBi / soft cap / sliding window present (every tile is masked and biased per element);
 // the plain causal instantiation masks only the tiles that straddle the diagonal.
-template <typename T, int D, int BS, int NB, bool EXTRAS>
+// LDSKV = the K/V tiles of a pair are staged ONCE per workgroup in LDS (direct-to-LDS buffer loads,
+// double buffered, one barrier per pair) and every wave reads its MFMA operands from there: a
+// quarter of the global-load instructions and of the L1 traffic of the register path, whose
+// per-wave K/V loads cost 45 % of its time.  Needs D % 32 == 0.
+template <typename T, int D, int BS, int NB, bool EXTRAS, bool LDSKV>
 __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const PrefillParams p) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
@@ -95,14 +102,20 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
   const int seq_len = p.seq_lens != nullptr ? p.seq_lens[seq] : qlen;  // no cache: the chunk is the context
   const int ctx = seq_len - qlen;
   const int t_first = qtile * TQWG + wave * TQW;  // first query token (inside the chunk) of this wave
-  if (t_first >= qlen || ctx < 0) return;
-  const int nq = min(TQW, qlen - t_first);        // live query tokens of this wave
+  if (qtile * TQWG >= qlen || ctx < 0) return;    // the whole workgroup is past the chunk
+  // (with LDSKV a wave past the end of the chunk stays: it still loads its share of every pair)
+  if (!LDSKV && t_first >= qlen) return;
+  const int nq = max(0, min(TQW, qlen - t_first));  // live query tokens of this wave
 
-  // keys this wave needs: [klo, khi)
-  const int khi = p.causal ? ctx + t_first + nq : seq_len;  // causal: last query's position + 1
-  const int klo = p.sliding_window > 0 ? max(0, ctx + t_first - p.sliding_window + 1) : 0;
+  // keys this wave needs: [klo, khi); LDSKV: the tile walk is the workgroup's (first wave's
+  // window start .. last live query), a wave computes only the pairs its own queries can see
+  const int khi = nq == 0 ? 0 : (p.causal ? ctx + t_first + nq : seq_len);
+  const int wg_first = LDSKV ? qtile * TQWG : t_first;
+  const int klo = p.sliding_window > 0 ? max(0, ctx + wg_first - p.sliding_window + 1) : 0;
   const int tile0 = klo >> 4;
-  const int ntiles = ((khi + 15) >> 4) - tile0;
+  const int khi_walk = !LDSKV ? khi : (p.causal ? ctx + min(qlen, (qtile + 1) * TQWG) : seq_len);
+  const int ntiles = ((khi_walk + 15) >> 4) - tile0;  // tiles loaded
+  const int my_npairs = khi > (tile0 << 4) ? (khi - (tile0 << 4) + 31) >> 5 : 0;  // pairs computed
 
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
@@ -144,9 +157,15 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
   // owns blocks cu_seqlens[s] / BS + s ..., which never overlap (prefill_attention.hip)
   const bool arithmetic_blocks = p.block_tables == nullptr;
   const int first_block = qbeg / BS + seq;
+  // The table is read through the CONSTANT address space: that keeps the loads scalar (s_load,
+  // lgkmcnt) also after the LDS copies and barriers of the LDSKV loop, which the compiler takes
+  // for stores that might alias -- as vector loads they came with an s_waitcnt vmcnt(0) that
+  // drained the copy pipeline every pair.
+  typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
+  const const_i32_ptr block_table_c = (const_i32_ptr)(uintptr_t)block_table;
   auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
     const int blk = min(((tile0 + j) << 4) / BS, last_block);
-    return arithmetic_blocks ? first_block + blk : block_table[blk];
+    return arithmetic_blocks ? first_block + blk : block_table_c[blk];
   };
 
   float m_run[NB], l_run[NB];
@@ -195,6 +214,61 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
       }
     }
   };
+  // ---- LDSKV: stage layout [K tile A | K tile B | V tile A | V tile B], each tile compact:
+  // K [D/8][16 tok][16 B] (= the MFMA A-operand order: slice j of lane l at j*1024 + l*16),
+  // V [D][16 tok][2 B] (piece of lane (g, c), d-tile t at t*512 + c*32 + g*8).
+  constexpr int kTile = D * 32;            // bytes of one K (or V) tile
+  constexpr int kStage = 4 * kTile;
+  constexpr int kStages = LVLLM_PREFILL_STAGES;
+  constexpr int kLoadsPerTile = kTile / 1024;  // wave loads of 16 bytes per lane
+  extern __shared__ __attribute__((aligned(16))) char kv_lds[];
+  // wave w copies one of the four tiles of every pair: K/V = w >> 1, tile A/B = w & 1
+  const int ld_kind = wave >> 1, ld_tsel = wave & 1;
+  auto issue_pair_loads = [&](const int jp, const int bn32) __attribute__((always_inline)) {
+    const int j = 2 * jp + ld_tsel;
+    const int tok_off = (BS == 32) ? (((tile0 + j) << 4) & 16) : 0;
+    __amdgpu_buffer_rsrc_t r = tile_rsrc(ld_kind ? vbytes : kbytes, j, bn32);
+    // lane's 16-byte chunk q = i*64 + lane of the compact tile, in the paged block:
+    //   K chunk (d8 = q / 16, tok = q % 16) at (d8 * BS + tok_off + tok) * 16
+    //   V chunk (d = q / 2, half = q % 2)    at (d * BS + tok_off + 8 * half) * 2
+    int voffset, step, soff0;
+    if (BS == 16) {
+      voffset = lane * 16;
+      step = 1024;
+      soff0 = 0;
+    } else if (ld_kind == 0) {
+      voffset = (lane >> 4) * (BS * 16) + (lane & 15) * 16;
+      step = 4 * BS * 16;
+      soff0 = tok_off * 16;
+    } else {
+      voffset = (lane >> 1) * (BS * 2) + (lane & 1) * 16;
+      step = 32 * BS * 2;
+      soff0 = tok_off * 2;
+    }
+    char* dst = kv_lds + (jp % kStages) * kStage + (2 * ld_kind + ld_tsel) * kTile;
+#pragma unroll
+    for (int i = 0; i < kLoadsPerTile; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               voffset, soff0 + i * step, 0, 0);
+  };
+  auto read_pair_k = [&](u32x4_t (&ka)[NS], u32x4_t (&kb)[NS], const int jp) __attribute__((always_inline)) {
+    const char* st = kv_lds + (jp % kStages) * kStage + lane * 16;
+#pragma unroll
+    for (int jj = 0; jj < NS; ++jj) {
+      ka[jj] = *reinterpret_cast<const u32x4_t*>(st + jj * 1024);
+      kb[jj] = *reinterpret_cast<const u32x4_t*>(st + kTile + jj * 1024);
+    }
+  };
+  auto read_pair_v = [&](u32x4_t (&v)[NDT], const int jp) __attribute__((always_inline)) {
+    const char* st = kv_lds + (jp % kStages) * kStage + 2 * kTile + c * 32 + g * 8;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      const u32x2_t a = *reinterpret_cast<const u32x2_t*>(st + t * 512);
+      const u32x2_t b = *reinterpret_cast<const u32x2_t*>(st + kTile + t * 512);
+      v[t] = u32x4_t{a.x, a.y, b.x, b.y};
+    }
+  };
+
   // butterfly max over the 4 lane groups g (rows of 16 lanes) without LDS: the gfx950 row swaps.
   // (inline asm: hipcc folds the builtin form of swap(x, x) + max away.)
   auto group_max = [&](float x) __attribute__((always_inline)) -> float {
@@ -234,20 +308,27 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 
   u32x4_t kA[NS], kB[NS];
   u32x4_t vv[NDT];
-  {
-    const int bnA = block_number(0), bnB = block_number(1);
+  int bnA = 0, bnB = 0;
+  if constexpr (!LDSKV) {
+    bnA = block_number(0);
+    bnB = block_number(1);
     load_k(kA, 0, bnA);
     load_k(kB, 1, bnB);
     load_v(vv, 0, 0, bnA);
     load_v(vv, 1, 1, bnB);
+    bnA = block_number(2);
+    bnB = block_number(3);
   }
-  int bnA = block_number(2), bnB = block_number(3);
   // One pair.  MASKED is a compile-time tag: the pairs wholly at or before the wave's first query
   // (all but the last one or two) run a copy of the body with no mask and no branch but the rescale.
   auto pair_step = [&](const int jp, auto masked_tag) __attribute__((always_inline)) {
     constexpr bool need_mask = decltype(masked_tag)::value;
     const int j = 2 * jp;
     const int base = (tile0 + j) << 4;
+    if constexpr (LDSKV) {
+      read_pair_k(kA, kB, jp);
+      read_pair_v(vv, jp);
+    }
     if constexpr (need_mask) {
       zero_tail(vv, 0, base);
       zero_tail(vv, 1, base + 16);
@@ -264,8 +345,10 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
       for (int jj = 0; jj < NS; ++jj) sB[b] = mfma_qk<T>(kB[jj], qf[b][jj], sB[b]);
     }
 #if LVLLM_PREFILL_EXP < 2  // diagnosis builds: 1 = no V stream, 2 = no K stream either (wrong results)
-    load_k(kA, j + 2, bnA);
-    load_k(kB, j + 3, bnB);
+    if constexpr (!LDSKV) {
+      load_k(kA, j + 2, bnA);
+      load_k(kB, j + 3, bnB);
+    }
 #endif
     // (1) logits, masks and the new running max of every column block
     float y[NB][8];
@@ -354,19 +437,46 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const Prefil
 #endif
 #pragma unroll
     for (int t = 0; t < NDT; ++t) acc[NB - 1][t] = mfma_qk<T>(vv[t], pb, acc[NB - 1][t]);
+    if constexpr (!LDSKV) {
 #if LVLLM_PREFILL_EXP < 1
-    load_v(vv, 0, j + 2, bnA);
-    load_v(vv, 1, j + 3, bnB);
+      load_v(vv, 0, j + 2, bnA);
+      load_v(vv, 1, j + 3, bnB);
 #endif
-    bnA = block_number(j + 4);
-    bnB = block_number(j + 5);
+      bnA = block_number(j + 4);
+      bnB = block_number(j + 5);
+    }
   };
   {
     // pairs whose last key (base + 31) is at or before the wave's first query need no mask
-    const int n_plain = EXTRAS ? 0 : min(npairs, max(0, (q_first_pos + 1 - (tile0 << 4)) >> 5));
-    int jp = 0;
-    for (; jp < n_plain; ++jp) pair_step(jp, std::false_type{});
-    for (; jp < npairs; ++jp) pair_step(jp, std::true_type{});
+    const int n_plain = EXTRAS ? 0 : min(my_npairs, max(0, (q_first_pos + 1 - (tile0 << 4)) >> 5));
+    if constexpr (!LDSKV) {
+      int jp = 0;
+      for (; jp < n_plain; ++jp) pair_step(jp, std::false_type{});
+      for (; jp < npairs; ++jp) pair_step(jp, std::true_type{});
+    } else {
+      // the stages start as zeros: a tile past the walk is never loaded (zero-size descriptor)
+      // and must still read as finite numbers
+      for (int i = threadIdx.x; i < kStages * kStage / 16; i += 256)
+        reinterpret_cast<u32x4_t*>(kv_lds)[i] = u32x4_t{0, 0, 0, 0};
+      __syncthreads();
+      // copies run kStages-1 pairs ahead of the multiplies (every pair is issued, valid or not,
+      // so that the number of loads in flight is a compile-time constant)
+#pragma unroll
+      for (int a = 0; a < kStages - 1; ++a) issue_pair_loads(a, block_number(2 * a + ld_tsel));
+      int bn = block_number(2 * (kStages - 1) + ld_tsel);
+      // s_waitcnt vmcnt(N) lgkmcnt(0): all but this wave's N youngest copies have landed
+      constexpr int kInFlight = (kStages - 2) * kLoadsPerTile;
+      constexpr int kWait = (kInFlight & 15) | (7 << 4) | (0 << 8) | ((kInFlight >> 4) << 14);
+      for (int jp = 0; jp < npairs; ++jp) {
+        __builtin_amdgcn_s_waitcnt(kWait);  // this wave's copies of pair jp are in LDS ...
+        __builtin_amdgcn_s_barrier();       // ... and everybody's; everybody is done reading pair jp-1
+        issue_pair_loads(jp + kStages - 1, bn);  // into the stage pair jp-1 used
+        bn = block_number(2 * (jp + kStages) + ld_tsel);
+        if (jp < n_plain) pair_step(jp, std::false_type{});
+        else if (jp < my_npairs) pair_step(jp, std::true_type{});
+      }
+      __builtin_amdgcn_s_waitcnt(0);  // no copy may still be landing when the workgroup's LDS is released
+    }
   }
 
   // ---- normalise and store: lane (g, c) holds d = 16t + 4g .. +3 of its column ----
@@ -407,12 +517,24 @@ static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_quer
   const int tqwg = 4 * NB * (16 >> p.gp_shift);
   const int qtiles = (max_query_len + tqwg - 1) / tqwg;
   const bool extras = p.alibi_slopes != nullptr || p.softcap > 0.f || p.sliding_window > 0;
+  const dim3 grid(p.num_kv_heads * HG, num_seqs, qtiles);
+  if constexpr (D % 32 == 0) {
+    if (tuning().prefill_lds) {
+      constexpr size_t smem = (size_t)LVLLM_PREFILL_STAGES * 4 * D * 32;  // stages of [K A | K B | V A | V B]
+      auto launch = [&](auto kern) {
+        if (smem > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+      };
+      if (extras) launch(paged_prefill_mfma_kernel<T, D, BS, NB, true, true>);
+      else launch(paged_prefill_mfma_kernel<T, D, BS, NB, false, true>);
+      return 0;
+    }
+  }
   if (extras)
-    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, true>),
-                       dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, true, false>), grid, dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, false>),
-                       dim3(p.num_kv_heads * HG, num_seqs, qtiles), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, false, false>), grid, dim3(256), 0, stream, p);
   return 0;
 }
 

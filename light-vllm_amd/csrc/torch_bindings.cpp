@@ -427,6 +427,30 @@ void varlen_attention(torch::Tensor& out, const torch::Tensor& query, const torc
                                (int64_t)workspace.nbytes(), current_stream(query)));
 }
 
+// csrc/prepare_inputs/advance_step.cu:59-125: same argument checks (verify_tensor)
+void advance_step(int64_t num_seqs, int64_t num_queries, int64_t block_size, torch::Tensor& input_tokens,
+                  torch::Tensor& sampled_token_ids, torch::Tensor& input_positions, torch::Tensor& seq_lens,
+                  torch::Tensor& slot_mapping, torch::Tensor& block_tables) {
+  auto verify = [](const char* name, const torch::Tensor& t, int64_t size_0, int64_t size_1, c10::ScalarType type) {
+    const bool ok = (size_0 == -1 || t.size(0) == size_0) && (size_1 == -1 || (t.dim() > 1 && t.size(1) == size_1)) &&
+                    t.is_contiguous() && t.scalar_type() == type && t.is_cuda();
+    TORCH_CHECK(ok, "tensor: name = ", name, ", shape = ", t.sizes(), " is_cont = ", t.is_contiguous(),
+                ", type = ", t.dtype(), " is not as expected: shape = [", size_0, ", ", size_1, "], type = ", type);
+  };
+  verify("input_tokens", input_tokens, num_seqs, -1, at::kLong);
+  verify("sampled_token_ids", sampled_token_ids, num_queries, 1, at::kLong);
+  verify("input_positions", input_positions, num_seqs, -1, at::kLong);
+  verify("seq_lens", seq_lens, num_seqs, -1, at::kInt);
+  verify("slot_mapping", slot_mapping, num_seqs, -1, at::kLong);
+  verify("block_tables", block_tables, num_seqs, -1, at::kInt);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(sampled_token_ids));
+  check(lvllm_advance_step((int)num_seqs, (int)num_queries, (int)block_size, input_tokens.data_ptr<int64_t>(),
+                           sampled_token_ids.data_ptr<int64_t>(), input_positions.data_ptr<int64_t>(),
+                           seq_lens.data_ptr<int32_t>(), slot_mapping.data_ptr<int64_t>(),
+                           block_tables.data_ptr<int32_t>(), block_tables.stride(0),
+                           current_stream(sampled_token_ids)));
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -472,6 +496,12 @@ TORCH_LIBRARY(_C, ops) {
       "    int blocksparse_vert_stride, int blocksparse_block_size,"
       "    int blocksparse_head_sliding_step) -> ()");
   ops.impl("paged_attention_v2", torch::kCUDA, &paged_attention_v2);
+
+  // prepare_inputs advance_step (torch_bindings.cpp:75-77 of the reference, schema inferred there)
+  ops.def("advance_step(int num_seqs, int num_queries, int block_size, Tensor! input_tokens, "
+          "Tensor sampled_token_ids, Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, "
+          "Tensor block_tables) -> ()");
+  ops.impl("advance_step", torch::kCUDA, &advance_step);
 
   ops.def("silu_and_mul(Tensor! out, Tensor input) -> ()");
   ops.impl("silu_and_mul", torch::kCUDA, &silu_and_mul);

@@ -130,6 +130,14 @@ def e4m3_to_f32(v: int) -> float:
     return float(lib().oracle_e4m3_to_f32(ctypes.c_uint8(v)))
 
 
+def advance_step(num_queries, block_size, input_tokens, sampled_token_ids, input_positions, seq_lens,
+                 slot_mapping, block_tables):
+    assert input_tokens.dtype == torch.int64 and seq_lens.dtype == torch.int32 and block_tables.dtype == torch.int32
+    lib().oracle_advance_step(_i(num_queries), _i(block_size), _p(input_tokens), _p(sampled_token_ids),
+                              _p(input_positions), _p(seq_lens), _p(slot_mapping), _p(block_tables),
+                              _l(block_tables.stride(0)))
+
+
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):
     assert slot_mapping.dtype == torch.int64
     lib().oracle_reshape_and_cache(

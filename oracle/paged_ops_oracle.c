@@ -531,6 +531,22 @@ void oracle_reshape_and_cache_fp8(const void* key, const void* value, uint8_t* k
   }
 }
 
+/* advance_step: csrc/prepare_inputs/advance_step.cu:14-57 (rows 0 .. num_queries-1) */
+void oracle_advance_step(int num_queries, int block_size, int64_t* input_tokens,
+                         const int64_t* sampled_token_ids, int64_t* input_positions,
+                         int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables,
+                         int64_t block_tables_stride) {
+  for (int i = 0; i < num_queries; ++i) {
+    input_tokens[i] = sampled_token_ids[i];
+    const int next_seq_len = seq_lens[i] + 1;
+    const int next_input_pos = next_seq_len - 1;
+    seq_lens[i] = next_seq_len;
+    input_positions[i] = next_input_pos;
+    const int32_t* row = block_tables + block_tables_stride * i;
+    slot_mapping[i] = (int64_t)row[next_input_pos / block_size] * block_size + next_input_pos % block_size;
+  }
+}
+
 /* reshape_and_cache_flash: csrc/cache_kernels.cu:218-246 */
 void oracle_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
                                     void* value_cache, const int64_t* slot_mapping,

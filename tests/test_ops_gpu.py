@@ -441,3 +441,31 @@ def test_full_size_properties(ops):
     d64 = dense_attention_fp64(sinp)
     check_attention(o2[sub], d64.to(torch.bfloat16), d64)
     check_attention(o1[sub], d64.to(torch.bfloat16), d64)
+
+
+# ---------------------------------------------------------------- advance_step (bit-exact)
+@pytest.mark.parametrize("num_seqs,num_queries,block_size", [(1, 1, 16), (37, 37, 16), (300, 290, 32), (8, 0, 8)])
+def test_advance_step_bit_exact(ops, num_seqs, num_queries, block_size):
+    g = torch.Generator().manual_seed(num_seqs)
+    width = 12
+    seq_lens = torch.randint(1, width * block_size - 1, (num_seqs,), generator=g, dtype=torch.int32)
+    block_tables = torch.randint(0, 5000, (num_seqs, width), generator=g, dtype=torch.int32)
+    tokens = torch.randint(0, 1000, (num_seqs,), generator=g)
+    positions = (seq_lens - 1).long()
+    slots = torch.randint(0, 1000, (num_seqs,), generator=g)
+    sampled = torch.randint(0, 128000, (num_queries, 1), generator=g)
+    want = [t.clone() for t in (tokens, positions, seq_lens, slots)]
+    oracle.advance_step(num_queries, block_size, want[0], sampled, want[1], want[2], want[3], block_tables)
+    got = [t.clone().to(DEV) for t in (tokens, positions, seq_lens, slots)]
+    ops.advance_step(num_seqs, num_queries, block_size, got[0], sampled.to(DEV), got[1], got[2], got[3],
+                     block_tables.to(DEV))
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
+    # what the host-side input builder would have produced for the same step
+    for i in range(num_queries):
+        pos = int(seq_lens[i])
+        assert int(want[3][i]) == int(block_tables[i, pos // block_size]) * block_size + pos % block_size
+    with pytest.raises(RuntimeError, match="is not as expected"):
+        ops.advance_step(num_seqs, num_queries, block_size, got[0].int(), sampled.to(DEV), got[1], got[2], got[3],
+                         block_tables.to(DEV))
