@@ -256,6 +256,18 @@ int lvllm_advance_step(int num_seqs, int num_queries, int block_size, int64_t* i
                        int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
                        void* stream);
 
+/* ---- fp8 activation quantisation (csrc/quantization/fp8/common.cu, torch_bindings.cpp:185-202) ----
+ * out: OCP e4m3fn bytes (c10::Float8_e4m3fn).  static: out = fp8(clamp(x * (1/scale), +-448)), scale[1].
+ * dynamic: scale[0] (<= 0 on entry) = max|x| / 448 first, then as static.  per token:
+ * scales[token] = max(min(absmax, *scale_ub) / 448, 1/(448*512)), out = fp8(clamp(x / scale)). */
+int lvllm_static_scaled_fp8_quant(void* out, const void* input, const float* scale, int64_t num_elems,
+                                  int dtype, void* stream);
+int lvllm_dynamic_scaled_fp8_quant(void* out, const void* input, float* scale, int64_t num_elems, int dtype,
+                                   void* stream);
+int lvllm_dynamic_per_token_scaled_fp8_quant(void* out, float* scales, const void* input,
+                                             const float* scale_ub, int num_tokens, int hidden_size,
+                                             int dtype, void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

@@ -98,6 +98,29 @@ def varlen_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, 
                                       alibi_slopes, sliding_window, softcap, workspace)
 
 
+def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                     num_token_padding: Optional[int] = None, scale_ub: Optional[torch.Tensor] = None,
+                     use_per_token_if_dynamic: bool = False):
+    """Quantize `input` [tokens, hidden] to fp8 (e4m3fn) and return (quantized, scale): static when a
+    scale is given, else dynamic per tensor or per token (_custom_ops.py:313-365 of the reference)."""
+    assert input.ndim == 2
+    shape = input.shape
+    if num_token_padding:
+        shape = (max(num_token_padding, input.shape[0]), shape[1])
+    output = torch.empty(shape, device=input.device, dtype=torch.float8_e4m3fn)
+    if scale is None:
+        if use_per_token_if_dynamic:
+            scale = torch.empty((shape[0], 1), device=input.device, dtype=torch.float32)
+            _C.dynamic_per_token_scaled_fp8_quant(output, input, scale, scale_ub)
+        else:
+            scale = torch.zeros(1, device=input.device, dtype=torch.float32)
+            _C.dynamic_scaled_fp8_quant(output, input, scale)
+    else:
+        assert scale.numel() == 1 or num_token_padding is None
+        _C.static_scaled_fp8_quant(output, input, scale)
+    return output, scale
+
+
 def advance_step(num_seqs: int, num_queries: int, block_size: int, input_tokens: torch.Tensor,
                  sampled_token_ids: torch.Tensor, input_positions: torch.Tensor, seq_lens: torch.Tensor,
                  slot_mapping: torch.Tensor, block_tables: torch.Tensor) -> None:

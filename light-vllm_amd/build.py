@@ -33,6 +33,7 @@ HIP_SOURCES = [
     "skinny_gemm.hip",
     "prefill_attention.hip",
     "prepare_inputs.hip",
+    "fp8_quant.hip",
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

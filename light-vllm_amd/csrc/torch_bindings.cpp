@@ -451,6 +451,43 @@ void advance_step(int64_t num_seqs, int64_t num_queries, int64_t block_size, tor
                            current_stream(sampled_token_ids)));
 }
 
+// fp8 activation quantisation, csrc/quantization/fp8/common.cu:226-292
+void check_fp8_out(const torch::Tensor& out, const torch::Tensor& input, const char* op) {
+  LV_CHECK_DEVICE(input);
+  TORCH_CHECK(out.element_size() == 1, op, ": out must be a float8_e4m3fn (one-byte) tensor");
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous(), op, ": input / out must be contiguous");
+}
+
+void static_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor const& scale) {
+  check_fp8_out(out, input, "static_scaled_fp8_quant");
+  TORCH_CHECK(scale.scalar_type() == at::kFloat && scale.is_cuda());
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input));
+  check(lvllm_static_scaled_fp8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(), input.numel(),
+                                      dtype_code(input, "static_scaled_fp8_quant"), current_stream(input)));
+}
+
+void dynamic_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor& scale) {
+  check_fp8_out(out, input, "dynamic_scaled_fp8_quant");
+  TORCH_CHECK(scale.scalar_type() == at::kFloat && scale.is_cuda());
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input));
+  check(lvllm_dynamic_scaled_fp8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(), input.numel(),
+                                       dtype_code(input, "dynamic_scaled_fp8_quant"), current_stream(input)));
+}
+
+void dynamic_per_token_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor& scales,
+                                        std::optional<at::Tensor> const& scale_ub) {
+  check_fp8_out(out, input, "dynamic_per_token_scaled_fp8_quant");
+  TORCH_CHECK(scales.scalar_type() == at::kFloat && scales.is_cuda() && scales.is_contiguous());
+  const int64_t hidden = input.size(-1);
+  const int64_t tokens = input.numel() / hidden;
+  TORCH_CHECK(scales.numel() >= tokens);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input));
+  check(lvllm_dynamic_per_token_scaled_fp8_quant(
+      out.data_ptr(), scales.data_ptr<float>(), input.data_ptr(),
+      scale_ub.has_value() ? scale_ub->data_ptr<float>() : nullptr, (int)tokens, (int)hidden,
+      dtype_code(input, "dynamic_per_token_scaled_fp8_quant"), current_stream(input)));
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -502,6 +539,14 @@ TORCH_LIBRARY(_C, ops) {
           "Tensor sampled_token_ids, Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, "
           "Tensor block_tables) -> ()");
   ops.impl("advance_step", torch::kCUDA, &advance_step);
+
+  // fp8 activation quantisation (torch_bindings.cpp:185-202 of the reference)
+  ops.def("static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()");
+  ops.impl("static_scaled_fp8_quant", torch::kCUDA, &static_scaled_fp8_quant);
+  ops.def("dynamic_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()");
+  ops.impl("dynamic_scaled_fp8_quant", torch::kCUDA, &dynamic_scaled_fp8_quant);
+  ops.def("dynamic_per_token_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale, Tensor? scale_ub) -> ()");
+  ops.impl("dynamic_per_token_scaled_fp8_quant", torch::kCUDA, &dynamic_per_token_scaled_fp8_quant);
 
   ops.def("silu_and_mul(Tensor! out, Tensor input) -> ()");
   ops.impl("silu_and_mul", torch::kCUDA, &silu_and_mul);

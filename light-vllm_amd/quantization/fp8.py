@@ -1,0 +1,48 @@
+"""apply_fp8_linear: light_vllm/backends/quantization/utils/w8a8_utils.py:103-189, the
+`cutlass_fp8_supported=False` branch (torch._scaled_mm), which is the one a ROCm build takes."""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _custom_ops as ops
+
+FP8_MAX = 448.0  # torch.finfo(torch.float8_e4m3fn).max
+
+
+def per_tensor_quantize_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N, K] weight -> (fp8 weight transposed to [K, N] as _scaled_mm wants its second operand,
+    scale [1]); the dynamic per-tensor kernel does the work (fp8.py:196-213 of the reference
+    quantises checkpoint weights the same way at load time)."""
+    q, scale = ops.scaled_fp8_quant(weight.contiguous())
+    return q.t(), scale
+
+
+def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: torch.Tensor,
+                     input_scale: Optional[torch.Tensor] = None, input_scale_ub: Optional[torch.Tensor] = None,
+                     bias: Optional[torch.Tensor] = None, cutlass_fp8_supported: bool = False,
+                     use_per_token_if_dynamic: bool = False) -> torch.Tensor:
+    if cutlass_fp8_supported:
+        raise NotImplementedError("cutlass_scaled_mm is an NVIDIA kernel; use the torch._scaled_mm path")
+    # the input is padded to 17 rows as in the reference (w8a8_utils.py:137-144)
+    qinput, x_scale = ops.scaled_fp8_quant(input, input_scale, num_token_padding=17,
+                                           scale_ub=input_scale_ub if use_per_token_if_dynamic else None,
+                                           use_per_token_if_dynamic=use_per_token_if_dynamic)
+    per_tensor_weights = weight_scale.numel() == 1
+    per_tensor_activations = x_scale.numel() == 1
+    if per_tensor_weights and per_tensor_activations:
+        output = torch._scaled_mm(qinput, weight, out_dtype=input.dtype, scale_a=x_scale, scale_b=weight_scale,
+                                  bias=bias)
+        if isinstance(output, tuple):
+            output = output[0]
+        return torch.narrow(output, 0, 0, input.shape[0])
+    # channelwise weights or per-token activations: C = s_w * s_x * (X W) + bias, unfused
+    one = torch.ones(1, dtype=torch.float32, device=input.device)
+    output = torch._scaled_mm(qinput, weight, out_dtype=torch.float32, scale_a=one, scale_b=one)
+    if isinstance(output, tuple):
+        output = output[0]
+    output = torch.narrow(output, 0, 0, input.shape[0])
+    x_scale = torch.narrow(x_scale, 0, 0, input.shape[0])
+    output = output * x_scale * weight_scale.t()
+    if bias is not None:
+        output = output + bias
+    return output.to(dtype=input.dtype)

@@ -138,6 +138,23 @@ def advance_step(num_queries, block_size, input_tokens, sampled_token_ids, input
                               _l(block_tables.stride(0)))
 
 
+def static_scaled_fp8_quant(out, input, scale):
+    assert out.dtype == torch.uint8 and scale.dtype == torch.float32
+    lib().oracle_static_scaled_fp8_quant(_p(out), _p(input), _p(scale), _l(input.numel()), _i(_DT[input.dtype]))
+
+
+def dynamic_scaled_fp8_quant(out, input, scale):
+    assert out.dtype == torch.uint8 and scale.dtype == torch.float32
+    lib().oracle_dynamic_scaled_fp8_quant(_p(out), _p(input), _p(scale), _l(input.numel()), _i(_DT[input.dtype]))
+
+
+def dynamic_per_token_scaled_fp8_quant(out, scales, input, scale_ub=None):
+    assert out.dtype == torch.uint8 and scales.dtype == torch.float32
+    lib().oracle_dynamic_per_token_scaled_fp8_quant(_p(out), _p(scales), _p(input), _p(scale_ub),
+                                                    _i(input.numel() // input.size(-1)), _i(input.size(-1)),
+                                                    _i(_DT[input.dtype]))
+
+
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping):
     assert slot_mapping.dtype == torch.int64
     lib().oracle_reshape_and_cache(

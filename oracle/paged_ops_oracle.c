@@ -547,6 +547,38 @@ void oracle_advance_step(int num_queries, int block_size, int64_t* input_tokens,
   }
 }
 
+/* fp8 activation quantisation: csrc/quantization/fp8/common.cu:24-38 (conversion: multiply by the
+ * inverted scale or divide, clamp with fmax(-448, fmin(x, 448)) -- so NaN -> +448 -- then round to
+ * nearest even), :46-83 (absmax / 448), :164-224 (per token). */
+static uint8_t fp8_conv(float v, float scale, int inverted) {
+  const float x = inverted ? v * scale : v / scale;
+  const float r = fmaxf(-448.f, fminf(x, 448.f));
+  return f_to_e4m3(r);
+}
+void oracle_static_scaled_fp8_quant(uint8_t* out, const void* input, const float* scale, int64_t n, int dt) {
+  const float inv = 1.0f / scale[0];
+  for (int64_t i = 0; i < n; ++i) out[i] = fp8_conv(ld(input, dt, i), inv, 1);
+}
+void oracle_dynamic_scaled_fp8_quant(uint8_t* out, const void* input, float* scale, int64_t n, int dt) {
+  float m = 0.f;
+  for (int64_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(ld(input, dt, i)));
+  if (m / 448.f > scale[0]) scale[0] = m / 448.f; /* atomic max into a value that starts <= 0 */
+  oracle_static_scaled_fp8_quant(out, input, scale, n, dt);
+}
+void oracle_dynamic_per_token_scaled_fp8_quant(uint8_t* out, float* scales, const void* input,
+                                               const float* scale_ub, int num_tokens, int hidden, int dt) {
+  const float min_scaling_factor = 1.0f / (448.f * 512.f);
+  for (int t = 0; t < num_tokens; ++t) {
+    float m = 0.f;
+    for (int i = 0; i < hidden; ++i) m = fmaxf(m, fabsf(ld(input, dt, (int64_t)t * hidden + i)));
+    if (scale_ub) m = fminf(m, scale_ub[0]);
+    const float s = fmaxf(m / 448.f, min_scaling_factor);
+    scales[t] = s;
+    for (int i = 0; i < hidden; ++i)
+      out[(int64_t)t * hidden + i] = fp8_conv(ld(input, dt, (int64_t)t * hidden + i), s, 0);
+  }
+}
+
 /* reshape_and_cache_flash: csrc/cache_kernels.cu:218-246 */
 void oracle_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
                                     void* value_cache, const int64_t* slot_mapping,

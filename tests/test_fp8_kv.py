@@ -184,3 +184,86 @@ def test_fp8_argument_errors(ops):
     with pytest.raises(RuntimeError, match="'auto' needs a cache of dtype"):
         ops.paged_attention_v1(out, q, kc.view(torch.uint8), vc.view(torch.uint8), 2, 1.0,
                                inp["block_tables"].to(DEV), inp["seq_lens"].to(DEV), 16, 20, None, "auto", 1.0, 1.0)
+
+
+# ------------------------------------------------------------------ fp8 activation quantisation
+def _fp8_inputs(dtype, tokens, hidden, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(tokens, hidden, generator=g) * 4).to(dtype)
+    x[0, :5] = torch.tensor([1e4, -1e4, 0.0, -0.0, float("nan")]).to(dtype)  # clamp, zeros, NaN -> +448
+    return x
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_fp8_quant_oracle_vs_torch(dtype):
+    """static: e4m3(clamp(x * (1/scale))); per token: scale = max(absmax/448, 1/(448*512))."""
+    x = _fp8_inputs(dtype, 5, 96)
+    x[0, 4] = 1.0  # (torch's clamp keeps NaN; checked separately below)
+    scale = torch.tensor([0.037], dtype=torch.float32)
+    out = torch.zeros(x.shape, dtype=torch.uint8)
+    oracle.static_scaled_fp8_quant(out, x, scale)
+    want = (x.float() * (1.0 / scale)).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(out, want)
+    scales = torch.zeros(5, 1, dtype=torch.float32)
+    oracle.dynamic_per_token_scaled_fp8_quant(out, scales, x)
+    want_s = (x.float().abs().amax(dim=1, keepdim=True) / 448.0).clamp_min(1.0 / (448.0 * 512.0))
+    assert torch.equal(scales, want_s)
+    assert torch.equal(out, (x.float() / want_s).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    nan_in = torch.tensor([[float("nan"), 1.0]], dtype=dtype)
+    o = torch.zeros(1, 2, dtype=torch.uint8)
+    oracle.static_scaled_fp8_quant(o, nan_in, torch.tensor([1.0]))
+    assert o[0, 0] == 0x7e  # fmax(-448, fmin(NaN, 448)) = 448
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("tokens,hidden", [(1, 16), (7, 4096), (33, 14336), (5, 100), (3, 7)])
+def test_fp8_quant_ops_bit_exact(ops, dtype, tokens, hidden):
+    x = _fp8_inputs(dtype, tokens, max(hidden, 5))[:, :hidden].contiguous()
+    xd = x.to(DEV)
+    # static
+    scale = torch.tensor([0.05], dtype=torch.float32)
+    want = torch.zeros(x.shape, dtype=torch.uint8)
+    oracle.static_scaled_fp8_quant(want, x, scale)
+    got, _ = ops.scaled_fp8_quant(xd, scale.to(DEV))
+    assert got.dtype == torch.float8_e4m3fn and torch.equal(got.view(torch.uint8).cpu(), want)
+    # dynamic per tensor
+    s_o = torch.zeros(1, dtype=torch.float32)
+    oracle.dynamic_scaled_fp8_quant(want, x, s_o)
+    got, s = ops.scaled_fp8_quant(xd)
+    if torch.isnan(x.float()).any():  # max(|x|) ignores NaN on both sides (fmaxf)
+        pass
+    assert torch.equal(s.cpu(), s_o) and torch.equal(got.view(torch.uint8).cpu(), want)
+    # dynamic per token, with and without an upper bound
+    for ub in (None, torch.tensor([3.0], dtype=torch.float32)):
+        s_o = torch.zeros(tokens, 1, dtype=torch.float32)
+        oracle.dynamic_per_token_scaled_fp8_quant(want, s_o, x, ub)
+        got, s = ops.scaled_fp8_quant(xd, scale_ub=ub.to(DEV) if ub is not None else None,
+                                      use_per_token_if_dynamic=True)
+        assert torch.equal(s.cpu(), s_o)
+        assert torch.equal(got.view(torch.uint8).cpu(), want)
+    # padding of the token dimension (static path keeps rows beyond the input untouched)
+    got, s = ops.scaled_fp8_quant(xd, num_token_padding=tokens + 3, use_per_token_if_dynamic=True)
+    assert got.shape == (tokens + 3, hidden) and s.shape == (tokens + 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_token", [False, True])
+def test_apply_fp8_linear_vs_dequantised_matmul(ops, per_token):
+    """W8A8 linear (w8a8_utils.py:103-189): quantise with the HIP kernels, multiply with
+    torch._scaled_mm, compare with the fp32 product of the dequantised operands."""
+    from light_vllm_amd.quantization import apply_fp8_linear, per_tensor_quantize_weight
+    g = torch.Generator().manual_seed(0)
+    M, K, N = 37, 512, 256
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+    wq, ws = per_tensor_quantize_weight(w)
+    try:
+        y = apply_fp8_linear(x, wq, ws, bias=bias, use_per_token_if_dynamic=per_token)
+    except RuntimeError as e:  # a torch build without fp8 _scaled_mm for this GPU
+        pytest.skip(f"torch._scaled_mm unavailable: {e}")
+    xq, xs = ops.scaled_fp8_quant(x, use_per_token_if_dynamic=per_token)
+    want = (xq.float() * xs) @ (wq.float() * ws) + bias.float()
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    assert float((y.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
