@@ -256,6 +256,12 @@ int lvllm_advance_step(int num_seqs, int num_queries, int block_size, int64_t* i
                        int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
                        void* stream);
 
+/* convert_fp8: csrc/cache_kernels.cu:334-410, torch_bindings.cpp:261-264 ("only for testing" there).
+ * to_fp8 != 0: dst (bytes) = fp8(float(src) / scale); else dst = T(float(fp8 src) * scale).  `dtype` is the
+ * element type of the non-fp8 side; contiguous buffers of num_elems elements. */
+int lvllm_convert_fp8(void* dst, const void* src, float scale, int64_t num_elems, int dtype, int to_fp8,
+                      int kv_dtype, void* stream);
+
 /* ---- fp8 activation quantisation (csrc/quantization/fp8/common.cu, torch_bindings.cpp:185-202) ----
  * out: OCP e4m3fn bytes (c10::Float8_e4m3fn).  static: out = fp8(clamp(x * (1/scale), +-448)), scale[1].
  * dynamic: scale[0] (<= 0 on entry) = max|x| / 448 first, then as static.  per token:

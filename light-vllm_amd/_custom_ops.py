@@ -165,6 +165,11 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tenso
     _CACHE.swap_blocks(src, dst, block_mapping)
 
 
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0, kv_dtype: str = "fp8") -> None:
+    """fp8 <-> float/half/bfloat16 elementwise (_custom_ops.py:466-470 of the reference)."""
+    torch.ops._C_cache_ops.convert_fp8(output, input, scale, kv_dtype)
+
+
 def get_device_attribute(attribute: int, device: int) -> int:
     return _UTILS.get_device_attribute(attribute, device)
 

@@ -132,6 +132,27 @@ __global__ void reshape_and_cache_fp8_kernel(
   }
 }
 
+// convert_fp8 (csrc/cache_kernels.cu:334-410, "only for testing" there): elementwise
+// T -> fp8(float(x) / scale) or fp8 -> T(float(fp8) * scale), the two scaled_convert directions.
+template <typename T, bool TO_FP8>
+__global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, const float scale,
+                                   const int64_t n) {
+  using S = typename T::store_t;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (TO_FP8) {
+      float v = T::to_float(reinterpret_cast<const S*>(src)[i]) / scale;
+      const bool nan = v != v;
+      v = fabsf(v) > 448.f ? copysignf(448.f, v) : v;
+      const uint32_t w = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+      reinterpret_cast<uint8_t*>(dst)[i] = nan ? (uint8_t)0x7f : (uint8_t)w;
+    } else {
+      const uint32_t w = reinterpret_cast<const uint8_t*>(src)[i];
+      const float v = __builtin_amdgcn_cvt_f32_fp8(w, 0);
+      reinterpret_cast<S*>(dst)[i] = T::from_float(v * scale);
+    }
+  }
+}
+
 // Flash layout [NB, BS, H, D]: both K and V rows are contiguous per token.
 template <typename store_t, int X>
 __global__ void reshape_and_cache_flash_kernel(
@@ -324,5 +345,23 @@ extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* bloc
     }
     i += run;
   }
+  return 0;
+}
+
+extern "C" int lvllm_convert_fp8(void* dst, const void* src, float scale, int64_t num_elems, int dtype,
+                                 int to_fp8, int kv_dtype, void* stream) {
+  LV_CHECK(kv_dtype == LVLLM_KV_FP8_E4M3, "convert_fp8: kv_cache_dtype must be 'fp8' / 'fp8_e4m3'");
+  LV_CHECK(scale > 0.f, "convert_fp8: scale must be positive");
+  if (num_elems <= 0) return 0;
+  const int64_t want = (num_elems + 255) / 256;
+  const int grid = (int)(want < 8192 ? want : 8192);
+  if (to_fp8) {
+    LV_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, true>), dim3(grid), dim3(256), 0,
+                                                (hipStream_t)stream, dst, src, scale, num_elems));
+  } else {
+    LV_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, false>), dim3(grid), dim3(256), 0,
+                                                (hipStream_t)stream, dst, src, scale, num_elems));
+  }
+  LV_LAUNCH_CHECK();
   return 0;
 }

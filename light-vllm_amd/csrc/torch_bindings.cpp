@@ -451,6 +451,24 @@ void advance_step(int64_t num_seqs, int64_t num_queries, int64_t block_size, tor
                            current_stream(sampled_token_ids)));
 }
 
+// csrc/cache_kernels.cu:352-410
+void convert_fp8(torch::Tensor& dst_cache, torch::Tensor& src_cache, const double scale,
+                 const std::string& kv_cache_dtype) {
+  TORCH_CHECK(src_cache.is_cuda(), "src must be on a GPU");
+  TORCH_CHECK(dst_cache.is_cuda(), "dst must be on a GPU");
+  TORCH_CHECK(src_cache.device().index() == dst_cache.device().index(), "src and dst must be on the same GPU");
+  TORCH_CHECK(src_cache.is_contiguous() && dst_cache.is_contiguous() && src_cache.numel() == dst_cache.numel(),
+              "convert_fp8: contiguous tensors of equal size");
+  TORCH_CHECK(kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3", "Unsupported data type: ", kv_cache_dtype);
+  const bool to_fp8 = dst_cache.element_size() == 1;
+  TORCH_CHECK(to_fp8 != (src_cache.element_size() == 1), "convert_fp8: exactly one side must be a one-byte tensor");
+  const torch::Tensor& wide = to_fp8 ? src_cache : dst_cache;
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(src_cache));
+  check(lvllm_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), (float)scale, src_cache.numel(),
+                          dtype_code(wide, "convert_fp8"), to_fp8 ? 1 : 0, LVLLM_KV_FP8_E4M3,
+                          current_stream(src_cache)));
+}
+
 // fp8 activation quantisation, csrc/quantization/fp8/common.cu:226-292
 void check_fp8_out(const torch::Tensor& out, const torch::Tensor& input, const char* op) {
   LV_CHECK_DEVICE(input);
@@ -567,6 +585,10 @@ TORCH_LIBRARY(_C, ops) {
 }
 
 TORCH_LIBRARY(_C_cache_ops, cache_ops) {
+  // torch_bindings.cpp:261-264 of the reference
+  cache_ops.def("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()");
+  cache_ops.impl("convert_fp8", torch::kCUDA, &convert_fp8);
+
   cache_ops.def("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()");
   cache_ops.impl("swap_blocks", torch::kCUDA, &swap_blocks);
   // a D2H swap dispatches on its CPU destination when src is listed first

@@ -267,3 +267,26 @@ def test_apply_fp8_linear_vs_dequantised_matmul(ops, per_token):
     want = (xq.float() * xs) @ (wq.float() * ws) + bias.float()
     assert y.shape == (M, N) and y.dtype == torch.bfloat16
     assert float((y.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_convert_fp8_both_directions(ops, dtype):
+    """T -> fp8(x / scale) bit-exact with the oracle's conversion (= torch.float8_e4m3fn after the
+    saturating clamp); fp8 -> T(float(fp8) * scale) for all 256 codes."""
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(9, 2, 64, generator=g) * 50).to(dtype)
+    scale = 0.75
+    want = (x.float() / scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    got = torch.zeros(x.shape, dtype=torch.uint8, device=DEV)
+    ops.convert_fp8(got, x.to(DEV), scale, "fp8")
+    assert torch.equal(got.cpu(), want)
+    codes = torch.arange(256, dtype=torch.uint8).view(4, 64)
+    back = torch.zeros(4, 64, dtype=dtype, device=DEV)
+    ops.convert_fp8(back, codes.to(DEV), scale, "fp8_e4m3")
+    ref = (codes.view(torch.float8_e4m3fn).float() * scale).to(dtype)
+    b = back.cpu()
+    ok = (b == ref) | (torch.isnan(b.float()) & torch.isnan(ref.float()))
+    assert bool(ok.all())
+    with pytest.raises(RuntimeError, match="Unsupported data type"):
+        ops.convert_fp8(back, codes.to(DEV), scale, "auto")
