@@ -274,6 +274,17 @@ int lvllm_dynamic_per_token_scaled_fp8_quant(void* out, float* scales, const voi
                                              const float* scale_ub, int num_tokens, int hidden_size,
                                              int dtype, void* stream);
 
+/* W8A8 decode projection on the weight-streaming kernel: y = T((fp8(x / *x_scale) . w8^T) * *x_scale *
+ * *w_scale + bias) -- torch._scaled_mm(fp8(x), fp8(w), scale_a, scale_b, bias) of w8a8_utils.py:147-156
+ * with a static activation scale, the activation quantised while the MFMA operands are built
+ * (arithmetic of static_scaled_fp8_quant).  x [M <= 64, K] in `dtype` (rows ldx apart), w_packed =
+ * fp8 e4m3fn weights [N, K] packed by lvllm_pack_weight on their [N, K/2] 16-bit view; K % 64 == 0,
+ * N % 16 == 0.  Returns 3 outside the envelope. */
+int64_t lvllm_skinny_gemm_w8a8_workspace_bytes(int M, int N, int K);
+int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const void* bias,
+                           const float* x_scale, const float* w_scale, int M, int N, int K, int64_t ldx,
+                           int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

@@ -48,6 +48,12 @@ __device__ __forceinline__ g_f32x4_t gemm_mfma<F16>(g_u32x4_t a, g_u32x4_t b, g_
                                                 __builtin_bit_cast(g_f16x8_t, b), c, 0, 0, 0);
 }
 
+// fp8 x fp8 (OCP e4m3fn), K = 32 per instruction, 8 bytes per lane and operand
+__device__ __forceinline__ g_f32x4_t gemm_mfma_fp8(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, g_f32x4_t c) {
+  const long a = (long)(((unsigned long)a1 << 32) | a0), b = (long)(((unsigned long)b1 << 32) | b0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
+
 constexpr int kGemmWaves = 8;
 constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load returns 0
 #ifndef LVLLM_GEMM_AUX
@@ -57,14 +63,23 @@ constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load r
 #define LVLLM_GEMM_NT 2   // partial slabs (n-tiles x m-tiles) accumulated between two wave meetings
 #endif
 
-template <typename T, int MT, int KSTEPS, bool PACKED, int NT>
+// W8 (W8A8): `w` holds fp8 (OCP e4m3fn) weights packed as if [N, K] bytes were [N, K/2] 16-bit
+// elements, so every address below is unchanged with K := K/2; a 16-byte fragment is then 16
+// consecutive k of one row and feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (bytes 0-7, bytes 8-15; the
+// contraction only needs W and X to agree on the order).  X arrives in T and is quantised while
+// the fragments are built, with the arithmetic of static_scaled_fp8_quant (fp8_quant.hip):
+// fp8(clamp(x * (1 / *x_scale))).  The result is T(acc * (*x_scale * *w_scale) + bias): what
+// torch._scaled_mm(fp8(x), fp8(w), scale_a, scale_b) computes (w8a8_utils.py:147-156).
+template <typename T, int MT, int KSTEPS, bool PACKED, int NT, bool W8>
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     typename T::store_t* __restrict__ y,   // [M, N]            (ksplit == 1)
     float* __restrict__ partial,           // [ksplit, M, N]    (ksplit > 1)
     const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
     const typename T::store_t* __restrict__ bias, const int M, const int N, const int K,
-    const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles) {
+    const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles,
+    const float* __restrict__ x_scale, const float* __restrict__ w_scale) {
   using S = typename T::store_t;
+  const float out_scale = W8 ? x_scale[0] * w_scale[0] : 1.f;
   constexpr int HALF = KSTEPS / 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   g_f32x4_t* red = reinterpret_cast<g_f32x4_t*>(smem_raw);  // [2][waves][NT * MT][64]
@@ -129,6 +144,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         float* dst = partial + ((int64_t)blockIdx.y * M + m) * N + n0;
         *reinterpret_cast<g_f32x4_t*>(dst) = sum;
       } else {
+        if constexpr (W8) sum *= out_scale;
         if (bias != nullptr) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n0 + r]);
@@ -191,8 +207,15 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 #pragma unroll
     for (int s = 0; s < HALF; ++s)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        ac[mt] = gemm_mfma<T>(a[s], h == 0 ? xf[mt][s] : xf[mt][HALF + s], ac[mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        const g_u32x4_t xb = h == 0 ? xf[mt][s] : xf[mt][HALF + s];
+        if constexpr (W8) {
+          ac[mt] = gemm_mfma_fp8(a[s].x, a[s].y, xb.x, xb.y, ac[mt]);
+          ac[mt] = gemm_mfma_fp8(a[s].z, a[s].w, xb.z, xb.w, ac[mt]);
+        } else {
+          ac[mt] = gemm_mfma<T>(a[s], xb, ac[mt]);
+        }
+      }
   };
 
   // units: (n-tile, half of the wave's k-steps); two register sets.  Each set is refilled right
@@ -209,7 +232,26 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
-      if (m < M && s < nvalid) {
+      if constexpr (W8) {
+        if (m < M && s < nvalid) {
+          // 16 consecutive k of row m: k = 64 (step0 + s) + 16 g ..  (K here is K/2, see above)
+          const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 64 + 16 * g;
+          S e[16];
+          *reinterpret_cast<g_u32x4_t*>(e) = *reinterpret_cast<const g_u32x4_t*>(src);
+          *reinterpret_cast<g_u32x4_t*>(e + 8) = *reinterpret_cast<const g_u32x4_t*>(src + 8);
+          const float inv = 1.0f / x_scale[0];
+          uint32_t q[4];
+#pragma unroll
+          for (int d4 = 0; d4 < 4; ++d4) {
+            float f[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = fmaxf(-448.f, fminf(T::to_float(e[4 * d4 + r]) * inv, 448.f));
+            uint32_t wq = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+            q[d4] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wq, true);
+          }
+          xf[mt][s] = g_u32x4_t{q[0], q[1], q[2], q[3]};
+        }
+      } else if (m < M && s < nvalid) {
         const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
         g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
         if (act == 1) {
@@ -255,7 +297,9 @@ template <typename T>
 __global__ void skinny_gemm_reduce_kernel(typename T::store_t* __restrict__ y,
                                           const float* __restrict__ partial,
                                           const typename T::store_t* __restrict__ bias,
-                                          const int64_t MN, const int N, const int ksplit) {
+                                          const int64_t MN, const int N, const int ksplit,
+                                          const float* __restrict__ x_scale = nullptr,
+                                          const float* __restrict__ w_scale = nullptr) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= MN) return;
   g_f32x4_t sum = *reinterpret_cast<const g_f32x4_t*>(partial + i);
@@ -263,6 +307,7 @@ __global__ void skinny_gemm_reduce_kernel(typename T::store_t* __restrict__ y,
     const g_f32x4_t v = *reinterpret_cast<const g_f32x4_t*>(partial + (int64_t)s * MN + i);
     sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
   }
+  if (x_scale != nullptr) sum *= x_scale[0] * w_scale[0];  // W8A8: see skinny_gemm_kernel
   if (bias != nullptr) {
     const int n = (int)(i % N);
 #pragma unroll
@@ -274,10 +319,11 @@ __global__ void skinny_gemm_reduce_kernel(typename T::store_t* __restrict__ y,
   *reinterpret_cast<uint2*>(y + i) = o;
 }
 
-template <typename T, int MT, int KSTEPS>
+template <typename T, int MT, int KSTEPS, bool W8 = false>
 static void launch_skinny(void* y, float* partial, const void* x, const void* w, const void* bias, int M,
                           int N, int K, int64_t ldx, int steps_per_wave, int ntiles, int groups, int ksplit,
-                          bool packed, int act, hipStream_t stream) {
+                          bool packed, int act, hipStream_t stream, const float* x_scale = nullptr,
+                          const float* w_scale = nullptr) {
   using S = typename T::store_t;
   constexpr int NT = LVLLM_GEMM_NT / MT > 0 ? LVLLM_GEMM_NT / MT : 1;  // NT * MT slabs per meeting
   const size_t red_bytes = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
@@ -288,18 +334,19 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
   if (stage_tiles > cap) stage_tiles = cap;
   if (stage_tiles < NT) stage_tiles = NT;
   const size_t smem = red_bytes + (size_t)stage_tiles * MT * 64 * sizeof(g_f32x4_t);
-  auto kp = skinny_gemm_kernel<T, MT, KSTEPS, true, NT>;
-  auto ku = skinny_gemm_kernel<T, MT, KSTEPS, false, NT>;
-  if (smem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute((const void*)ku, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  auto go = [&](auto kern) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
+                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act,
+                       stage_tiles, x_scale, w_scale);
+  };
+  if constexpr (W8) {
+    go(skinny_gemm_kernel<T, MT, KSTEPS, true, NT, true>);  // fp8 weights are always packed
+  } else {
+    if (packed) go(skinny_gemm_kernel<T, MT, KSTEPS, true, NT, false>);
+    else go(skinny_gemm_kernel<T, MT, KSTEPS, false, NT, false>);
   }
-  if (packed)
-    hipLaunchKernelGGL(kp, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
-                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act, stage_tiles);
-  else
-    hipLaunchKernelGGL(ku, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
-                       (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act, stage_tiles);
 }
 
 // W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
@@ -425,6 +472,78 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
     else
       hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(threads), 0, s, (uint16_t*)y,
                          partial, (const uint16_t*)bias, MN, N, ksplit);
+    LV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// W8A8: Y[M,N] = T((fp8(X / x_scale) . W8^T) * x_scale * w_scale + bias).  X [M, K] in T (ldx apart),
+// W8 = fp8 weights [N, K] packed by lvllm_pack_weight on their [N, K/2] 16-bit view, per-tensor
+// scales on the device (w8a8_utils.py:103-156 of the reference with a static activation scale).
+extern "C" int64_t lvllm_skinny_gemm_w8a8_workspace_bytes(int M, int N, int K) {
+  return lvllm_skinny_gemm_workspace_bytes(M, N, K / 2);
+}
+
+extern "C" int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const void* bias,
+                                      const float* x_scale, const float* w_scale, int M, int N, int K,
+                                      int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  LV_CHECK(x_scale != nullptr && w_scale != nullptr, "scales are device pointers to one float each");
+  if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 64) != 0 || (N % 16) != 0 ||
+      (int64_t)N * K >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
+      ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) & 15) != 0)) {
+    set_error("lvllm_skinny_gemm_w8a8: shape outside the kernel's envelope");
+    return 3;
+  }
+  const int K2 = K / 2;  // the kernel's K: 16-bit units of the weight rows
+  const int total_steps = K2 / 32;
+  const int cap = kGemmWaves * max_steps_per_wave(M);
+  const int ksplit = (total_steps + cap - 1) / cap;
+  const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
+  const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;
+  const int ntiles = N / 16;
+  int groups = tuning().gemm_workgroups / ksplit;
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  float* partial = nullptr;
+  if (ksplit > 1) {
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
+             "workspace too small (see lvllm_skinny_gemm_w8a8_workspace_bytes)");
+    partial = (float*)workspace;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int MT = (M + 15) / 16;
+  const bool k8 = steps_per_wave <= 8;
+#define LV_SG8(T_, MT_)                                                                                   \
+  do {                                                                                                    \
+    if (k8 || MT_ == 4)                                                                                   \
+      launch_skinny<T_, MT_, 8, true>(y, partial, x, w_packed, bias, M, N, K2, ldx, steps_per_wave, ntiles, \
+                                      groups, ksplit, true, 0, s, x_scale, w_scale);                      \
+    else                                                                                                  \
+      launch_skinny<T_, MT_, (MT_ == 4 ? 8 : 16), true>(y, partial, x, w_packed, bias, M, N, K2, ldx,       \
+                                                       steps_per_wave, ntiles, groups, ksplit, true, 0, s, \
+                                                       x_scale, w_scale);                                 \
+  } while (0)
+#define LV_SG8_MT(T_)          \
+  switch (MT) {                \
+    case 1: LV_SG8(T_, 1); break; \
+    case 2: LV_SG8(T_, 2); break; \
+    default: LV_SG8(T_, 4); break; \
+  }
+  if (dtype == LVLLM_BF16) { LV_SG8_MT(BF16) } else { LV_SG8_MT(F16) }
+#undef LV_SG8_MT
+#undef LV_SG8
+  LV_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const int64_t MN = (int64_t)M * N;
+    const int grid = (int)((MN / 4 + 255) / 256);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<BF16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit, x_scale, w_scale);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit, x_scale, w_scale);
     LV_LAUNCH_CHECK();
   }
   return 0;

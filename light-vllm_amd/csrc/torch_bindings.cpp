@@ -506,6 +506,30 @@ void dynamic_per_token_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const&
       dtype_code(input, "dynamic_per_token_scaled_fp8_quant"), current_stream(input)));
 }
 
+torch::Tensor skinny_linear_w8a8(const torch::Tensor& x, const torch::Tensor& w_packed, const torch::Tensor& w_scale,
+                                 const torch::Tensor& x_scale, int64_t N, int64_t K,
+                                 const std::optional<torch::Tensor>& bias) {
+  LV_CHECK_DEVICE(x);
+  LV_CHECK_DEVICE(w_packed);
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1, "skinny_linear_w8a8: x must be [M, K]");
+  TORCH_CHECK(w_packed.is_contiguous() && w_packed.numel() * w_packed.element_size() == N * K,
+              "skinny_linear_w8a8: w_packed must hold N*K fp8 bytes");
+  TORCH_CHECK(w_scale.scalar_type() == at::kFloat && x_scale.scalar_type() == at::kFloat && w_scale.is_cuda() &&
+                  x_scale.is_cuda() && w_scale.numel() == 1 && x_scale.numel() == 1,
+              "skinny_linear_w8a8: per-tensor float32 scales on the device");
+  const int64_t M = x.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto y = torch::empty({M, N}, x.options());
+  const int64_t ws_bytes = lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
+  check(lvllm_skinny_gemm_w8a8(y.data_ptr(), x.data_ptr(), w_packed.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                               x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N, (int)K,
+                               x.stride(0), dtype_code(x, "skinny_linear_w8a8"),
+                               ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, current_stream(x)));
+  return y;
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -640,6 +664,9 @@ TORCH_LIBRARY(_C_amd, amd) {
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
           "str kv_cache_dtype, bool causal=True) -> ()");
   amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
+  amd.def("skinny_linear_w8a8(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
+          "Tensor? bias) -> Tensor");
+  amd.impl("skinny_linear_w8a8", torch::kCUDA, &skinny_linear_w8a8);
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });

@@ -46,3 +46,19 @@ def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: to
     if bias is not None:
         output = output + bias
     return output.to(dtype=input.dtype)
+
+
+def pack_fp8_weight(weight_fp8: torch.Tensor) -> torch.Tensor:
+    """[N, K] fp8 weight (row-major, K % 64 == 0, N % 16 == 0) -> the order the weight-streaming
+    kernel reads: lvllm_pack_weight applied to the [N, K/2] 16-bit view of the same bytes."""
+    N, K = weight_fp8.shape
+    assert weight_fp8.element_size() == 1 and weight_fp8.is_contiguous() and K % 64 == 0 and N % 16 == 0
+    return torch.ops._C_amd.pack_weight(weight_fp8.view(torch.float16)).view(torch.uint8)
+
+
+def skinny_fp8_linear(x: torch.Tensor, w_packed: torch.Tensor, w_scale: torch.Tensor, x_scale: torch.Tensor,
+                      N: int, K: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W8A8 projection of a decode batch (M <= 64) with a static per-tensor activation scale:
+    one launch, activation quantised inside the kernel, fp8 x fp8 MFMA, scales and bias in the
+    epilogue -- the fused equivalent of apply_fp8_linear's per-tensor branch."""
+    return torch.ops._C_amd.skinny_linear_w8a8(x, w_packed, w_scale, x_scale, N, K, bias)

@@ -290,3 +290,32 @@ def test_convert_fp8_both_directions(ops, dtype):
     assert bool(ok.all())
     with pytest.raises(RuntimeError, match="Unsupported data type"):
         ops.convert_fp8(back, codes.to(DEV), scale, "auto")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 64])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (256, 14336), (512, 64), (48, 8192)])
+def test_skinny_w8a8_vs_dequantised_matmul(ops, dtype, M, N, K):
+    """The W8A8 weight-streaming kernel against the fp64 product of the very fp8 values it multiplies
+    (activation quantised by the oracle's static_scaled_fp8_quant arithmetic), scales and bias applied
+    as torch._scaled_mm does.  fp8 x fp8 products are exact in fp32; only the summation order and the
+    final rounding to T differ."""
+    from light_vllm_amd.quantization import pack_fp8_weight, skinny_fp8_linear
+    g = torch.Generator().manual_seed(N + K + M)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g).to(dtype)
+    w_scale = (w.abs().max() / 448.0).reshape(1).float()
+    wq = (w / w_scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    x_scale = torch.tensor([float(x.float().abs().max()) / 448.0 * 0.8])  # some values saturate on purpose
+    xq = torch.zeros(M, K, dtype=torch.uint8)
+    oracle.static_scaled_fp8_quant(xq, x, x_scale)
+    want = (xq.view(torch.float8_e4m3fn).double() @ wq.double().T) * float(x_scale) * float(w_scale) + bias.double()
+    wp = pack_fp8_weight(wq.to(DEV))
+    y = skinny_fp8_linear(x.to(DEV), wp, w_scale.to(DEV), x_scale.to(DEV), N, K, bias.to(DEV))
+    torch.cuda.synchronize()
+    assert y.shape == (M, N) and y.dtype == dtype
+    err = (y.cpu().double() - want).abs().max().item()
+    tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(1.0, want.abs().max().item())
+    assert err <= tol, (err, tol)
