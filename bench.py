@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
                     help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
+    ap.add_argument("--quantization", default=None, choices=["fp8"],
+                    help="non-default runs only: W8A8 projections (BASELINE config 5; the headline is bf16)")
     ap.add_argument("--on-the-fly", type=int, default=2,
                     help="steps in flight with async scheduling (reference default: 2)")
     ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
@@ -190,6 +192,7 @@ def main():
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
     cfg.fuse_decode_ops = not a.no_fusion
+    cfg.quantization = a.quantization
     total_steps = a.steps + a.warmup
     max_len = ctx + total_steps // on_the_fly + 8
     max_model_len = (max_len + 511) // 512 * 512
@@ -256,7 +259,11 @@ def main():
             "metric": "decode tokens/sec Llama-3-8B bs=32 seq=1k; paged-attn HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "bf16" if not (a.quantization or a.kv_cache_dtype != "auto") else
+                     "bf16" + (" + fp8 (e4m3) W8A8 projections" if a.quantization else "") +
+                     (" + fp8 (e4m3) KV cache" if a.kv_cache_dtype != "auto" else ""),
+            "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
                                    f"decode bs={B} per step, context {ctx}..{int(ctx_now)}, block_size 16, "
                                    f"{a.scheduling} scheduling ({on_the_fly} batches in flight, one stream each), "

@@ -23,6 +23,9 @@ class ModelConfig:
     dtype: torch.dtype = torch.bfloat16
     pack_weights: bool = True       # keep an MFMA-ordered copy of each projection for decode
     fuse_decode_ops: bool = True    # rope+cache write in one launch, split-K sum inside add+norm
+    # "fp8": W8A8 projections (BASELINE config 5): per-tensor e4m3 weights, static per-tensor
+    # activation scales calibrated once on a random batch (the reference's activation_scheme="static")
+    quantization: Optional[str] = None
 
     @property
     def head_dim(self) -> int:

@@ -22,25 +22,50 @@ class Weight:
     weight-streaming kernel reads one contiguous KiB per wave load (csrc/skinny_gemm.hip).
     Twice the bytes; sized for 288 GB of HBM."""
 
-    __slots__ = ("w", "packed", "N", "K")
+    __slots__ = ("w", "packed", "N", "K", "w8_t", "w8_packed", "w_scale", "x_scale", "x_absmax")
 
     def __init__(self, w: torch.Tensor, pack: bool = True):
         self.w = w
         self.N, self.K = w.shape
         ok = pack and w.is_cuda and self.N % 16 == 0 and self.K % 32 == 0 and self.N * self.K * 2 < (1 << 32) - 16
         self.packed = torch.ops._C_amd.pack_weight(w) if ok else None
+        self.w8_t = self.w8_packed = self.w_scale = self.x_scale = None
+        self.x_absmax = None  # calibration: running max |x| of this projection's input
 
     def numel(self) -> int:
-        return self.w.numel()
+        return self.N * self.K
+
+    def quantize_fp8(self) -> None:
+        """Per-tensor e4m3 weights + the calibrated static activation scale; the 16-bit copies are
+        dropped (fp8.py:196-239 of the reference quantises at load time the same way)."""
+        from ..quantization import pack_fp8_weight
+        q, self.w_scale = ops.scaled_fp8_quant(self.w)          # [N, K] fp8, scale [1]
+        self.w8_t = q.t()                                        # torch._scaled_mm wants [K, N] column-major
+        ok = self.N % 16 == 0 and self.K % 64 == 0 and self.N * self.K < (1 << 32) - 16
+        self.w8_packed = pack_fp8_weight(q) if ok else None
+        absmax = self.x_absmax if self.x_absmax is not None else torch.ones((), device=self.w.device)
+        self.x_scale = (absmax.float() / 448.0).clamp_min(1e-6).reshape(1)
+        self.w = self.packed = None
 
 
 def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense projection.  Decode batches (<= 64 rows) stream the weights through the gfx950
     weight-streaming kernel; larger batches use the library GEMM (hipBLASLt)."""
+    if w.w8_t is not None:  # W8A8
+        if x.shape[0] <= 64 and w.w8_packed is not None:
+            return torch.ops._C_amd.skinny_linear_w8a8(x, w.w8_packed, w.w_scale, w.x_scale, w.N, w.K, bias)
+        from ..quantization import apply_fp8_linear
+        return apply_fp8_linear(x, w.w8_t, w.w_scale, input_scale=w.x_scale, bias=bias)
+    if _CALIBRATING:
+        m = x.detach().abs().amax()
+        w.x_absmax = m if w.x_absmax is None else torch.maximum(w.x_absmax, m)
     if x.shape[0] <= 64 and x.is_cuda:
         if w.packed is not None:
             return torch.ops._C_amd.skinny_linear_packed(x, w.packed, bias, w.N, w.K)
     return F.linear(x, w.w, bias)
+
+
+_CALIBRATING = False
 
 
 def build_cos_sin_cache(head_dim: int, max_pos: int, base: float, dtype, device) -> torch.Tensor:
@@ -87,12 +112,52 @@ class DecoderModel:
         self.attn = attn_impl  # DecodeOnlyAttentionImpl-like: forward(q, k, v, kv_cache, metadata)
         self.q_size = cfg.num_attention_heads * cfg.head_dim
         self.kv_size = cfg.num_key_value_heads * cfg.head_dim
+        if cfg.quantization is not None:
+            if cfg.quantization != "fp8":
+                raise ValueError(f"unsupported quantization {cfg.quantization!r}")
+            self._quantize_fp8(gen)
+
+    def all_weights(self) -> List["Weight"]:
+        ws = [self.lm_head]
+        for l in self.layers:
+            ws += [l.qkv, l.o, l.gate_up, l.down]
+        return ws
+
+    @torch.inference_mode()
+    def _quantize_fp8(self, gen: torch.Generator) -> None:
+        """Static activation scales from one 16-bit forward of a random 64-token prompt (dense
+        causal attention, no KV cache), then every projection becomes fp8."""
+        global _CALIBRATING
+        cfg = self.cfg
+        T = 64
+        ids = torch.randint(0, cfg.vocab_size, (T,), generator=gen, device=self.device)
+        pos = torch.arange(T, device=self.device)
+
+        class _DenseAttn:  # the calibration pass needs attention outputs of realistic scale only
+            def forward(_, q, k, v, kv_cache, md):
+                H, KVH, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+                qh = q.view(T, H, D).transpose(0, 1)
+                kh = k.view(T, KVH, D).transpose(0, 1).repeat_interleave(H // KVH, dim=0)
+                vh = v.view(T, KVH, D).transpose(0, 1).repeat_interleave(H // KVH, dim=0)
+                o = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
+                return o.transpose(0, 1).reshape(T, H * D)
+
+        real_attn, self.attn = self.attn, _DenseAttn()
+        _CALIBRATING = True
+        try:
+            md = type("MD", (), {"num_prefill_tokens": T})()
+            hidden = self.forward(ids, pos, None, md)
+            self.compute_logits(hidden)
+        finally:
+            _CALIBRATING = False
+            self.attn = real_attn
+        for w in self.all_weights():
+            w.quantize_fp8()
+        torch.cuda.empty_cache()
 
     def weight_bytes(self) -> int:
-        n = self.lm_head.numel()
-        for l in self.layers:
-            n += l.qkv.numel() + l.o.numel() + l.gate_up.numel() + l.down.numel()
-        return n * self.lm_head.w.element_size()
+        n = sum(w.numel() for w in self.all_weights())
+        return n * (1 if self.cfg.quantization == "fp8" else self.embed.element_size())
 
     def _add_norm(self, x, residual: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         """residual += x; return norm(residual) * weight.  `x` is either the projection output
@@ -142,7 +207,7 @@ class DecoderModel:
             gate_up = linear(hidden, lw.gate_up)
             act = torch.empty(T, cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
             ops.silu_and_mul(act, gate_up)
-            if decode_only and lw.down.packed is not None:
+            if decode_only and lw.down.packed is not None and lw.down.w8_t is None:
                 # [S, T, hidden] fp32 split-K partial sums; the next add+norm adds them up
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(act, lw.down.packed, lw.down.N,
                                                                         lw.down.K, False)

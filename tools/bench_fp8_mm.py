@@ -5,6 +5,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import light_vllm_amd  # noqa
+from light_vllm_amd.quantization import pack_fp8_weight, skinny_fp8_linear
 
 dev = "cuda:0"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -23,4 +25,19 @@ for name, N, K in [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 40
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
     med = ts[len(ts) // 2]
-    print(f"{name:8s} N={N:6d} K={K:5d}  _scaled_mm fp8 {med:7.1f} us  ({N * K / med / 1e6:.2f} TB/s of weight bytes)")
+    # the W8A8 weight-streaming kernel (bf16 activations quantised in the kernel)
+    wps = [pack_fp8_weight(w.t().contiguous()) for w in ws]
+    xb = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    xs = torch.tensor([0.01], device=dev)
+    f2 = lambda i: skinny_fp8_linear(xb, wps[i % len(wps)], one, xs, N, K)
+    for i in range(5):
+        f2(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    for i, (a, b) in enumerate(evs):
+        a.record(); f2(i); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    med2 = ts[len(ts) // 2]
+    print(f"{name:8s} N={N:6d} K={K:5d}  _scaled_mm fp8 {med:7.1f} us ({N * K / med / 1e6:.2f} TB/s)   "
+          f"skinny w8a8 {med2:7.1f} us ({N * K / med2 / 1e6:.2f} TB/s of weight bytes)")
