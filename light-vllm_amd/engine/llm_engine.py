@@ -110,12 +110,12 @@ class Worker:
             g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor)
             tokens = g.replay()[:mi.input_tokens.shape[0]]
             if len(mi.sample_indices) != mi.input_tokens.shape[0]:
-                tokens = tokens[torch.tensor(mi.sample_indices, device=self.device)]
+                tokens = tokens[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
         else:
             mi.to(self.device)
             hidden = self.model.forward(mi.input_tokens, mi.input_positions, ce.gpu_cache, md)
             if len(mi.sample_indices) != hidden.shape[0]:
-                hidden = hidden[torch.tensor(mi.sample_indices, device=self.device)]
+                hidden = hidden[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
             logits = self.model.compute_logits(hidden)
             if self.capture_logits:
                 self.last_logits = logits.float().cpu()

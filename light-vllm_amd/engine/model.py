@@ -51,6 +51,8 @@ class Weight:
 def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Dense projection.  Decode batches (<= 64 rows) stream the weights through the gfx950
     weight-streaming kernel; larger batches use the library GEMM (hipBLASLt)."""
+    if x.shape[0] == 0:  # a step of unfinished prompt chunks samples nothing
+        return x.new_empty((0, w.N))
     if w.w8_t is not None:  # W8A8
         if x.shape[0] <= 64 and w.w8_packed is not None:
             return torch.ops._C_amd.skinny_linear_w8a8(x, w.w8_packed, w.w_scale, w.x_scale, w.N, w.K, bias)

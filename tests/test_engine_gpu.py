@@ -230,3 +230,24 @@ def test_fp8_weights_engine_tracks_the_bf16_run():
     assert sum(a == b for a, b in zip(eager, graph)) >= len(eager) - 1
     for a, b in zip(eager, graph):
         assert a[:4] == b[:4]
+
+
+def test_chunked_prefill_steps_that_sample_nothing():
+    """One 90-token prompt under a 16-token budget: the first five steps are unfinished prompt
+    chunks and sample nothing (empty index tensors, zero-row logits), then decoding starts."""
+    engine = make_engine(graph=False, chunked=True, budget=16)
+    g = torch.Generator().manual_seed(3)
+    p = torch.randint(0, 512, (90,), generator=g).tolist()
+    engine.add_request("0", p, max_tokens=3)
+    empties = 0
+    final = None
+    while engine.has_unfinished_requests():
+        outs = engine.step()
+        if outs and len(outs[0].token_ids) == 0:
+            empties += 1
+        for o in outs:
+            if o.finished:
+                final = o.token_ids
+    assert empties == 5 and len(final) == 3
+    ref = dense_reference_logits(engine.worker.model, p + final)
+    assert int(ref[len(p) - 1].argmax()) == final[0]
