@@ -473,6 +473,12 @@ class BlockSpaceManagerV2(BlockSpaceManager):
         first_block_idx = table.num_full_slots // bs
         first_chunk = bs - (table.num_full_slots % bs)
         chunks = [token_ids[:first_chunk]] + [token_ids[i:i + bs] for i in range(first_chunk, len(token_ids), bs)]
+        if not token_ids:
+            # A running prompt still in chunked prefill has no new token, and when its table is
+            # exactly full the reference indexes one block past the end here (block_table.py:
+            # 150-156 with _chunk_token_blocks_for_append returning [[]]) and raises IndexError;
+            # there is nothing to write, so nothing is touched.
+            chunks = []
         for i, chunk in enumerate(chunks):
             pool.append_tokens(table.blocks[first_block_idx + i], chunk)
         table.num_full_slots += len(token_ids)

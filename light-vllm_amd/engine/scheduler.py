@@ -192,8 +192,17 @@ class DecodingScheduler:
             while not self.block_manager.can_append_slots(seq_group, 0):
                 budget.subtract_num_batched_tokens(seq_group.request_id, num_running_tokens)
                 budget.subtract_num_seqs(seq_group.request_id, seq_group.get_max_num_running_seqs())
-                if q:  # evict the most recently arrived group first
-                    victim = q.pop()
+                # evict the most recently arrived group first -- but never one that a step still in
+                # flight is computing on (the reference pops the tail whatever its `busy` flag,
+                # scheduler.py:408-416: under memory pressure with two steps in flight it then
+                # frees the blocks of a sequence the GPU is writing to)
+                victim = None
+                for idx in range(len(q) - 1, -1, -1):
+                    if not q[idx].busy:
+                        victim = q[idx]
+                        del q[idx]
+                        break
+                if victim is not None:
                     mode = self._preempt(victim, blocks_to_swap_out)
                     (preempted if mode == PreemptionMode.RECOMPUTE else swapped_out).append(victim)
                 else:  # nothing else to evict: this group itself goes

@@ -52,17 +52,18 @@ def dense_reference_logits(model, token_ids):
 
 
 def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048,
-                cache_dtype="auto", quantization=None):
+                cache_dtype="auto", quantization=None, v2=False, prefix_caching=False, preemption_mode=None):
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
     cfg = ModelConfig.tiny()
     cfg.quantization = quantization
     return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32,
-                                      cache_dtype=cache_dtype),
+                                      cache_dtype=cache_dtype, enable_prefix_caching=prefix_caching),
                      SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=512,
                                      scheduling=scheduling, max_num_on_the_fly=2,
-                                     chunked_prefill_enabled=chunked),
+                                     chunked_prefill_enabled=chunked, use_v2_block_manager=v2,
+                                     preemption_mode=preemption_mode),
                      device=DEV, use_hip_graph=graph, seed=0)
 
 
@@ -251,3 +252,58 @@ def test_chunked_prefill_steps_that_sample_nothing():
     assert empties == 5 and len(final) == 3
     ref = dense_reference_logits(engine.worker.model, p + final)
     assert int(ref[len(p) - 1].argmax()) == final[0]
+
+
+@pytest.mark.parametrize("v2", [False, True])
+@pytest.mark.parametrize("prefix_caching", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "chunked", "swap", "async"])
+def test_engine_stress_every_request_finishes(v2, prefix_caching, mode):
+    """40 requests with prompt lengths 1..200 (a third of them sharing a 48-token prefix) on a pool
+    too small for all of them: admission control, preemption by recompute or by swap, prefix-cache
+    hits, chunked prefill and two steps in flight must all end with every request finished at its
+    token budget, and with the tokens of an unconstrained run up to where near-ties may flip."""
+    if mode == "swap" and v2:
+        pytest.skip("the reference's v2 manager cannot swap forked / cached blocks (bm_driver.py)")
+    if mode == "chunked" and prefix_caching:
+        pytest.skip("the reference refuses chunked prefill with a prefix-cache hit (model_input_builder.py)")
+    g = torch.Generator().manual_seed(11)
+    shared = torch.randint(0, 512, (48,), generator=g).tolist()
+    reqs = []
+    for i in range(40):
+        n = int(torch.randint(1, 200, (1,), generator=g))
+        body = torch.randint(0, 512, (n,), generator=g).tolist()
+        reqs.append(((shared + body) if i % 3 == 0 else body, int(torch.randint(8, 24, (1,), generator=g))))
+    kw = dict(graph=mode == "async", v2=v2, prefix_caching=prefix_caching, num_blocks=72, max_seqs=16)
+    if mode == "chunked":
+        kw.update(chunked=True, budget=64)
+    if mode == "swap":
+        kw.update(preemption_mode="swap")
+    if mode == "async":
+        kw.update(scheduling="async")
+    engine = make_engine(**kw)
+    for i, (p, mt) in enumerate(reqs):
+        engine.add_request(str(i), p, max_tokens=mt)
+    final = {}
+    step = engine.async_step if mode == "async" else engine.step
+    for _ in range(5000):
+        for out in step():
+            if out.finished:
+                final[out.request_id] = out.token_ids
+        if not engine.has_unfinished_requests() and engine.num_on_the_fly == 0:
+            break
+    engine.shutdown()
+    assert len(final) == len(reqs)
+    for i, (p, mt) in enumerate(reqs):
+        assert len(final[str(i)]) == mt, (i, len(final[str(i)]), mt)
+    assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == 72 or prefix_caching
+    # unconstrained eager run of the same requests: first tokens agree (same prompt, same weights)
+    ref = make_engine(graph=False, num_blocks=1024, max_seqs=64)
+    for i, (p, mt) in enumerate(reqs):
+        ref.add_request(str(i), p, max_tokens=mt)
+    want = {}
+    while ref.has_unfinished_requests():
+        for out in ref.step():
+            if out.finished:
+                want[out.request_id] = out.token_ids
+    same_first = sum(final[k][0] == want[k][0] for k in want)
+    assert same_first >= len(reqs) - 2, same_first
