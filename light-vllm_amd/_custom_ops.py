@@ -90,10 +90,12 @@ def varlen_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, 
     need = torch.ops._C_amd.varlen_attention_workspace_bytes(query.shape[0], cu_seqlens.numel() - 1,
                                                              max_seq_len, key.shape[1], query.shape[2])
     if workspace is None:
-        workspace = _VARLEN_WS.get(query.device)
+        # one scratch buffer per (device, stream): steps in flight on different streams must not share it
+        ws_key = (query.device, torch.cuda.current_stream(query.device).cuda_stream)
+        workspace = _VARLEN_WS.get(ws_key)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=query.device)
-            _VARLEN_WS[query.device] = workspace
+            _VARLEN_WS[ws_key] = workspace
     torch.ops._C_amd.varlen_attention(out, query, key, value, cu_seqlens, max_seq_len, scale, causal,
                                       alibi_slopes, sliding_window, softcap, workspace)
 

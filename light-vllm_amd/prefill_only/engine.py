@@ -1,0 +1,207 @@
+"""Encode-only engine: scheduler -> model input (tokens of the scheduled prompts back to back +
+seq_lens metadata) -> one forward pass -> per-request embedding.
+
+Step structure of light_vllm/core/llm_engine.py (sync step :119-130, async step :132-176) with the
+prefill-only executor's overlap of host->device copies, compute and device->host copies
+(prefill_only/executor/gpu_executor.py:109-262: three streams) obtained the same way as in the
+decoding engine of this package: every step in flight owns a stream, so one step's copies run beside
+another step's kernels.  One engine = one GPU; `engine.replicas` shards requests over GPUs."""
+import queue
+import threading
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from .config import PrefillOnlySchedulerConfig
+from .model import EncoderConfig, EncoderModel
+from .scheduler import (PrefillOnlyRequestOutput, PrefillOnlyScheduler, PrefillOnlySchedulerOutput,
+                        SchedulableRequest)
+
+
+@dataclass
+class ModelInput:
+    """prefill_only/processor/model_input_builder.py:17-52: flattened tokens + positions + metadata."""
+    input_ids: torch.Tensor
+    positions: torch.Tensor
+    attn_metadata: object
+    seq_lens: List[int]
+
+    def to(self, device, non_blocking=True):
+        self.input_ids = self.input_ids.to(device, non_blocking=non_blocking)
+        self.positions = self.positions.to(device, non_blocking=non_blocking)
+        self.attn_metadata.to(device, non_blocking=non_blocking)
+        return self
+
+
+class PrefillOnlyEngine:
+    """`pooling`: "cls" (bge-m3's dense embedding: first token, L2-normalised, fp32), "mean", or
+    "last_hidden_states" (the whole [len, hidden] block per request)."""
+
+    def __init__(self, model_config: EncoderConfig, scheduler_config: PrefillOnlySchedulerConfig,
+                 device: str = "cuda:0", pooling: str = "cls", seed: int = 0):
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.model_config, self.scheduler_config = model_config, scheduler_config
+        self.model = EncoderModel(model_config, device, seed)
+        self.scheduler = PrefillOnlyScheduler(scheduler_config)
+        self.builder = self.model.backend.make_metadata_builder()
+        assert pooling in ("cls", "mean", "last_hidden_states")
+        self.pooling = pooling
+        self.num_slots = (max(1, scheduler_config.max_num_on_the_fly)
+                          if scheduler_config.scheduling in ("async", "double_buffer") else 1)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.num_slots)]
+        self.free_slots: "queue.Queue" = queue.Queue()
+        for i in range(self.num_slots):
+            self.free_slots.put(i)
+        self.executor_in: "queue.Queue" = queue.Queue()
+        self.executor_out: "queue.Queue" = queue.Queue()
+        self._done_q: "queue.Queue" = queue.Queue()
+        self._threads: List[threading.Thread] = []
+        self.num_on_the_fly = 0
+
+    # ---- requests ----
+    def add_request(self, request_id: str, prompt_token_ids: List[int]) -> None:
+        self.scheduler.add_request(SchedulableRequest(request_id, time.time(), list(prompt_token_ids)))
+
+    def abort_request(self, request_id) -> None:
+        self.scheduler.abort_request(request_id)
+
+    def has_unfinished_requests(self) -> bool:
+        return self.scheduler.has_unfinished_requests()
+
+    # ---- one step ----
+    def _build(self, sched: PrefillOnlySchedulerOutput) -> ModelInput:
+        pin = torch.cuda.is_available()
+        toks: List[int] = []
+        pos: List[int] = []
+        lens: List[int] = []
+        for r in sched.scheduled_requests:
+            toks.extend(r.prompt_token_ids)
+            pos.extend(range(r.num_new_tokens))
+            lens.append(r.num_new_tokens)
+        ids = torch.tensor(toks, dtype=torch.long)
+        p = torch.tensor(pos, dtype=torch.long)
+        if pin:
+            ids, p = ids.pin_memory(), p.pin_memory()
+        return ModelInput(ids, p, self.builder(seq_lens=lens), lens)
+
+    @torch.inference_mode()
+    def _execute(self, mi: ModelInput) -> torch.Tensor:
+        """On the current stream: H2D, forward, pooling, D2H into pinned memory (not yet complete)."""
+        mi.to(self.device)
+        hidden = self.model.forward(mi.input_ids, mi.positions, mi.attn_metadata)
+        if self.pooling == "last_hidden_states":
+            out = hidden
+        else:
+            start = mi.attn_metadata.seq_start_loc[:-1].long()
+            if self.pooling == "cls":
+                pooled = hidden[start].float()
+            else:
+                csum = torch.cat([hidden.new_zeros(1, hidden.shape[1], dtype=torch.float32),
+                                  hidden.float().cumsum(0)])
+                end = mi.attn_metadata.seq_start_loc[1:].long()
+                pooled = (csum[end] - csum[start]) / (end - start).unsqueeze(1)
+            out = torch.nn.functional.normalize(pooled, dim=-1)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        return host
+
+    def _process(self, sched: PrefillOnlySchedulerOutput, host: Optional[torch.Tensor], lens: List[int]):
+        outs: List[PrefillOnlyRequestOutput] = []
+        off = 0
+        for i, r in enumerate(sched.scheduled_requests):
+            if self.pooling == "last_hidden_states":
+                o = host[off:off + lens[i]]
+                off += lens[i]
+            else:
+                o = host[i]
+            outs.append(PrefillOnlyRequestOutput(r.request_id, o, r.prompt_token_ids, True, r.arrival_time))
+        for r in sched.ignored_requests:
+            outs.append(PrefillOnlyRequestOutput(r.request_id, None, r.prompt_token_ids, True, r.arrival_time))
+        outs = self.scheduler.remove_abort_request(outs)
+        self.scheduler.free_finished_request(outs)
+        return outs
+
+    def step(self) -> List[PrefillOnlyRequestOutput]:
+        sched = self.scheduler.schedule()
+        if sched.is_empty():
+            return self._process(sched, None, []) if sched.ignored_requests else []
+        mi = self._build(sched)
+        with torch.cuda.stream(self.streams[0]):
+            host = self._execute(mi)
+        self.streams[0].synchronize()
+        return self._process(sched, host, mi.seq_lens)
+
+    # ---- steps in flight ----
+    def _execute_loop(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self.executor_in.get()
+            if item is None:
+                self._done_q.put(None)
+                return
+            sched, mi = item
+            try:
+                slot = self.free_slots.get()
+                with torch.cuda.stream(self.streams[slot]):
+                    host = self._execute(mi)
+                    ev = torch.cuda.Event()
+                    ev.record(self.streams[slot])
+                self._done_q.put((slot, ev, sched, host, mi.seq_lens))
+            except Exception as e:
+                self.executor_out.put(e)
+
+    def _done_loop(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self._done_q.get()
+            if item is None:
+                return
+            slot, ev, sched, host, lens = item
+            ev.synchronize()
+            self.free_slots.put(slot)
+            self.executor_out.put((sched, host, lens))
+
+    def async_step(self) -> List[PrefillOnlyRequestOutput]:
+        if not self._threads:
+            self._threads = [threading.Thread(target=self._execute_loop, daemon=True),
+                             threading.Thread(target=self._done_loop, daemon=True)]
+            for t in self._threads:
+                t.start()
+        outs: List[PrefillOnlyRequestOutput] = []
+        while self.num_on_the_fly < self.scheduler_config.max_num_on_the_fly:
+            sched = self.scheduler.schedule()
+            if sched.ignored_requests:
+                outs.extend(self._process(PrefillOnlySchedulerOutput([], sched.ignored_requests), None, []))
+            if sched.is_empty():
+                break
+            self.executor_in.put((sched, self._build(sched)))
+            self.num_on_the_fly += 1
+        if self.num_on_the_fly == 0:
+            return outs
+        item = self.executor_out.get()
+        if isinstance(item, Exception):
+            raise item
+        self.num_on_the_fly -= 1
+        sched, host, lens = item
+        return outs + self._process(PrefillOnlySchedulerOutput(sched.scheduled_requests, []), host, lens)
+
+    def shutdown(self) -> None:
+        if self._threads:
+            self.executor_in.put(None)
+            for t in self._threads:
+                t.join(timeout=5)
+            self._threads = []
+
+    def encode(self, prompts: List[List[int]], use_async: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """Convenience: run `prompts` to completion, return {index: embedding}."""
+        for i, p in enumerate(prompts):
+            self.add_request(str(i), p)
+        use_async = self.num_slots > 1 if use_async is None else use_async
+        res: Dict[str, torch.Tensor] = {}
+        while self.has_unfinished_requests() or self.num_on_the_fly > 0:
+            for o in (self.async_step() if use_async else self.step()):
+                res[o.request_id] = o.outputs
+        return res

@@ -1,0 +1,44 @@
+"""BASELINE config 4: bge-m3-shaped (XLM-RoBERTa-large: 24 layers, hidden 1024, 16 heads of 64)
+encode-only throughput through the prefill-only engine: random prompts of `--len` tokens, dense (CLS)
+embeddings out.  Prints sequences/s and tokens/s for the sync and the async (two steps in flight)
+engine."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import light_vllm_amd  # noqa
+from light_vllm_amd.prefill_only import PrefillOnlySchedulerConfig
+from light_vllm_amd.prefill_only.engine import PrefillOnlyEngine
+from light_vllm_amd.prefill_only.model import EncoderConfig
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-prompts", type=int, default=512)
+    ap.add_argument("--len", type=int, default=512)
+    ap.add_argument("--max-num-seqs", type=int, default=32)
+    ap.add_argument("--tiny", action="store_true")
+    a = ap.parse_args()
+    cfg = EncoderConfig.tiny() if a.tiny else EncoderConfig.bge_m3()
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(2, cfg.vocab_size, (a.len,), generator=g).tolist() for _ in range(a.num_prompts)]
+    for sched in ("sync", "async"):
+        eng = PrefillOnlyEngine(cfg, PrefillOnlySchedulerConfig(max_model_len=max(a.len, 8), max_num_seqs=a.max_num_seqs,
+                                                                scheduling=sched), device="cuda:0")
+        eng.encode(prompts[: 2 * a.max_num_seqs])  # warm up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = eng.encode(prompts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.shutdown()
+        assert len(res) == a.num_prompts
+        print(f"{sched:5s}: {a.num_prompts / dt:8.1f} sequences/s  {a.num_prompts * a.len / dt:10.0f} tokens/s  "
+              f"({a.num_prompts} x {a.len} tokens, {a.max_num_seqs} per step, {dt * 1e3:.0f} ms)")
+
+
+if __name__ == "__main__":
+    main()
