@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
         dot += qs[d] * T::to_float(kb[(d / X) * block_size * X + (d % X)]);
       float x = dot * p.scale;
       x += (alibi != 0.f) ? alibi * (float)(tok - seq_len + 1) : 0.f;
+      // a token of a block this head does not attend: logit -FLT_MAX, no contribution
+      // (attention_kernels.cu:234-247)
+      if (p.bs_vert_stride > 1 && !blocksparse_attended(p, tok, seq_len, head, kvh, block_size)) x = -FLT_MAX;
       logits[tok - cs] = x;
       m_loc = fmaxf(m_loc, x);
     }
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
     m_run = m_new;
     float psum = 0.f;
     for (int i = threadIdx.x; i < ce - cs; i += blockDim.x) {
-      const float e = __expf(logits[i] - m_new);
+      const float e = logits[i] == -FLT_MAX ? 0.f : __expf(logits[i] - m_new);
       // probabilities are rounded to T before P.V (attention_kernels.cu:398-400)
       logits[i] = T::to_float(T::from_float(e));
       psum += e;
@@ -178,7 +181,8 @@ static int check_common(int num_seqs, int num_heads, int head_size, int num_kv_h
     LV_CHECK(head_size % 16 == 0, "fp8 kv cache: head size must be a multiple of 16");
     LV_CHECK(k_scale > 0.f && v_scale > 0.f, "fp8 kv cache: scales must be positive");
   }
-  LV_CHECK(blocksparse_vert_stride <= 1, "block-sparse attention is not built in this round");
+  LV_CHECK(blocksparse_vert_stride <= 1 || kv_dtype == LVLLM_KV_AUTO,
+           "block-sparse attention over an fp8 kv cache is not supported");
   LV_CHECK(block_size == 8 || block_size == 16 || block_size == 32,
            "Unsupported block size: " + std::to_string(block_size));
   LV_CHECK(mfma_head_size(head_size), "Unsupported head size: " + std::to_string(head_size));
@@ -198,11 +202,12 @@ extern "C" int lvllm_paged_attention_v1(
     int dtype, int kv_dtype, float k_scale, float v_scale, int tp_rank,
     int blocksparse_local_blocks, int blocksparse_vert_stride,
     int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
-  (void)tp_rank; (void)blocksparse_local_blocks; (void)blocksparse_block_size;
-  (void)blocksparse_head_sliding_step;
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
+  const bool bsparse = blocksparse_vert_stride > 1;
+  LV_CHECK(!bsparse || (blocksparse_block_size > 0 && blocksparse_block_size % block_size == 0),
+           "blocksparse_block_size must be a positive multiple of block_size");
   if (num_seqs == 0) return 0;
   if (max_num_blocks_per_seq <= 0) {
     // no block table at all: every context is empty, the result is zeros
@@ -211,6 +216,9 @@ extern "C" int lvllm_paged_attention_v1(
     return 0;
   }
   AttnParams p{};
+  p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
+  p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
+  p.tp_rank = tp_rank;
   p.out = out; p.exp_sums = nullptr; p.max_logits = nullptr;
   p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
@@ -226,9 +234,10 @@ extern "C" int lvllm_paged_attention_v1(
                       (kv_head_stride * kvb) % 16 == 0 && block_size >= 16;
   LV_CHECK(!p.kv_fp8 || vec_ok, "fp8 kv cache: operands must be 16-byte aligned");
   int rc = 0;
-  if (dtype == LVLLM_BF16 && vec_ok)
+  // block-sparse requests take the generic kernel (per-head masks; a niche of the reference's op)
+  if (dtype == LVLLM_BF16 && vec_ok && !bsparse)
     rc = launch_mfma_hs<BF16>(p, head_size, block_size, num_seqs, 1, max_seq_len, s);
-  else if (dtype == LVLLM_F16 && vec_ok)
+  else if (dtype == LVLLM_F16 && vec_ok && !bsparse)
     rc = launch_mfma_hs<F16>(p, head_size, block_size, num_seqs, 1, max_seq_len, s);
   else {
     LV_DISPATCH_DTYPE(dtype, rc = launch_generic<scalar_t>(p, head_size, block_size, num_seqs, 1, s));
@@ -249,11 +258,12 @@ extern "C" int lvllm_paged_attention_v2_phases(
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
     int blocksparse_head_sliding_step, int phases, void* stream) {
-  (void)tp_rank; (void)blocksparse_local_blocks; (void)blocksparse_block_size;
-  (void)blocksparse_head_sliding_step;
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
+  const bool bsparse = blocksparse_vert_stride > 1;
+  LV_CHECK(!bsparse || (blocksparse_block_size > 0 && blocksparse_block_size % block_size == 0),
+           "blocksparse_block_size must be a positive multiple of block_size");
   LV_CHECK((phases & ~3) == 0 && phases != 0, "phases must be 1 (partitions), 2 (reduce) or 3 (both)");
   LV_CHECK(max_num_partitions >= 1 &&
                (int64_t)max_num_partitions * kPartitionSize >= (int64_t)max_seq_len,
@@ -266,6 +276,9 @@ extern "C" int lvllm_paged_attention_v2_phases(
     return 0;
   }
   AttnParams p{};
+  p.bs_vert_stride = blocksparse_vert_stride; p.bs_local_blocks = blocksparse_local_blocks;
+  p.bs_block_size = blocksparse_block_size; p.bs_head_sliding_step = blocksparse_head_sliding_step;
+  p.tp_rank = tp_rank;
   p.out = tmp_out; p.exp_sums = exp_sums; p.max_logits = max_logits;
   p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
@@ -286,7 +299,7 @@ extern "C" int lvllm_paged_attention_v2_phases(
   // just enough shares, bounded by the caller's scratch (max_num_partitions slots per head)
   // and by a minimum of 4 tiles of work per share.
   const int G = num_heads / num_kv_heads;
-  const bool use_mfma = (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && vec_ok;
+  const bool use_mfma = (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && vec_ok && !bsparse;
   const int64_t pairs = use_mfma ? (int64_t)num_seqs * num_kv_heads * ((G + 15) / 16)
                                  : (int64_t)num_seqs * num_heads;
   const int64_t want = use_mfma ? (2048 + 8 * pairs - 1) / (8 * pairs) : (1024 + pairs - 1) / pairs;

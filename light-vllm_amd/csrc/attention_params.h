@@ -26,7 +26,22 @@ struct AttnParams {
   // element is T(float(fp8) * scale) (csrc/quantization/fp8/nvidia/quant_utils.cuh:295-300)
   int kv_fp8;
   float k_scale, v_scale;
+  // block-sparse attention (attention_kernels.cu:209-247): active when bs_vert_stride > 1.  A KV
+  // cache block is attended by a head iff (k + offset) % vert_stride == 0 ("remote") or
+  // k > q - local_blocks ("local"), k / q = the block-sparse block of the cache block / of the
+  // query, offset = (tp_rank * heads + head) * sliding_step + 1 (kv heads for a negative step).
+  int bs_vert_stride, bs_local_blocks, bs_block_size, bs_head_sliding_step, tp_rank;
 };
+
+__host__ __device__ inline bool blocksparse_attended(const AttnParams& p, int token, int seq_len, int head,
+                                                     int kv_head, int cache_block_size) {
+  const int q_bs = (seq_len - 1) / p.bs_block_size;
+  const int off = p.bs_head_sliding_step >= 0
+                      ? (p.tp_rank * p.num_heads + head) * p.bs_head_sliding_step + 1
+                      : (p.tp_rank * p.num_kv_heads + kv_head) * (-p.bs_head_sliding_step) + 1;
+  const int k_bs = (token / cache_block_size) * cache_block_size / p.bs_block_size;
+  return ((k_bs + off) % p.bs_vert_stride == 0) || (k_bs > q_bs - p.bs_local_blocks);
+}
 
 
 // Share `s` of a context of `seq_len` tokens cut into at most `num_splits` equal shares of

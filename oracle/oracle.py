@@ -108,6 +108,12 @@ def varlen_attention(out, query, key, value, cu_seqlens, scale, causal):
         _i(_DT[query.dtype]))
 
 
+def set_blocksparse(vert_stride=0, local_blocks=0, block_size=64, head_sliding_step=0, tp_rank=0):
+    """Block-sparse arguments of the attention oracles (off when vert_stride <= 1)."""
+    lib().oracle_set_blocksparse(_i(vert_stride), _i(local_blocks), _i(block_size), _i(head_sliding_step),
+                                 _i(tp_rank))
+
+
 def set_kv_cache_fp8(on, k_scale=1.0, v_scale=1.0):
     """kv_cache_dtype of the attention oracles: on = the caches hold OCP e4m3fn bytes."""
     lib().oracle_set_kv_cache_fp8(_i(1 if on else 0), _f(k_scale), _f(v_scale))

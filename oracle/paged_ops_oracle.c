@@ -156,6 +156,30 @@ void oracle_set_kv_cache_fp8(int on, float k_scale, float v_scale) {
   g_k_scale = k_scale;
   g_v_scale = v_scale;
 }
+/* block-sparse attention (attention_kernels.cu:209-247, 385-393): a cache block is attended by a
+ * head iff (k + offset) % vert_stride == 0 or k > q - local_blocks; skipped tokens get the logit
+ * -FLT_MAX and add nothing.  Off when vert_stride <= 1. */
+static int g_bs_vert = 0, g_bs_local = 0, g_bs_block = 64, g_bs_step = 0, g_tp_rank = 0;
+void oracle_set_blocksparse(int vert_stride, int local_blocks, int block_size, int head_sliding_step,
+                            int tp_rank) {
+  g_bs_vert = vert_stride;
+  g_bs_local = local_blocks;
+  g_bs_block = block_size;
+  g_bs_step = head_sliding_step;
+  g_tp_rank = tp_rank;
+}
+static int bs_attended(int token, int seq_len, int head, int kv_head, int num_heads, int num_kv_heads,
+                       int cache_block_size) {
+  if (g_bs_vert <= 1) return 1;
+  const int q_bs_block_id = (seq_len - 1) / g_bs_block;
+  const int bs_block_offset = g_bs_step >= 0 ? (g_tp_rank * num_heads + head) * g_bs_step + 1
+                                             : (g_tp_rank * num_kv_heads + kv_head) * (-g_bs_step) + 1;
+  const int k_bs_block_id = (token / cache_block_size) * cache_block_size / g_bs_block;
+  const int is_remote = ((k_bs_block_id + bs_block_offset) % g_bs_vert == 0);
+  const int is_local = (k_bs_block_id > q_bs_block_id - g_bs_local);
+  return is_remote || is_local;
+}
+
 static inline float ldkv(const void* cache, int dt, int64_t i, float scale) {
   if (!g_kv_fp8) return ld(cache, dt, i);
   return rnd(e4m3_to_f(((const uint8_t*)cache)[i]) * scale, dt);
@@ -184,6 +208,10 @@ uint16_t oracle_f32_to_bf16(float f) { return f_to_bf16(f); }
  * The reference's CPU kernel (csrc/cpu/attention.cpp:209-214,48-71) keeps fp32
  * probabilities and divides by sum (no 1e-6): a difference below 2^-8 relative.
  * ------------------------------------------------------------------------------- */
+/* the (head, head counts) of the attend_range call in progress on this thread: block-sparse masks
+ * depend on the head */
+static __thread int t_head = 0, t_num_heads = 1, t_num_kv_heads = 1;
+
 static void attend_range(const void* q, int64_t q_off, const void* k_cache, const void* v_cache,
                          const int32_t* block_table, int kv_head, int64_t kv_block_stride,
                          int64_t kv_head_stride, int head_size, int block_size, int x, float scale,
@@ -205,12 +233,14 @@ static void attend_range(const void* q, int64_t q_off, const void* k_cache, cons
     }
     float qk = scale * dot;
     qk += (alibi_slope != 0.f) ? alibi_slope * (float)(tok - seq_len + 1) : 0.f;
+    if (!bs_attended(tok, seq_len, t_head, kv_head, t_num_heads, t_num_kv_heads, block_size))
+      qk = -FLT_MAX; /* :241-247 */
     logits[i] = qk;
     qk_max = fmaxf(qk_max, qk);
   }
   float exp_sum = 0.f;
   for (int i = 0; i < n; ++i) {
-    logits[i] = expf(logits[i] - qk_max);
+    logits[i] = logits[i] == -FLT_MAX ? 0.f : expf(logits[i] - qk_max);
     exp_sum += logits[i];
   }
   const float inv_sum = 1.f / (exp_sum + 1e-6f);
@@ -251,6 +281,7 @@ void oracle_paged_attention_v1(void* out, const void* query, const void* key_cac
     for (int s = 0; s < num_seqs; ++s)
       for (int h = 0; h < num_heads; ++h) {
         float mx, sm;
+        t_head = h; t_num_heads = num_heads; t_num_kv_heads = num_kv_heads;
         attend_range(query, (int64_t)s * q_stride + (int64_t)h * head_size, key_cache, value_cache,
                      block_tables + (int64_t)s * max_num_blocks_per_seq, h / G, kv_block_stride,
                      kv_head_stride, head_size, block_size, x, scale,
@@ -440,6 +471,7 @@ void oracle_paged_attention_v2(void* out, float* exp_sums, float* max_logits, vo
           if (t0 >= seq_len) continue; /* :116-119 */
           const int t1 = t0 + PARTITION_SIZE < seq_len ? t0 + PARTITION_SIZE : seq_len;
           float mx, sm;
+          t_head = h; t_num_heads = num_heads; t_num_kv_heads = num_kv_heads;
           attend_range(query, (int64_t)s * q_stride + (int64_t)h * head_size, key_cache,
                        value_cache, block_tables + (int64_t)s * max_num_blocks_per_seq, h / G,
                        kv_block_stride, kv_head_stride, head_size, block_size, x, scale,

@@ -469,3 +469,59 @@ def test_advance_step_bit_exact(ops, num_seqs, num_queries, block_size):
     with pytest.raises(RuntimeError, match="is not as expected"):
         ops.advance_step(num_seqs, num_queries, block_size, got[0].int(), sampled.to(DEV), got[1], got[2], got[3],
                          block_tables.to(DEV))
+
+
+# ---------------------------------------------------------------- block-sparse attention
+def _blocksparse_fp64(inp, vert, local, bsz, step, tp_rank=0):
+    """Independent statement: a token counts for head h iff its cache block's block-sparse index k
+    satisfies (k + offset(h)) % vert == 0 or k > q - local (attention_kernels.cu:209-247)."""
+    q = inp["query"]
+    S, H, D = q.shape
+    KVH, BS = inp["num_kv_heads"], inp["block_size"]
+    out = torch.zeros(S, H, D, dtype=torch.float64)
+    for s in range(S):
+        k, v = inp["k_dense"][s].double(), inp["v_dense"][s].double()
+        n = k.shape[0]
+        if n == 0:
+            continue
+        tok = torch.arange(n)
+        k_bs = (tok // BS) * BS // bsz
+        q_bs = (n - 1) // bsz
+        for h in range(H):
+            kv = h // (H // KVH)
+            off = (tp_rank * H + h) * step + 1 if step >= 0 else (tp_rank * KVH + kv) * (-step) + 1
+            att = ((k_bs + off) % vert == 0) | (k_bs > q_bs - local)
+            logits = (k[:, kv] @ q[s, h].double()) * inp["scale"]
+            logits = logits.masked_fill(~att, float("-inf"))
+            out[s, h] = torch.softmax(logits, 0) @ v[:, kv]
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("vert,local,bsz,step", [(4, 2, 64, 1), (8, 1, 32, 0), (3, 4, 16, -1), (2, 1, 64, 2)])
+def test_blocksparse_attention(ops, dtype, version, vert, local, bsz, step):
+    lens = [700, 130, 64, 1, 17]
+    inp = make_paged_inputs(len(lens), 8, 2, 64, 16, lens, dtype=dtype, seed=vert + bsz)
+    oracle.set_blocksparse(vert, local, bsz, step, 1)
+    try:
+        want = torch.zeros_like(inp["query"])
+        oracle.paged_attention_v1(want, inp["query"], inp["key_cache"], inp["value_cache"], 2, inp["scale"],
+                                  inp["block_tables"], inp["seq_lens"], 16, max(lens))
+    finally:
+        oracle.set_blocksparse(0)
+    d = to_dev(inp)
+    out = torch.full_like(d["query"], float("nan"))
+    args = (d["query"], d["key_cache"], d["value_cache"], 2, inp["scale"], d["block_tables"], d["seq_lens"], 16,
+            max(lens), None, "auto", 1.0, 1.0, 1, local, vert, bsz, step)
+    if version == "v1":
+        ops.paged_attention_v1(out, *args)
+    else:
+        es, ml, tmp = v2_scratch(len(lens), 8, 64, max(lens), dtype, DEV)
+        ops.paged_attention_v2(out, es, ml, tmp, *args)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    check_attention(out, want, _blocksparse_fp64(inp, vert, local, bsz, step, tp_rank=1))
+    # and it differs from dense attention (the mask really bites)
+    dense = dense_attention_fp64(inp)
+    assert float((out.double().cpu() - dense).abs().max()) > 1e-3
