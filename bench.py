@@ -110,13 +110,22 @@ def kernel_leg(engine, B, iters):
     for i in range(8):
         launch(i, 1)
     torch.cuda.synchronize(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for i, (a, b) in enumerate(evs):
+    # HIP events on the launch stream around TRAINS of back-to-back launches, one layer's cache per
+    # launch: the per-launch average then carries the kernel and its launch gap, not the cost of
+    # recording two events per kernel (which added ~3 us to a 24 us kernel and made the figure
+    # disagree with rocprof's duration of the same kernel)
+    train = len(caches)
+    ntrains = max(2, iters // train)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ntrains)]
+    k = 0
+    for a, b in evs:
         a.record()
-        launch(i, 1)
+        for _ in range(train):
+            launch(k, 1)
+            k += 1
         b.record()
     torch.cuda.synchronize(dev)
-    ts = [a.elapsed_time(b) * 1e-3 for a, b in evs]  # seconds
+    ts = [a.elapsed_time(b) * 1e-3 / train for a, b in evs]  # seconds per launch
     avg = sum(ts) / len(ts)
     esz = 2
     algo_bytes = (2 * sum(lens) * KVH * D * (1 if kv_fp8 else esz) + 2 * len(seqs) * H * D * esz +
