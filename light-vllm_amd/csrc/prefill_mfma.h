@@ -33,6 +33,9 @@
 #ifndef LVLLM_PREFILL_EXP
 #define LVLLM_PREFILL_EXP 0
 #endif
+#ifndef LVLLM_PREFILL_WAVES_PER_SIMD
+#define LVLLM_PREFILL_WAVES_PER_SIMD 2  // 2: <= 256 VGPRs; 1: the 512-register body for large NB
+#endif
 #ifndef LVLLM_PREFILL_STAGES
 #define LVLLM_PREFILL_STAGES 3  // LDS stages of the LDSKV variant: copies run STAGES-1 pairs ahead
 #endif
@@ -69,7 +72,7 @@ struct PrefillParams {
 // quarter of the global-load instructions and of the L1 traffic of the register path, whose
 // per-wave K/V loads cost 45 % of its time.  Needs D % 32 == 0.
 template <typename T, int D, int BS, int NB, bool EXTRAS, bool LDSKV>
-__global__ __launch_bounds__(256, 2) void paged_prefill_mfma_kernel(const PrefillParams p) {
+__global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefill_mfma_kernel(const PrefillParams p) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
   static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");

@@ -247,8 +247,8 @@ class LLMEngine:
                 self._done_q.put(None)
                 return
             sched, ei = item
+            slot = self.free_slots.get()
             try:
-                slot = self.free_slots.get()
                 t0 = time.perf_counter()
                 stream = self.streams[slot]
                 with torch.cuda.stream(stream):
@@ -258,6 +258,7 @@ class LLMEngine:
                 out.execute_begin_ts = t0
                 self._done_q.put((slot, ev, sched, out))
             except Exception as e:  # surfaced on the engine thread (core/executor.py:59-60)
+                self.free_slots.put(slot)
                 self.executor_out.put(e)
 
     def _done_loop(self) -> None:

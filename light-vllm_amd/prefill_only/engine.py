@@ -143,14 +143,15 @@ class PrefillOnlyEngine:
                 self._done_q.put(None)
                 return
             sched, mi = item
+            slot = self.free_slots.get()
             try:
-                slot = self.free_slots.get()
                 with torch.cuda.stream(self.streams[slot]):
                     host = self._execute(mi)
                     ev = torch.cuda.Event()
                     ev.record(self.streams[slot])
                 self._done_q.put((slot, ev, sched, host, mi.seq_lens))
             except Exception as e:
+                self.free_slots.put(slot)
                 self.executor_out.put(e)
 
     def _done_loop(self) -> None:
