@@ -204,12 +204,47 @@ def make_prefill_only_vectors():
     print("prefill_only_attn.npz", len(cases), "cases")
 
 
+def make_sampler_vectors():
+    """Golden outputs of the reference's sampler front half (decoding/backends/sampler.py:
+    _apply_penalties :281-301, _apply_top_k_top_p :304-330, _apply_min_p :333-347) on random logits
+    and token histories (fp32, CPU)."""
+    import numpy as np
+    import torch
+    from oracle import ref_block_manager
+    ref_block_manager.load()
+    from light_vllm.decoding.backends import sampler as S
+    g = torch.Generator().manual_seed(77)
+    N, V = 6, 97
+    logits = torch.randn(N, V, generator=g) * 3
+    prompt = torch.randint(0, V, (N, 12), generator=g)
+    output = torch.randint(0, V, (N, 9), generator=g)
+    prompt[0, 8:] = V  # padding id
+    output[1, 3:] = V
+    pres = torch.tensor([0.0, 0.5, 1.0, 0.0, 0.3, 2.0])
+    freq = torch.tensor([0.0, 0.2, 0.0, 0.7, 0.1, 1.0])
+    rep = torch.tensor([1.0, 1.3, 1.0, 2.0, 0.8, 1.1])
+    out = {"logits": logits.numpy(), "prompt": prompt.numpy(), "output": output.numpy(), "pres": pres.numpy(),
+           "freq": freq.numpy(), "rep": rep.numpy()}
+    out["penalised"] = S._apply_penalties(logits.clone(), prompt, output, pres.clone(), freq.clone(), rep.clone()).numpy()
+    p = torch.tensor([1.0, 0.9, 0.5, 0.1, 0.99, 0.3])
+    k = torch.tensor([V, 10, V, 3, 1, 50])
+    out["top_p"], out["top_k"] = p.numpy(), k.numpy()
+    out["filtered"] = S._apply_top_k_top_p(logits.clone(), p, k).numpy()
+    mp = torch.tensor([0.0, 0.05, 0.2, 0.5, 0.01, 0.9])
+    out["min_p"] = mp.numpy()
+    out["min_p_out"] = S._apply_min_p(logits.clone(), mp.clone()).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "sampler_front_half.npz"), **out)
+    print("sampler_front_half.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only"]
+    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only", "sampler"]
     if "block_manager" in what:
         make_block_manager_traces()
     if "ops" in what:
         make_op_vectors()
     if "prefill_only" in what:
         make_prefill_only_vectors()
+    if "sampler" in what:
+        make_sampler_vectors()
