@@ -230,6 +230,17 @@ int lvllm_paged_prefill_attention(
     int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, void* stream);
 
+/* The same over an fp8 (e4m3fn) cache: kv_dtype = LVLLM_KV_FP8_E4M3 with its scales (head size a
+ * multiple of 64); lvllm_paged_prefill_attention is this with scales 1.0. */
+int lvllm_paged_prefill_attention_ex(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
+    int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream);
+
 /* Dense varlen attention without a KV cache: the encode-only / prefill-only path
  * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
  * cu_seqlens, causal=...); in-tree definition torch_naive.py:65-149).  query [T, num_heads, D],

@@ -68,13 +68,14 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
                             block_tables: torch.Tensor, seq_lens: torch.Tensor,
                             query_start_loc: torch.Tensor, max_query_len: int, block_size: int,
                             alibi_slopes: Optional[torch.Tensor] = None, sliding_window: int = 0,
-                            softcap: float = 0.0, kv_cache_dtype: str = "auto", causal: bool = True) -> None:
+                            softcap: float = 0.0, kv_cache_dtype: str = "auto", causal: bool = True,
+                            k_scale: float = 1.0, v_scale: float = 1.0) -> None:
     """Causal varlen attention of prompt chunks over the paged cache: the job of
     flash_attn_varlen_func(..., block_table=...) at flash_attn.py:538-555 of the reference."""
     torch.ops._C_amd.paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, scale,
                                              block_tables, seq_lens, query_start_loc, max_query_len,
                                              block_size, alibi_slopes, sliding_window, softcap,
-                                             kv_cache_dtype, causal)
+                                             kv_cache_dtype, causal, k_scale, v_scale)
 
 
 _VARLEN_WS = {}

@@ -349,7 +349,8 @@ class PagedAttnImpl:
         """With a cache: one launch of the HIP varlen kernel over the paged cache (the chunk's own
         K/V were written just before).  Without one (the memory-profiling run, kv_cache None,
         flash_attn.py:518-536): torch SDPA on the dense prompt."""
-        if (self.use_hip_prefill and key_cache is not None and self.kv_cache_dtype == "auto"
+        if (self.use_hip_prefill and key_cache is not None
+                and (self.kv_cache_dtype == "auto" or self.head_size % 64 == 0)
                 and q.dtype in (torch.float16, torch.bfloat16)
                 and value_cache.shape[3] in (16, 32) and meta.block_tables.numel() > 0
                 and self.sliding_window is None):

@@ -13,10 +13,27 @@ extern "C" int lvllm_paged_prefill_attention(
     int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
     int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, void* stream) {
+  return lvllm_paged_prefill_attention_ex(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                                          num_kv_heads, scale, block_tables, seq_lens, query_start_loc,
+                                          max_query_len, block_size, max_num_blocks_per_seq, alibi_slopes, causal,
+                                          sliding_window, softcap, q_stride, out_stride, kv_block_stride,
+                                          kv_head_stride, dtype, kv_dtype, 1.f, 1.f, stream);
+}
+
+extern "C" int lvllm_paged_prefill_attention_ex(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
+    int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream) {
   LV_CHECK(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
            "num_heads must be a positive multiple of num_kv_heads");
   LV_CHECK(dtype == LVLLM_F16 || dtype == LVLLM_BF16, "dtype must be float16 or bfloat16");
-  LV_CHECK(kv_dtype == LVLLM_KV_AUTO, "fp8 kv cache is not built in this round (kv_cache_dtype must be 'auto')");
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
+  LV_CHECK(kv_dtype == LVLLM_KV_FP8_E4M3 ? (k_scale > 0.f && v_scale > 0.f) : (k_scale == 1.f && v_scale == 1.f),
+           "k_scale / v_scale: positive with an fp8 cache, 1.0 otherwise");
   LV_CHECK(block_size == 16 || block_size == 32, "Unsupported block size: " + std::to_string(block_size));
   LV_CHECK(max_query_len >= 0 && max_num_blocks_per_seq >= 0, "negative sizes");
   LV_CHECK(causal || (alibi_slopes == nullptr && sliding_window <= 0),
@@ -24,8 +41,9 @@ extern "C" int lvllm_paged_prefill_attention(
   if (num_seqs == 0 || max_query_len == 0) return 0;
   LV_CHECK(max_num_blocks_per_seq > 0, "query tokens without a block table");
   LV_CHECK((((uintptr_t)query | (uintptr_t)out | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
-               (q_stride * 2) % 16 == 0 && (out_stride * 2) % 8 == 0 && (kv_block_stride * 2) % 16 == 0 &&
-               (kv_head_stride * 2) % 16 == 0,
+               (q_stride * 2) % 16 == 0 && (out_stride * 2) % 8 == 0 &&
+               (kv_block_stride * (kv_dtype == LVLLM_KV_AUTO ? 2 : 1)) % 16 == 0 &&
+               (kv_head_stride * (kv_dtype == LVLLM_KV_AUTO ? 2 : 1)) % 16 == 0,
            "operands must be 16-byte aligned");
   PrefillParams p{};
   p.out = out; p.q = query; p.k_cache = key_cache; p.v_cache = value_cache;
@@ -34,6 +52,7 @@ extern "C" int lvllm_paged_prefill_attention(
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.max_num_blocks_per_seq = max_num_blocks_per_seq;
   p.causal = causal ? 1 : 0;
+  p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   p.sliding_window = sliding_window; p.scale = scale; p.softcap = softcap;
   p.q_stride = q_stride; p.out_stride = out_stride;
   p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;

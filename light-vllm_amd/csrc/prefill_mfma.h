@@ -60,7 +60,9 @@ struct PrefillParams {
   int sliding_window;  // <= 0: none; else a query at position p sees keys p-w+1 .. p (causal only)
   float scale;
   float softcap;  // <= 0: none; else logits = cap * tanh(logits / cap)
-  int64_t q_stride, out_stride, kv_block_stride, kv_head_stride;
+  int64_t q_stride, out_stride, kv_block_stride, kv_head_stride;  // kv strides in cache elements
+  int kv_fp8;                // caches hold OCP e4m3fn bytes (x = 16 layouts); see attention_mfma.h KV8
+  float k_scale, v_scale;    // a dequantised element is T(float(fp8) * scale)
 };
 
 // Column layout of one 16-column MFMA block: column c = (query token c / GP, head c % GP) with
@@ -71,14 +73,19 @@ struct PrefillParams {
 // double buffered, one barrier per pair) and every wave reads its MFMA operands from there: a
 // quarter of the global-load instructions and of the L1 traffic of the register path, whose
 // per-wave K/V loads cost 45 % of its time.  Needs D % 32 == 0.
-template <typename T, int D, int BS, int NB, bool EXTRAS, bool LDSKV>
+// KV8 (with LDSKV only, D % 64 == 0): fp8 caches.  The tile images in LDS are the fp8 bytes (half the
+// copy and half the LDS); a K fragment read is 16 fp8 = two k-slices after conversion, a V piece 4
+// bytes; Q is loaded with the matching head-dim permutation, exactly as in the decode kernel's KV8.
+template <typename T, int D, int BS, int NB, bool EXTRAS, bool LDSKV, bool KV8 = false>
 __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefill_mfma_kernel(const PrefillParams p) {
+  static_assert(!KV8 || (LDSKV && D % 64 == 0), "fp8 caches: LDS path, head size a multiple of 64");
+  constexpr int KVB = KV8 ? 1 : 2;  // bytes per cache element
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
   static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
   constexpr int NS = (D + 31) / 32;
   constexpr int NDT = (D + 15) / 16;
-  constexpr int kHeadBytes = D * BS * 2;
+  constexpr int kHeadBytes = D * BS * KVB;
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr float kMasked = -FLT_MAX;
   constexpr float kMInit = -1e30f;  // > kMasked: exp2(kMasked - m) == 0 even before any key is seen
@@ -121,9 +128,9 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
   const int my_npairs = khi > (tile0 << 4) ? (khi - (tile0 << 4) + 31) >> 5 : 0;  // pairs computed
 
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
-  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
-  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * 2;
-  const int64_t bsb = p.kv_block_stride * 2;
+  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * KVB;
+  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * KVB;
+  const int64_t bsb = p.kv_block_stride * KVB;
   const int koff = (g * BS + c) * 16;
   const int voff = (c * BS + 4 * g) * 2;
 
@@ -144,9 +151,10 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
     const S* qrow = (const S*)p.q + (int64_t)(qbeg + t_first + t) * p.q_stride + (int64_t)(head0 + ch) * D;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      const int d8 = 4 * j + g;
+      // 16-bit caches: d = 32j + 8g ..; fp8 caches: d = 64(j>>1) + 16g + 8(j&1) .. (K chunks of 16 d)
+      const int d0 = KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g;
       qf[b][j] = u32x4_t{0, 0, 0, 0};
-      if (ok && d8 * 8 < D) qf[b][j] = *reinterpret_cast<const u32x4_t*>(qrow + d8 * 8);
+      if (ok && d0 < D) qf[b][j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
     }
   }
   const float alibi = (p.alibi_slopes != nullptr && head_ok) ? p.alibi_slopes[head0 + ch] * kLog2e : 0.f;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
   // ---- LDSKV: stage layout [K tile A | K tile B | V tile A | V tile B], each tile compact:
   // K [D/8][16 tok][16 B] (= the MFMA A-operand order: slice j of lane l at j*1024 + l*16),
   // V [D][16 tok][2 B] (piece of lane (g, c), d-tile t at t*512 + c*32 + g*8).
-  constexpr int kTile = D * 32;            // bytes of one K (or V) tile
+  constexpr int kTile = D * 16 * KVB;      // bytes of one K (or V) tile
   constexpr int kStage = 4 * kTile;
   constexpr int kStages = LVLLM_PREFILL_STAGES;
   constexpr int kLoadsPerTile = kTile / 1024;  // wave loads of 16 bytes per lane
@@ -239,6 +247,12 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
       voffset = lane * 16;
       step = 1024;
       soff0 = 0;
+    } else if (KV8) {
+      // fp8: K chunk (d16 = q / 16, tok = q % 16) at (d16 * BS + tok_off + tok) * 16; V chunk = row
+      // d = q, its 16 tokens at d * BS + tok_off
+      voffset = ld_kind == 0 ? (lane >> 4) * (BS * 16) + (lane & 15) * 16 : lane * BS;
+      step = ld_kind == 0 ? 4 * BS * 16 : 64 * BS;
+      soff0 = ld_kind == 0 ? tok_off * 16 : tok_off;
     } else if (ld_kind == 0) {
       voffset = (lane >> 4) * (BS * 16) + (lane & 15) * 16;
       step = 4 * BS * 16;
@@ -254,21 +268,48 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
                                                voffset, soff0 + i * step, 0, 0);
   };
+  const bool k_scaled = KV8 && p.k_scale != 1.f, v_scaled = KV8 && p.v_scale != 1.f;
   auto read_pair_k = [&](u32x4_t (&ka)[NS], u32x4_t (&kb)[NS], const int jp) __attribute__((always_inline)) {
     const char* st = kv_lds + (jp % kStages) * kStage + lane * 16;
+    if constexpr (KV8) {
 #pragma unroll
-    for (int jj = 0; jj < NS; ++jj) {
-      ka[jj] = *reinterpret_cast<const u32x4_t*>(st + jj * 1024);
-      kb[jj] = *reinterpret_cast<const u32x4_t*>(st + kTile + jj * 1024);
+      for (int i = 0; i < NS / 2; ++i) {
+        const u32x4_t wa = *reinterpret_cast<const u32x4_t*>(st + i * 1024);
+        const u32x4_t wb = *reinterpret_cast<const u32x4_t*>(st + kTile + i * 1024);
+        const u32x2_t a0 = dequant4<T>(wa.x, p.k_scale, k_scaled), a1 = dequant4<T>(wa.y, p.k_scale, k_scaled);
+        const u32x2_t a2 = dequant4<T>(wa.z, p.k_scale, k_scaled), a3 = dequant4<T>(wa.w, p.k_scale, k_scaled);
+        ka[2 * i] = u32x4_t{a0.x, a0.y, a1.x, a1.y};
+        ka[2 * i + 1] = u32x4_t{a2.x, a2.y, a3.x, a3.y};
+        const u32x2_t b0 = dequant4<T>(wb.x, p.k_scale, k_scaled), b1 = dequant4<T>(wb.y, p.k_scale, k_scaled);
+        const u32x2_t b2 = dequant4<T>(wb.z, p.k_scale, k_scaled), b3 = dequant4<T>(wb.w, p.k_scale, k_scaled);
+        kb[2 * i] = u32x4_t{b0.x, b0.y, b1.x, b1.y};
+        kb[2 * i + 1] = u32x4_t{b2.x, b2.y, b3.x, b3.y};
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) {
+        ka[jj] = *reinterpret_cast<const u32x4_t*>(st + jj * 1024);
+        kb[jj] = *reinterpret_cast<const u32x4_t*>(st + kTile + jj * 1024);
+      }
     }
   };
   auto read_pair_v = [&](u32x4_t (&v)[NDT], const int jp) __attribute__((always_inline)) {
-    const char* st = kv_lds + (jp % kStages) * kStage + 2 * kTile + c * 32 + g * 8;
+    if constexpr (KV8) {
+      const char* st = kv_lds + (jp % kStages) * kStage + 2 * kTile + c * 16 + g * 4;  // row 16t + c, tokens 4g..
 #pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-      const u32x2_t a = *reinterpret_cast<const u32x2_t*>(st + t * 512);
-      const u32x2_t b = *reinterpret_cast<const u32x2_t*>(st + kTile + t * 512);
-      v[t] = u32x4_t{a.x, a.y, b.x, b.y};
+      for (int t = 0; t < NDT; ++t) {
+        const u32x2_t a = dequant4<T>(*reinterpret_cast<const uint32_t*>(st + t * 256), p.v_scale, v_scaled);
+        const u32x2_t b = dequant4<T>(*reinterpret_cast<const uint32_t*>(st + kTile + t * 256), p.v_scale, v_scaled);
+        v[t] = u32x4_t{a.x, a.y, b.x, b.y};
+      }
+    } else {
+      const char* st = kv_lds + (jp % kStages) * kStage + 2 * kTile + c * 32 + g * 8;
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(st + t * 512);
+        const u32x2_t b = *reinterpret_cast<const u32x2_t*>(st + kTile + t * 512);
+        v[t] = u32x4_t{a.x, a.y, b.x, b.y};
+      }
     }
   };
 
@@ -523,17 +564,26 @@ static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_quer
   const dim3 grid(p.num_kv_heads * HG, num_seqs, qtiles);
   if constexpr (D % 32 == 0) {
     if (tuning().prefill_lds) {
-      constexpr size_t smem = (size_t)LVLLM_PREFILL_STAGES * 4 * D * 32;  // stages of [K A | K B | V A | V B]
+      const size_t smem = (size_t)LVLLM_PREFILL_STAGES * 4 * D * 16 * (p.kv_fp8 ? 1 : 2);  // [K A | K B | V A | V B]
       auto launch = [&](auto kern) {
         if (smem > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
       };
+      if constexpr (D % 64 == 0) {
+        if (p.kv_fp8) {
+          if (extras) launch(paged_prefill_mfma_kernel<T, D, BS, NB, true, true, true>);
+          else launch(paged_prefill_mfma_kernel<T, D, BS, NB, false, true, true>);
+          return 0;
+        }
+      }
+      LV_CHECK(!p.kv_fp8, "fp8 kv cache: the prefill kernel needs a head size that is a multiple of 64");
       if (extras) launch(paged_prefill_mfma_kernel<T, D, BS, NB, true, true>);
       else launch(paged_prefill_mfma_kernel<T, D, BS, NB, false, true>);
       return 0;
     }
   }
+  LV_CHECK(!p.kv_fp8, "fp8 kv cache: the prefill kernel needs the LDS path and a head size multiple of 64");
   if (extras)
     hipLaunchKernelGGL((paged_prefill_mfma_kernel<T, D, BS, NB, true, false>), grid, dim3(256), 0, stream, p);
   else

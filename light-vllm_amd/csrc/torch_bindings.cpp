@@ -368,9 +368,12 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
                              const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
                              const torch::Tensor& query_start_loc, int64_t max_query_len, int64_t block_size,
                              const c10::optional<torch::Tensor>& alibi_slopes, int64_t sliding_window,
-                             double softcap, const std::string& kv_cache_dtype, bool causal) {
+                             double softcap, const std::string& kv_cache_dtype, bool causal, double k_scale,
+                             double v_scale) {
   LV_CHECK_DEVICE(query);
   LV_CHECK_DEVICE(out);
+  check_cache_dtype(key_cache, query, kv_dtype_code(kv_cache_dtype), "paged_prefill_attention");
+  check_cache_dtype(value_cache, query, kv_dtype_code(kv_cache_dtype), "paged_prefill_attention");
   TORCH_CHECK(query.dim() == 3 && out.dim() == 3, "paged_prefill_attention: query/out must be [T, H, D]");
   TORCH_CHECK(query.stride(2) == 1 && query.stride(1) == query.size(2) && out.stride(2) == 1 &&
                   out.stride(1) == out.size(2),
@@ -384,14 +387,14 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
   TORCH_CHECK(value_cache.size(3) == block_size, "paged_prefill_attention: block_size does not match the cache");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
   const float* alibi = alibi_slopes.has_value() ? alibi_slopes->data_ptr<float>() : nullptr;
-  check(lvllm_paged_prefill_attention(
+  check(lvllm_paged_prefill_attention_ex(
       out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs,
       (int)query.size(1), (int)query.size(2), (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(),
       seq_lens.data_ptr<int32_t>(), query_start_loc.data_ptr<int32_t>(), (int)max_query_len, (int)block_size,
       (int)block_tables.size(1), alibi, causal ? 1 : 0, (int)sliding_window, (float)softcap, query.stride(0),
       out.stride(0),
       key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_prefill_attention"),
-      kv_dtype_code(kv_cache_dtype), current_stream(query)));
+      kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale, current_stream(query)));
 }
 
 int64_t varlen_attention_workspace_bytes(int64_t num_tokens, int64_t num_seqs, int64_t max_seq_len,
@@ -662,7 +665,7 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
           "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
-          "str kv_cache_dtype, bool causal=True) -> ()");
+          "str kv_cache_dtype, bool causal=True, float k_scale=1.0, float v_scale=1.0) -> ()");
   amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
   amd.def("skinny_linear_w8a8(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
           "Tensor? bias) -> Tensor");

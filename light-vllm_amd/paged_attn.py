@@ -127,7 +127,8 @@ class PagedAttention:
                        context_lens: Optional[torch.Tensor], max_query_len: int,
                        alibi_slopes: Optional[torch.Tensor], sliding_window: Optional[int],
                        scale: Optional[float] = None, softcap: float = 0.0,
-                       kv_cache_dtype: str = "auto", output: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       kv_cache_dtype: str = "auto", output: Optional[torch.Tensor] = None,
+                       k_scale: float = 1.0, v_scale: float = 1.0) -> torch.Tensor:
         """Prompt chunks against the paged cache (paged_attn.py:194-225 of the reference, which
         runs the Triton context_attention_fwd; the live backend calls flash_attn_varlen_func with
         block_table, flash_attn.py:538-555).  query [T, H, D]; `key`/`value` of the chunk must
@@ -142,7 +143,7 @@ class PagedAttention:
         ops.paged_prefill_attention(output, query, key_cache, value_cache, num_kv_heads, scale,
                                     block_tables, seq_lens_tensor, query_start_loc, max_query_len,
                                     value_cache.shape[3], alibi_slopes, sliding_window or 0, softcap,
-                                    kv_cache_dtype)
+                                    kv_cache_dtype, True, k_scale, v_scale)
         return output
 
     @staticmethod

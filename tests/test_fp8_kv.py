@@ -319,3 +319,32 @@ def test_skinny_w8a8_vs_dequantised_matmul(ops, dtype, M, N, K):
     err = (y.cpu().double() - want).abs().max().item()
     tol = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * max(1.0, want.abs().max().item())
     assert err <= tol, (err, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("head_size,H,KVH", [(128, 8, 2), (64, 4, 4), (256, 4, 1), (192, 6, 2)])
+def test_fp8_prefill_over_the_paged_cache(ops, dtype, block_size, head_size, H, KVH):
+    """Chunked prefill / prefix hits over an fp8 cache: the LDS prefill kernel's KV8 instantiation
+    against the oracle (dequantised element = T(fp8 * scale)) and fp64 over the dequantised values."""
+    from helpers import dense_prefill_fp64, make_prefill_inputs
+    from test_ops_gpu import check_attention
+    seq, ql = [37, 200, 5, 129, 64], [37, 40, 5, 129, 17]
+    inp = make_prefill_inputs(H, KVH, head_size, block_size, seq, ql, dtype=dtype, seed=head_size + block_size)
+    twin = quantize_paged_inputs_fp8(inp, 0.5, 2.0)
+    want = torch.zeros_like(twin["query"])
+    oracle.set_kv_cache_fp8(True, 0.5, 2.0)
+    try:
+        oracle.paged_prefill_attention(want, twin["query"], twin["key_cache"], twin["value_cache"], KVH, twin["scale"],
+                                       twin["block_tables"], twin["seq_lens"], twin["query_start_loc"], block_size)
+    finally:
+        oracle.set_kv_cache_fp8(False)
+    out = torch.full_like(twin["query"], float("nan")).to(DEV)
+    ops.paged_prefill_attention(out, twin["query"].to(DEV), twin["key_cache"].to(DEV), twin["value_cache"].to(DEV),
+                                KVH, twin["scale"], twin["block_tables"].to(DEV), twin["seq_lens"].to(DEV),
+                                twin["query_start_loc"].to(DEV), max(ql), block_size, None, 0, 0.0, "fp8", True,
+                                0.5, 2.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    check_attention(out, want, dense_prefill_fp64(twin))

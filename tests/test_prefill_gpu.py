@@ -159,7 +159,7 @@ def test_prefill_argument_errors(ops):
                                     d["block_tables"], d["seq_lens"], d["query_start_loc"], 20, 16,
                                     None, 0, 0.0, "fp8")
     with pytest.raises(RuntimeError, match="float16 or bfloat16"):
-        ops.paged_prefill_attention(out.float(), d["query"].float(), d["key_cache"], d["value_cache"], 2, 1.0,
+        ops.paged_prefill_attention(out.float(), d["query"].float(), d["key_cache"].float(), d["value_cache"].float(), 2, 1.0,
                                     d["block_tables"], d["seq_lens"], d["query_start_loc"], 20, 16,
                                     None, 0, 0.0, "auto")
 
