@@ -208,6 +208,15 @@ int lvllm_rotary_embedding_and_cache(
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, void* stream);
 
+/* ... and into an fp8 (e4m3fn, x = 16) cache: the rotated key and the value are quantised with their
+ * scales on the way in (as lvllm_reshape_and_cache with kv_dtype FP8_E4M3 would after the rotation). */
+int lvllm_rotary_embedding_and_cache_ex(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream);
+
 /* Causal varlen attention of prompt chunks over the paged cache: prefill, chunked prefill and
  * prefix-cache hits.  Replaces the reference's third-party call
  *   flash_attn_varlen_func(q, key_cache, value_cache, cu_seqlens_q=query_start_loc,

@@ -78,21 +78,7 @@ __global__ void reshape_and_cache_fp8_kernel(
     const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
     const int64_t value_stride, const float k_scale, const float v_scale) {
   const int chunks_per_token = chunks_per_head * num_heads;
-  auto quant4 = [](float a, float b, float c, float d, float scale) -> uint32_t {
-    auto sat = [scale](float v) {
-      v = v / scale;
-      return fabsf(v) > 448.f ? copysignf(448.f, v) : v;  // NaN compares false and passes through
-    };
-    const float sa = sat(a), sb = sat(b), sc = sat(c), sd = sat(d);
-    uint32_t w = __builtin_amdgcn_cvt_pk_fp8_f32(sa, sb, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(sc, sd, w, true);
-    // NaN -> the one code 0x7f whatever sign the division left on it
-    if (sa != sa) w = (w & 0xffffff00u) | 0x0000007fu;
-    if (sb != sb) w = (w & 0xffff00ffu) | 0x00007f00u;
-    if (sc != sc) w = (w & 0xff00ffffu) | 0x007f0000u;
-    if (sd != sd) w = (w & 0x00ffffffu) | 0x7f000000u;
-    return w;
-  };
+  auto quant4 = [](float a, float b, float c, float d, float scale) { return fp8_kv_quant4(a, b, c, d, scale); };
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < num_chunks;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t token = idx / chunks_per_token;

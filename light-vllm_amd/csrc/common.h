@@ -81,6 +81,24 @@ struct BF16 {
   }
 };
 
+// 4 floats -> 4 fp8 (OCP e4m3fn) in one dword: fp8(x / scale), saturating at +-448, NaN -> 0x7f
+// (the store side of an fp8 KV cache: csrc/cache_kernels.cu:194-202,
+// fp8/nvidia/quant_utils.cuh:458-489; round to nearest even by v_cvt_pk_fp8_f32)
+__device__ inline uint32_t fp8_kv_quant4(float a, float b, float c, float d, float scale) {
+  auto sat = [scale](float v) {
+    v = v / scale;
+    return fabsf(v) > 448.f ? copysignf(448.f, v) : v;  // NaN compares false and passes through
+  };
+  const float sa = sat(a), sb = sat(b), sc = sat(c), sd = sat(d);
+  uint32_t w = __builtin_amdgcn_cvt_pk_fp8_f32(sa, sb, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(sc, sd, w, true);
+  if (sa != sa) w = (w & 0xffffff00u) | 0x0000007fu;
+  if (sb != sb) w = (w & 0xffff00ffu) | 0x00007f00u;
+  if (sc != sc) w = (w & 0xff00ffffu) | 0x007f0000u;
+  if (sd != sd) w = (w & 0x00ffffffu) | 0x7f000000u;
+  return w;
+}
+
 // 16-byte vector of storage elements
 template <typename T>
 struct Vec16 {

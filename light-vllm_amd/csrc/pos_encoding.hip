@@ -98,17 +98,32 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
 // RoPE in place on q and k with the roundings above, and in the same pass the rotated k row and
 // the v row are scattered into the paged caches at slot_mapping[token] (layouts of
 // csrc/cache_kernels.cu:184-192).  rot_dim == head_size, 16-bit types, 16-byte aligned rows.
-template <typename T, bool IS_NEOX>
+// KV8: the caches hold fp8 (e4m3fn) with x = 16; the rotated key (already rounded to T, as the two
+// separate launches would see it) and the value are quantised with fp8_kv_quant4 on the way in.
+template <typename T, bool IS_NEOX, bool KV8>
 __global__ void rotary_embedding_and_cache_kernel(
     const int64_t* __restrict__ positions, typename T::store_t* __restrict__ query,
     typename T::store_t* __restrict__ key, const typename T::store_t* __restrict__ value,
-    const typename T::store_t* __restrict__ cos_sin_cache, typename T::store_t* __restrict__ key_cache,
-    typename T::store_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
+    const typename T::store_t* __restrict__ cos_sin_cache, void* __restrict__ key_cache_v,
+    void* __restrict__ value_cache_v, const int64_t* __restrict__ slot_mapping,
     const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
-    const int num_kv_heads, const int head_size, const int block_size) {
+    const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale) {
   using S = typename T::store_t;
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
+  S* key_cache = reinterpret_cast<S*>(key_cache_v);
+  S* value_cache = reinterpret_cast<S*>(value_cache_v);
+  uint8_t* key_cache8 = reinterpret_cast<uint8_t*>(key_cache_v);
+  uint8_t* value_cache8 = reinterpret_cast<uint8_t*>(value_cache_v);
+  // 8 elements of head `head` starting at d (a multiple of 8) -> their 8 bytes inside the x = 16 chunk
+  auto store_k8 = [&](const V& x, const int head, const int d) {
+    uint8_t* dst = key_cache8 + (((slot_mapping[blockIdx.x] / block_size) * num_kv_heads + head) * (head_size / 16) + d / 16) *
+                                    (int64_t)block_size * 16 + (slot_mapping[blockIdx.x] % block_size) * 16 + (d % 16);
+    uint2 q;
+    q.x = fp8_kv_quant4(T::to_float(x.v[0]), T::to_float(x.v[1]), T::to_float(x.v[2]), T::to_float(x.v[3]), k_scale);
+    q.y = fp8_kv_quant4(T::to_float(x.v[4]), T::to_float(x.v[5]), T::to_float(x.v[6]), T::to_float(x.v[7]), k_scale);
+    *reinterpret_cast<uint2*>(dst) = q;
+  };
   const int64_t token = blockIdx.x;
   const int64_t pos = positions[token];
   const int embed_dim = head_size / 2;
@@ -139,8 +154,13 @@ __global__ void rotary_embedding_and_cache_kernel(
         *reinterpret_cast<V*>(base + u * N) = x;
         *reinterpret_cast<V*>(base + embed_dim + u * N) = y;
         if (is_k && slot >= 0) {  // chunk d8 = u holds x', chunk d8 = D/16 + u holds y'
-          *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = x;
-          *reinterpret_cast<V*>(kc + (int64_t)(embed_dim / N + u) * block_size * N) = y;
+          if constexpr (KV8) {
+            store_k8(x, head, u * N);
+            store_k8(y, head, embed_dim + u * N);
+          } else {
+            *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = x;
+            *reinterpret_cast<V*>(kc + (int64_t)(embed_dim / N + u) * block_size * N) = y;
+          }
         }
       } else {
         V xy = *reinterpret_cast<const V*>(base + u * N);
@@ -150,15 +170,31 @@ __global__ void rotary_embedding_and_cache_kernel(
           rotate<T>(xy.v[2 * e], xy.v[2 * e + 1], cos_ptr[r], sin_ptr[r]);
         }
         *reinterpret_cast<V*>(base + u * N) = xy;
-        if (is_k && slot >= 0) *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = xy;
+        if (is_k && slot >= 0) {
+          if constexpr (KV8) store_k8(xy, head, u * N);
+          else *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = xy;
+        }
       }
     } else if (slot >= 0) {
       const int j = i - nq - nk;
       const int head = j / cph, ch = j - head * cph;
       const V v = *reinterpret_cast<const V*>(value + token * value_stride + (int64_t)head * head_size + ch * N);
-      S* vdst = value_cache + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
+      if constexpr (KV8) {
+        uint8_t* vdst = value_cache8 + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
 #pragma unroll
-      for (int e = 0; e < N; ++e) vdst[(int64_t)e * block_size] = v.v[e];
+        for (int e = 0; e < N; e += 4) {
+          const uint32_t w = fp8_kv_quant4(T::to_float(v.v[e]), T::to_float(v.v[e + 1]), T::to_float(v.v[e + 2]),
+                                           T::to_float(v.v[e + 3]), v_scale);
+          vdst[(int64_t)(e + 0) * block_size] = (uint8_t)w;
+          vdst[(int64_t)(e + 1) * block_size] = (uint8_t)(w >> 8);
+          vdst[(int64_t)(e + 2) * block_size] = (uint8_t)(w >> 16);
+          vdst[(int64_t)(e + 3) * block_size] = (uint8_t)(w >> 24);
+        }
+      } else {
+        S* vdst = value_cache + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
+#pragma unroll
+        for (int e = 0; e < N; ++e) vdst[(int64_t)e * block_size] = v.v[e];
+      }
     }
   }
 }
@@ -219,7 +255,23 @@ extern "C" int lvllm_rotary_embedding_and_cache(
     int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, void* stream) {
+  return lvllm_rotary_embedding_and_cache_ex(positions, query, key, value, num_tokens, num_heads, num_kv_heads,
+                                             head_size, rot_dim, query_stride, key_stride, value_stride,
+                                             cos_sin_cache, is_neox, key_cache, value_cache, slot_mapping,
+                                             block_size, dtype, LVLLM_KV_AUTO, 1.f, 1.f, stream);
+}
+
+extern "C" int lvllm_rotary_embedding_and_cache_ex(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    void* stream) {
   if (num_tokens == 0) return 0;
+  LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
+  const bool kv8 = kv_dtype == LVLLM_KV_FP8_E4M3;
+  LV_CHECK(kv8 ? (k_scale > 0.f && v_scale > 0.f) : (k_scale == 1.f && v_scale == 1.f),
+           "k_scale / v_scale: positive with an fp8 cache, 1.0 otherwise");
   const bool ok = (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && rot_dim == head_size && head_size % 16 == 0 &&
                   (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)cos_sin_cache |
                     (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
@@ -231,16 +283,21 @@ extern "C" int lvllm_rotary_embedding_and_cache(
   const int units = (num_heads + num_kv_heads) * (is_neox ? head_size / 16 : head_size / 8) + num_kv_heads * head_size / 8;
   int threads = ((units + 63) / 64) * 64;
   threads = threads > 512 ? 512 : threads;
-#define LV_RC(T_, NEOX_)                                                                                   \
-  hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_>), dim3(num_tokens), dim3(threads), 0,   \
+#define LV_RC(T_, NEOX_, KV8_)                                                                              \
+  hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_, KV8_>), dim3(num_tokens), dim3(threads), 0, \
                      (hipStream_t)stream, positions, (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value, \
-                     (const uint16_t*)cos_sin_cache, (uint16_t*)key_cache, (uint16_t*)value_cache, slot_mapping, \
-                     query_stride, key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size)
-  if (dtype == LVLLM_BF16) {
-    if (is_neox) LV_RC(BF16, true); else LV_RC(BF16, false);
-  } else {
-    if (is_neox) LV_RC(F16, true); else LV_RC(F16, false);
-  }
+                     (const uint16_t*)cos_sin_cache, key_cache, value_cache, slot_mapping, query_stride,      \
+                     key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size, k_scale, v_scale)
+#define LV_RC_N(T_)                                   \
+  do {                                                \
+    if (is_neox) {                                    \
+      if (kv8) LV_RC(T_, true, true); else LV_RC(T_, true, false);   \
+    } else {                                          \
+      if (kv8) LV_RC(T_, false, true); else LV_RC(T_, false, false); \
+    }                                                 \
+  } while (0)
+  if (dtype == LVLLM_BF16) LV_RC_N(BF16); else LV_RC_N(F16);
+#undef LV_RC_N
 #undef LV_RC
   LV_LAUNCH_CHECK();
   return 0;

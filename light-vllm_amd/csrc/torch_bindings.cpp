@@ -345,19 +345,22 @@ void fused_add_rms_norm_splitk(torch::Tensor& out, torch::Tensor& residual, cons
 bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, torch::Tensor& key,
                                 const torch::Tensor& value, int64_t head_size, torch::Tensor& cos_sin_cache,
                                 bool is_neox, torch::Tensor& key_cache, torch::Tensor& value_cache,
-                                const torch::Tensor& slot_mapping) {
+                                const torch::Tensor& slot_mapping, const std::string& kv_cache_dtype,
+                                double k_scale, double v_scale) {
   LV_CHECK_DEVICE(query);
   TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
-  if (key_cache.scalar_type() != query.scalar_type() || value_cache.scalar_type() != query.scalar_type())
-    return false;  // quantised cache: outside the fused kernel's envelope
+  const int kv_code = kv_dtype_code(kv_cache_dtype);
+  check_cache_dtype(key_cache, query, kv_code, "rotary_embedding_and_cache");
+  check_cache_dtype(value_cache, query, kv_code, "rotary_embedding_and_cache");
   const int64_t num_tokens = query.numel() / query.size(-1);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
-  const int rc = lvllm_rotary_embedding_and_cache(
+  const int rc = lvllm_rotary_embedding_and_cache_ex(
       positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(), (int)num_tokens,
       (int)(query.size(-1) / head_size), (int)(key.size(-1) / head_size), (int)head_size,
       (int)cos_sin_cache.size(1), query.stride(-2), key.stride(-2), value.stride(-2), cos_sin_cache.data_ptr(),
       is_neox ? 1 : 0, key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
-      (int)value_cache.size(3), dtype_code(query, "rotary_embedding_and_cache"), current_stream(query));
+      (int)value_cache.size(3), dtype_code(query, "rotary_embedding_and_cache"), kv_code, (float)k_scale,
+      (float)v_scale, current_stream(query));
   if (rc == 3) return false;
   check(rc);
   return true;
@@ -660,7 +663,7 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("fused_add_rms_norm_splitk", torch::kCUDA, &fused_add_rms_norm_splitk);
   amd.def("rotary_embedding_and_cache(Tensor positions, Tensor! query, Tensor! key, Tensor value, "
           "int head_size, Tensor cos_sin_cache, bool is_neox, Tensor! key_cache, Tensor! value_cache, "
-          "Tensor slot_mapping) -> bool");
+          "Tensor slot_mapping, str kv_cache_dtype=\"auto\", float k_scale=1.0, float v_scale=1.0) -> bool");
   amd.impl("rotary_embedding_and_cache", torch::kCUDA, &rotary_embedding_and_cache);
   amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
           "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "

@@ -194,10 +194,10 @@ class DecoderModel:
             fused = False
             if decode_only:
                 key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
-            if decode_only and key_cache.dtype == q.dtype:  # (an fp8 cache takes the two separate ops)
+            if decode_only:
                 fused = torch.ops._C_amd.rotary_embedding_and_cache(
                     positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
-                    attn_metadata.slot_mapping)
+                    attn_metadata.slot_mapping, self.attn.kv_cache_dtype, 1.0, 1.0)
             if fused:
                 attn_out = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata)
             else:

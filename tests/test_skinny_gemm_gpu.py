@@ -74,6 +74,19 @@ def test_fused_decode_ops_are_bit_identical_to_the_unfused_sequence(ops, dtype):
         assert torch.ops._C_amd.rotary_embedding_and_cache(pos, qb, kb, vb, D, cache, neox, kc_b, vc_b, slots)
         for x, y in ((a, b), (kc_a, kc_b), (vc_a, vc_b)):
             assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+        # the same into an fp8 cache: rope, then reshape_and_cache(fp8) == the fused launch with kv "fp8"
+        kc8 = torch.randint(0, 255, (NB, KVH, D // 16, BS, 16), generator=g, device=DEV, dtype=torch.uint8)
+        vc8 = torch.randint(0, 255, (NB, KVH, D, BS), generator=g, device=DEV, dtype=torch.uint8)
+        kc8_a, vc8_a, kc8_b, vc8_b = kc8.clone(), vc8.clone(), kc8.clone(), vc8.clone()
+        a8, b8 = qkv.clone(), qkv.clone()
+        qa, ka, va = a8.split([H * D, KVH * D, KVH * D], dim=-1)
+        ops.rotary_embedding(pos, qa, ka, D, cache, neox)
+        ops.reshape_and_cache(ka.view(T, KVH, D), va.view(T, KVH, D), kc8_a, vc8_a, slots, "fp8", 0.5, 1.7)
+        qb, kb, vb = b8.split([H * D, KVH * D, KVH * D], dim=-1)
+        assert torch.ops._C_amd.rotary_embedding_and_cache(pos, qb, kb, vb, D, cache, neox, kc8_b, vc8_b, slots,
+                                                           "fp8", 0.5, 1.7)
+        assert torch.equal(a8.view(torch.int16), b8.view(torch.int16))
+        assert torch.equal(kc8_a, kc8_b) and torch.equal(vc8_a, vc8_b)
     # SwiGLU + down projection + add + norm
     gate_up = (torch.randn(T, 2 * inter, generator=g, device=DEV)).to(dtype)
     w = (torch.randn(hid, inter, generator=g, device=DEV) * 0.02).to(dtype)
