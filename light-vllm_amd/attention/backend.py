@@ -344,6 +344,24 @@ class PagedAttnImpl:
                                       force_version="v1" if use_v1 else "v2", scratch=scratch, output=out)
         return out.view(num_tokens, hidden_size)
 
+    def unified_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                          block_tables: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
+                          max_query_len: int) -> torch.Tensor:
+        """Every sequence of a mixed step as a chunk of query_len >= 1 tokens over its paged context
+        (a decode token is a chunk of one): one launch of the prefill kernel with device-side
+        metadata only, so a mixed step can be captured into a HIP graph.  K/V of all tokens must
+        already be in the cache."""
+        num_tokens, hidden_size = query.shape
+        q = query.view(-1, self.num_heads, self.head_size)
+        out = torch.zeros_like(q)  # rows of padding tokens belong to no sequence: keep them finite
+        alibi = self.alibi_slopes
+        if alibi is not None and alibi.device != q.device:
+            alibi = self.alibi_slopes = alibi.to(q.device)
+        PagedAttention.forward_prefix(q, None, None, key_cache, value_cache, block_tables, query_start_loc,
+                                      seq_lens, None, max_query_len, alibi, None, scale=self.scale,
+                                      kv_cache_dtype=self.kv_cache_dtype, output=out)
+        return out.view(num_tokens, hidden_size)
+
     # ---- prompt attention ----
     def _prefill(self, q, k, v, key_cache, value_cache, meta: PagedAttnMetadata, out) -> None:
         """With a cache: one launch of the HIP varlen kernel over the paged cache (the chunk's own

@@ -83,6 +83,74 @@ class DecodeGraph:
         return self.next_tokens
 
 
+class MixedGraph:
+    """One captured graph for every mixed step (prompt chunks + decode tokens) of at most `max_tokens`
+    tokens in at most `max_seqs` sequences.  Everything the step depends on is data in static device
+    buffers -- token ids, positions, slot mapping, block tables, sequence lengths, query_start_loc and
+    the rows to sample -- because the prefill kernel takes all of it from the device; padding tokens
+    write no cache (slot -1) and padding sequences own no tokens."""
+
+    def __init__(self, model, kv_caches: List[torch.Tensor], max_tokens: int, max_seqs: int,
+                 max_blocks_per_seq: int, block_size: int, device):
+        self.model, self.kv_caches = model, kv_caches
+        self.max_tokens, self.max_seqs = max_tokens, max_seqs
+        self.max_blocks_per_seq, self.block_size = max_blocks_per_seq, block_size
+        dev = torch.device(device)
+        self.input_ids = torch.zeros(max_tokens, dtype=torch.int64, device=dev)
+        self.positions = torch.zeros(max_tokens, dtype=torch.int64, device=dev)
+        self.slot_mapping = torch.full((max_tokens,), -1, dtype=torch.int64, device=dev)
+        self.block_tables = torch.zeros(max_seqs, max_blocks_per_seq, dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(max_seqs, dtype=torch.int32, device=dev)
+        self.query_start_loc = torch.zeros(max_seqs + 1, dtype=torch.int32, device=dev)
+        self.sample_rows = torch.zeros(max_seqs, dtype=torch.int64, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.next_tokens: Optional[torch.Tensor] = None
+
+    def _step(self):
+        unified = (self.block_tables, self.seq_lens, self.query_start_loc, self.max_tokens, self.slot_mapping)
+        hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, None, unified=unified)
+        logits = self.model.compute_logits(hidden[self.sample_rows])
+        return torch.argmax(logits, dim=-1)
+
+    def capture(self) -> None:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
+            self.next_tokens = self._step()
+        torch.cuda.synchronize()
+
+    def fits(self, num_tokens: int, num_seqs: int, table_width: int) -> bool:
+        return (num_tokens <= self.max_tokens and num_seqs <= self.max_seqs
+                and table_width <= self.max_blocks_per_seq)
+
+    def load(self, input_ids, positions, slot_mapping, block_tables, seq_lens, query_start_loc,
+             sample_indices: List[int]) -> None:
+        n, ns = input_ids.shape[0], seq_lens.shape[0]
+        self.input_ids[:n].copy_(input_ids, non_blocking=True)
+        self.positions[:n].copy_(positions, non_blocking=True)
+        self.slot_mapping[:n].copy_(slot_mapping, non_blocking=True)
+        self.slot_mapping[n:].fill_(-1)
+        self.seq_lens[:ns].copy_(seq_lens, non_blocking=True)
+        self.seq_lens[ns:].zero_()
+        self.query_start_loc[:ns + 1].copy_(query_start_loc, non_blocking=True)
+        self.query_start_loc[ns + 1:].fill_(n)  # padding sequences own no tokens
+        self.block_tables[:ns, :block_tables.shape[1]].copy_(block_tables, non_blocking=True)
+        rows = torch.tensor(sample_indices + [0] * (self.max_seqs - len(sample_indices)), dtype=torch.int64)
+        if torch.cuda.is_available():
+            rows = rows.pin_memory()
+        self.sample_rows.copy_(rows, non_blocking=True)
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.next_tokens
+
+
 class DecodeGraphPool:
     """One captured graph per padded batch size (powers of two and multiples of 8)."""
 
@@ -90,6 +158,7 @@ class DecodeGraphPool:
         self.model, self.kv_caches = model, kv_caches
         self.max_blocks_per_seq, self.block_size, self.device = max_blocks_per_seq, block_size, device
         self.graphs: Dict[int, DecodeGraph] = {}
+        self.mixed: Optional[MixedGraph] = None
 
     @staticmethod
     def padded(batch_size: int) -> int:
@@ -99,6 +168,13 @@ class DecodeGraphPool:
                 p *= 2
             return p
         return (batch_size + 7) // 8 * 8
+
+    def get_mixed(self, max_tokens: int, max_seqs: int) -> MixedGraph:
+        if self.mixed is None:
+            self.mixed = MixedGraph(self.model, self.kv_caches, max_tokens, max_seqs, self.max_blocks_per_seq,
+                                    self.block_size, self.device)
+            self.mixed.capture()
+        return self.mixed
 
     def get(self, batch_size: int) -> DecodeGraph:
         p = self.padded(batch_size)

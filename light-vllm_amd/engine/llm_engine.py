@@ -46,7 +46,8 @@ class Worker:
 
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, attn_backend,
                  device: str, use_hip_graph: bool = True, decode_version: Optional[str] = None,
-                 max_model_len: int = 8192, seed: int = 0, num_slots: int = 1):
+                 max_model_len: int = 8192, seed: int = 0, num_slots: int = 1, mixed_graph_tokens: int = 0,
+                 mixed_graph_seqs: int = 0):
         self.device = torch.device(device)
         self.model_config = model_config
         self.cache_config = cache_config
@@ -63,6 +64,8 @@ class Worker:
         # one graph pool (own static input buffers) per execution slot: steps in flight on
         # different streams must not share them
         self.num_slots = max(1, num_slots)
+        # > 0: mixed (chunked-prefill) steps of at most this many tokens / sequences replay one graph
+        self.mixed_graph_tokens, self.mixed_graph_seqs = mixed_graph_tokens, mixed_graph_seqs
         self.graph_pools: Optional[List[DecodeGraphPool]] = None
         # tests: keep the logits of the sampled rows of the last eager step
         self.capture_logits = False
@@ -111,6 +114,15 @@ class Worker:
             tokens = g.replay()[:mi.input_tokens.shape[0]]
             if len(mi.sample_indices) != mi.input_tokens.shape[0]:
                 tokens = tokens[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
+        elif (graphs is not None and self.mixed_graph_tokens > 0 and not self.capture_logits
+              and mi.input_tokens.shape[0] <= self.mixed_graph_tokens
+              and md.seq_lens_tensor.shape[0] <= self.mixed_graph_seqs
+              and md.block_tables.shape[0] == md.seq_lens_tensor.shape[0]
+              and 0 < md.block_tables.shape[1] <= graphs.max_blocks_per_seq):
+            g = graphs.get_mixed(self.mixed_graph_tokens, self.mixed_graph_seqs)
+            g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor,
+                   md.query_start_loc, mi.sample_indices)
+            tokens = g.replay()[:len(mi.sample_indices)]
         else:
             mi.to(self.device)
             hidden = self.model.forward(mi.input_tokens, mi.input_positions, ce.gpu_cache, md)
@@ -138,8 +150,16 @@ class LLMEngine:
         # each needs its own graph static buffers
         self.num_slots = (max(1, scheduler_config.max_num_on_the_fly)
                           if scheduler_config.scheduling in ("async", "double_buffer") else 1)
+        # chunked prefill with a token budget the decode GEMM takes (<= 64 rows): mixed steps replay a graph
+        mixed = (scheduler_config.chunked_prefill_enabled and scheduler_config.max_num_batched_tokens <= 64
+                 and cache_config.sliding_window is None and model_config.fuse_decode_ops
+                 and cache_config.block_size in (16, 32)
+                 and (cache_config.cache_dtype == "auto" or model_config.head_dim % 64 == 0))
         self.worker = Worker(model_config, cache_config, self.attn_backend, device, use_hip_graph,
-                             decode_version, scheduler_config.max_model_len, seed, num_slots=self.num_slots)
+                             decode_version, scheduler_config.max_model_len, seed, num_slots=self.num_slots,
+                             mixed_graph_tokens=scheduler_config.max_num_batched_tokens if mixed else 0,
+                             mixed_graph_seqs=min(scheduler_config.max_num_seqs,
+                                                  scheduler_config.max_num_batched_tokens) if mixed else 0)
         # with steps on several streams every decode GEMM takes half the CUs and leaves the rest
         # to the other step's kernel (measured: +10 % tokens/s at two steps in flight)
         torch.ops._C_amd.set_tuning("gemm_workgroups", 128 if self.num_slots > 1 else 256)

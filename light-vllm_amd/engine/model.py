@@ -172,14 +172,20 @@ class DecoderModel:
         return x
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor,
-                kv_caches: Optional[List[torch.Tensor]], attn_metadata) -> torch.Tensor:
+                kv_caches: Optional[List[torch.Tensor]], attn_metadata, unified=None) -> torch.Tensor:
+        """`unified` = (block_tables, seq_lens, query_start_loc, max_query_len, slot_mapping): the step is
+        a mix of prompt chunks and decode tokens with all of its metadata on the device (a captured
+        mixed step): rope + cache write fused, attention by the prefill kernel over every sequence."""
         cfg = self.cfg
         hidden = F.embedding(input_ids, self.embed)
         T = hidden.shape[0]
         # decode-only steps take the fused launches: rope + cache write in one kernel, split-K
         # partials of the down projection summed inside the next add+norm
-        decode_only = (cfg.fuse_decode_ops and kv_caches is not None and T <= 64 and
-                       attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
+        decode_only = unified is not None or (
+            cfg.fuse_decode_ops and kv_caches is not None and T <= 64 and
+            attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
+        slot_mapping = unified[4] if unified is not None else (
+            attn_metadata.slot_mapping if attn_metadata is not None else None)
         residual = None
         for i, lw in enumerate(self.layers):
             if residual is None:  # qwen2.py:203-208
@@ -197,8 +203,12 @@ class DecoderModel:
             if decode_only:
                 fused = torch.ops._C_amd.rotary_embedding_and_cache(
                     positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
-                    attn_metadata.slot_mapping, self.attn.kv_cache_dtype, 1.0, 1.0)
-            if fused:
+                    slot_mapping, self.attn.kv_cache_dtype, 1.0, 1.0)
+            if unified is not None:
+                assert fused, "a captured mixed step needs the fused rope + cache write"
+                attn_out = self.attn.unified_attention(q, key_cache, value_cache, unified[0], unified[1],
+                                                       unified[2], unified[3])
+            elif fused:
                 attn_out = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata)
             else:
                 ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin_cache, True)

@@ -356,3 +356,23 @@ def test_llama_width_two_layer_model_matches_dense_reference(dtype, tol):
                 assert torch.allclose(row, want, atol=tol * scale + 1e-3, rtol=tol), (i, (row - want).abs().max(), scale)
     same = sum(toks[False][k] == toks[True][k] for k in toks[False])
     assert same >= len(ps) - 1, (toks[False], toks[True])
+
+
+def test_mixed_steps_replay_one_graph():
+    """Chunked prefill under a 48-token budget with HIP graphs on: every mixed step (prompt chunks +
+    decode tokens) replays ONE captured graph whose attention is the prefill kernel over all
+    sequences (a decode token = a chunk of one), all metadata in static device buffers.  Tokens
+    against the eager chunked run (same schedule, near-ties may flip late) and the dense forward."""
+    eager = make_engine(graph=False, chunked=True, budget=48)
+    graph = make_engine(graph=True, chunked=True, budget=48)
+    assert graph.worker.mixed_graph_tokens == 48
+    te = run_to_completion(eager)
+    tg = run_to_completion(graph)
+    assert graph.worker.graph_pools[0].mixed is not None and graph.worker.graph_pools[0].mixed.graph is not None
+    assert sum(a == b for a, b in zip(te, tg)) >= len(te) - 1
+    for a, b in zip(te, tg):
+        assert a[:4] == b[:4]
+    ps = prompts()
+    for i, p in enumerate(ps):
+        ref = dense_reference_logits(graph.worker.model, p + tg[i])
+        assert int(ref[len(p) - 1].argmax()) == tg[i][0]
