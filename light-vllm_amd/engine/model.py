@@ -184,8 +184,7 @@ class DecoderModel:
         decode_only = unified is not None or (
             cfg.fuse_decode_ops and kv_caches is not None and T <= 64 and
             attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
-        slot_mapping = unified[4] if unified is not None else (
-            attn_metadata.slot_mapping if attn_metadata is not None else None)
+        slot_mapping = unified[4] if unified is not None else getattr(attn_metadata, "slot_mapping", None)
         residual = None
         for i, lw in enumerate(self.layers):
             if residual is None:  # qwen2.py:203-208
