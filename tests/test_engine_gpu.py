@@ -273,7 +273,7 @@ def test_engine_stress_every_request_finishes(v2, prefix_caching, mode):
         n = int(torch.randint(1, 200, (1,), generator=g))
         body = torch.randint(0, 512, (n,), generator=g).tolist()
         reqs.append(((shared + body) if i % 3 == 0 else body, int(torch.randint(8, 24, (1,), generator=g))))
-    kw = dict(graph=mode == "async", v2=v2, prefix_caching=prefix_caching, num_blocks=72, max_seqs=16)
+    kw = dict(graph=mode in ("async", "chunked"), v2=v2, prefix_caching=prefix_caching, num_blocks=72, max_seqs=16)
     if mode == "chunked":
         kw.update(chunked=True, budget=64)
     if mode == "swap":
