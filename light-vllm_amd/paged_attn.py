@@ -21,16 +21,20 @@ _NUM_CUS = 256
 
 @dataclass
 class PagedAttentionMetadata:
-    """Metadata for PagedAttention (paged_attn.py:17-31 of the reference)."""
-    # (batch_size,). The length of sequences (entire tokens seen so far) per sequence.
+    """What a decode launch needs besides the tensors (paged_attn.py:17-31 of the reference):
+    per-sequence lengths [batch], the longest of them (0 for a prompt-only batch), and the block
+    table [batch, max blocks per sequence]."""
     seq_lens_tensor: Optional[torch.Tensor]
-    # Maximum sequence length in the batch. 0 if it is prefill-only batch.
     max_decode_seq_len: int
-    # (batch_size, max_blocks_per_seq). Block addresses per sequence.
     block_tables: Optional[torch.Tensor]
 
 
+def _ceil_div(a: int, b: int) -> int:
+    return -(-a // b)
+
+
 class PagedAttention:
+    """Static helpers only, as in the reference: the class is a namespace."""
 
     @staticmethod
     def get_supported_head_sizes() -> List[int]:
@@ -39,86 +43,66 @@ class PagedAttention:
     @staticmethod
     def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int,
                            head_size: int) -> Tuple[int, ...]:
+        # one tensor per layer: plane 0 = keys, plane 1 = values, a block's elements flattened
         return (2, num_blocks, block_size * num_kv_heads * head_size)
 
     @staticmethod
     def split_kv_cache(kv_cache: torch.Tensor, num_kv_heads: int,
                        head_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The two planes as the kernels address them: K [NB, KVH, D/x, BS, x] with x = 16 bytes
+        worth of elements (8 for 16-bit types, 16 for an fp8 cache), V [NB, KVH, D, BS]."""
+        keys, values = kv_cache[0], kv_cache[1]
+        nb = kv_cache.shape[1]
         x = 16 // kv_cache.element_size()
-        num_blocks = kv_cache.shape[1]
-        key_cache = kv_cache[0].view(num_blocks, num_kv_heads, head_size // x, -1, x)
-        value_cache = kv_cache[1].view(num_blocks, num_kv_heads, head_size, -1)
-        return key_cache, value_cache
+        return keys.view(nb, num_kv_heads, head_size // x, -1, x), values.view(nb, num_kv_heads, head_size, -1)
 
     @staticmethod
     def write_to_paged_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
                              value_cache: torch.Tensor, slot_mapping: torch.Tensor,
                              kv_cache_dtype: str, k_scale: float, v_scale: float) -> None:
-        ops.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping.flatten(),
-                              kv_cache_dtype, k_scale, v_scale)
+        ops.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping.flatten(), kv_cache_dtype,
+                              k_scale, v_scale)
 
     @staticmethod
     def use_v1(num_seqs: int, num_kv_heads: int, num_heads: int, max_seq_len: int) -> bool:
-        max_num_partitions = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
-        head_groups = (num_heads // num_kv_heads + 15) // 16
-        workgroups_v1 = num_seqs * num_kv_heads * head_groups
-        return max_num_partitions == 1 or workgroups_v1 >= _NUM_CUS
+        """One pass (v1) when the (sequence, kv head, head group) grid alone fills the CUs or the
+        context fits a single partition; otherwise v2 cuts the contexts."""
+        if _ceil_div(max_seq_len, _PARTITION_SIZE) == 1:
+            return True
+        groups_per_kv_head = _ceil_div(num_heads // num_kv_heads, 16)
+        return num_seqs * num_kv_heads * groups_per_kv_head >= _NUM_CUS
 
     @staticmethod
-    def forward_decode(
-        query: torch.Tensor,
-        key_cache: torch.Tensor,
-        value_cache: torch.Tensor,
-        block_tables: torch.Tensor,
-        seq_lens: torch.Tensor,
-        max_seq_len: int,
-        kv_cache_dtype: str,
-        num_kv_heads: int,
-        scale: float,
-        alibi_slopes: Optional[torch.Tensor],
-        k_scale: float,
-        v_scale: float,
-        tp_rank: int = 0,
-        blocksparse_local_blocks: int = 0,
-        blocksparse_vert_stride: int = 0,
-        blocksparse_block_size: int = 64,
-        blocksparse_head_sliding_step: int = 0,
-        force_version: Optional[str] = None,
-        scratch: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
-        output: Optional[torch.Tensor] = None,
-    ) -> torch.Tensor:
-        if output is None:
-            output = torch.empty_like(query)
-        block_size = value_cache.shape[3]
+    def forward_decode(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                       block_tables: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int,
+                       kv_cache_dtype: str, num_kv_heads: int, scale: float,
+                       alibi_slopes: Optional[torch.Tensor], k_scale: float, v_scale: float,
+                       tp_rank: int = 0, blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64, blocksparse_head_sliding_step: int = 0,
+                       force_version: Optional[str] = None,
+                       scratch: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+                       output: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """query [num_seqs, H, D] -> output of the same shape.  `force_version` ("v1" | "v2") overrides
+        the heuristic; `scratch` = (exp_sums, max_logits, tmp_out) lets a caller reuse the v2 buffers
+        (shapes of paged_attn.py:156-166 of the reference)."""
+        out = torch.empty_like(query) if output is None else output
         num_seqs, num_heads, head_size = query.shape
-        max_num_partitions = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
-        if force_version is None:
-            v1 = PagedAttention.use_v1(num_seqs, num_kv_heads, num_heads, max_seq_len)
-        else:
-            v1 = force_version == "v1"
-        if v1:
-            ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
-                                   block_tables, seq_lens, block_size, max_seq_len, alibi_slopes,
-                                   kv_cache_dtype, k_scale, v_scale, tp_rank,
-                                   blocksparse_local_blocks, blocksparse_vert_stride,
-                                   blocksparse_block_size, blocksparse_head_sliding_step)
-        else:
-            if scratch is None:
-                # scratch shapes as paged_attn.py:156-166 of the reference
-                tmp_output = torch.empty(size=(num_seqs, num_heads, max_num_partitions, head_size),
-                                         dtype=output.dtype, device=output.device)
-                exp_sums = torch.empty(size=(num_seqs, num_heads, max_num_partitions),
-                                       dtype=torch.float32, device=output.device)
-                max_logits = torch.empty_like(exp_sums)
-            else:
-                exp_sums, max_logits, tmp_output = scratch
-            ops.paged_attention_v2(output, exp_sums, max_logits, tmp_output, query, key_cache,
-                                   value_cache, num_kv_heads, scale, block_tables, seq_lens,
-                                   block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
-                                   v_scale, tp_rank, blocksparse_local_blocks,
-                                   blocksparse_vert_stride, blocksparse_block_size,
-                                   blocksparse_head_sliding_step)
-        return output
+        tail = (kv_cache_dtype, k_scale, v_scale, tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+                blocksparse_block_size, blocksparse_head_sliding_step)
+        common = (query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                  value_cache.shape[3], max_seq_len, alibi_slopes)
+        single_pass = (force_version == "v1") if force_version is not None else \
+            PagedAttention.use_v1(num_seqs, num_kv_heads, num_heads, max_seq_len)
+        if single_pass:
+            ops.paged_attention_v1(out, *common, *tail)
+            return out
+        if scratch is None:
+            parts = _ceil_div(max_seq_len, _PARTITION_SIZE)
+            exp_sums = torch.empty((num_seqs, num_heads, parts), dtype=torch.float32, device=out.device)
+            scratch = (exp_sums, torch.empty_like(exp_sums),
+                       torch.empty((num_seqs, num_heads, parts, head_size), dtype=out.dtype, device=out.device))
+        ops.paged_attention_v2(out, scratch[0], scratch[1], scratch[2], *common, *tail)
+        return out
 
     @staticmethod
     def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
@@ -149,11 +133,9 @@ class PagedAttention:
     @staticmethod
     def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
                     src_to_dst: torch.Tensor) -> None:
-        ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)
-        ops.swap_blocks(src_kv_cache[1], dst_kv_cache[1], src_to_dst)
+        for plane in (0, 1):  # keys, then values
+            ops.swap_blocks(src_kv_cache[plane], dst_kv_cache[plane], src_to_dst)
 
     @staticmethod
     def copy_blocks(kv_caches: List[torch.Tensor], src_to_dists: torch.Tensor) -> None:
-        key_caches = [kv_cache[0] for kv_cache in kv_caches]
-        value_caches = [kv_cache[1] for kv_cache in kv_caches]
-        ops.copy_blocks(key_caches, value_caches, src_to_dists)
+        ops.copy_blocks([c[0] for c in kv_caches], [c[1] for c in kv_caches], src_to_dists)

@@ -50,35 +50,35 @@ class PrefillOnlyRequestOutput:
                 f"prompt_token_ids={self.prompt_token_ids}, finished={self.finished})")
 
 
-@dataclass
 class PrefillOnlySchedulingBudget:
-    token_budget: int
-    max_num_requests: int
-    _curr_requests: Set[str] = field(default_factory=set)
-    _num_batched_tokens: int = 0
+    """What one scheduling pass may still admit: prompt tokens and requests.  A request is
+    charged once however often it is offered (prefill_only/scheduler.py:14-43 of the reference)."""
 
-    def can_schedule(self, *, num_new_tokens: int, num_new_request: int = 1) -> bool:
-        assert num_new_tokens != 0
-        assert num_new_request != 0
-        return (self.num_batched_tokens + num_new_tokens <= self.token_budget
-                and self.num_curr_request + num_new_request <= self.max_num_requests)
-
-    def add_num_batched_tokens(self, req_id: str, num_batched_tokens: int) -> None:
-        if req_id in self._curr_requests:
-            return
-        self._curr_requests.add(req_id)
-        self._num_batched_tokens += num_batched_tokens
+    def __init__(self, token_budget: int, max_num_requests: int):
+        self.token_budget, self.max_num_requests = token_budget, max_num_requests
+        self._charged = {}  # request id -> tokens
 
     @property
     def num_batched_tokens(self) -> int:
-        return self._num_batched_tokens
+        return sum(self._charged.values())
 
     @property
     def num_curr_request(self) -> int:
-        return len(self._curr_requests)
+        return len(self._charged)
+
+    def can_schedule(self, *, num_new_tokens: int, num_new_request: int = 1) -> bool:
+        assert num_new_tokens != 0 and num_new_request != 0
+        tokens_ok = self.num_batched_tokens + num_new_tokens <= self.token_budget
+        return tokens_ok and self.num_curr_request + num_new_request <= self.max_num_requests
+
+    def add_num_batched_tokens(self, req_id: str, num_batched_tokens: int) -> None:
+        self._charged.setdefault(req_id, num_batched_tokens)
 
 
 class PrefillOnlyScheduler:
+    """Waiting queue + the set of live request ids.  Aborts are lazy: an aborted id is dropped
+    when the queue reaches it, or filtered out of the outputs of a step already in flight
+    (light_vllm/core/scheduler.py:14-89)."""
     support_scheduling = ["sync_scheduling", "async_scheduling"]
 
     def __init__(self, scheduler_config, request_processor: Optional[Callable[[Request], SchedulableRequest]] = None):
@@ -88,63 +88,61 @@ class PrefillOnlyScheduler:
         self.requests: Set[str] = set()
         self.aborted_requests: Set[str] = set()
 
-    # ---- light_vllm/core/scheduler.py ----
     def add_request(self, request: Request) -> None:
-        if request.request_id in self.requests or request.request_id in self.aborted_requests:
-            return  # request_id conflict (the reference logs a warning)
+        rid = request.request_id
+        if rid in self.requests or rid in self.aborted_requests:
+            return  # duplicate id: the reference warns and drops it
+        self.requests.add(rid)
         self.waiting.append(request)
-        self.requests.add(request.request_id)
 
     def abort_request(self, request_id: Union[str, Iterable[str]]) -> None:
-        if isinstance(request_id, str):
-            request_id = (request_id,)
-        request_ids = set(request_id)
-        self.requests -= request_ids
-        self.aborted_requests |= request_ids
+        ids = {request_id} if isinstance(request_id, str) else set(request_id)
+        self.aborted_requests |= ids
+        self.requests -= ids
 
     def remove_abort_request(self, request_outputs: List[PrefillOnlyRequestOutput]) -> List[PrefillOnlyRequestOutput]:
-        if not self.aborted_requests:
-            return request_outputs
-        need_abort = self.aborted_requests & {r.request_id for r in request_outputs}
-        if not need_abort:
-            return request_outputs
-        self.aborted_requests -= need_abort
-        return [r for r in request_outputs if r.request_id not in need_abort]
+        hit = self.aborted_requests.intersection(r.request_id for r in request_outputs)
+        if hit:
+            self.aborted_requests -= hit
+            request_outputs = [r for r in request_outputs if r.request_id not in hit]
+        return request_outputs
 
     def has_unfinished_requests(self) -> bool:
-        return len(self.requests) != 0
+        return bool(self.requests)
 
     def get_num_unfinished_requests(self) -> int:
         return len(self.requests)
 
     def free_finished_request(self, request_outputs) -> None:
-        self.requests -= {r.request_id for r in request_outputs if r.finished}
+        self.requests.difference_update(r.request_id for r in request_outputs if r.finished)
 
-    # ---- light_vllm/prefill_only/scheduler.py:57-100 ----
     def schedule(self) -> PrefillOnlySchedulerOutput:
-        budget = PrefillOnlySchedulingBudget(token_budget=self.scheduler_config.max_num_batched_tokens,
-                                             max_num_requests=self.scheduler_config.max_num_seqs)
-        waiting_queue = self.waiting
-        scheduled_requests: List[SchedulableRequest] = []
-        ignored_requests: List[SchedulableRequest] = []
-        while waiting_queue:
-            request = waiting_queue[0]
-            if request.request_id in self.aborted_requests:
-                self.aborted_requests.remove(request.request_id)
-                waiting_queue.popleft()
+        """One pass in arrival order (prefill_only/scheduler.py:57-100 of the reference): stop at the
+        first prompt that does not fit the token / request budget; prompts over max_model_len
+        are returned as ignored and forgotten."""
+        cfg = self.scheduler_config
+        budget = PrefillOnlySchedulingBudget(cfg.max_num_batched_tokens, cfg.max_num_seqs)
+        admitted: List[SchedulableRequest] = []
+        too_long: List[SchedulableRequest] = []
+        queue = self.waiting
+        while queue:
+            head = queue[0]
+            rid = head.request_id
+            if rid in self.aborted_requests:
+                self.aborted_requests.discard(rid)
+                queue.popleft()
                 continue
-            if not isinstance(request, SchedulableRequest):
-                request = self.request_processor(request)
-                waiting_queue[0] = request
-            num_new_tokens = request.num_new_tokens
-            if num_new_tokens > self.scheduler_config.max_model_len:
-                self.requests.remove(request.request_id)
-                waiting_queue.popleft()
-                ignored_requests.append(request)
-                continue
-            if not budget.can_schedule(num_new_tokens=num_new_tokens):
+            if not isinstance(head, SchedulableRequest):  # tokenise once, keep the result queued
+                head = queue[0] = self.request_processor(head)
+            n = head.num_new_tokens
+            if n > cfg.max_model_len:
+                queue.popleft()
+                self.requests.remove(rid)
+                too_long.append(head)
+            elif budget.can_schedule(num_new_tokens=n):
+                queue.popleft()
+                budget.add_num_batched_tokens(rid, n)
+                admitted.append(head)
+            else:
                 break
-            budget.add_num_batched_tokens(request.request_id, num_new_tokens)
-            waiting_queue.popleft()
-            scheduled_requests.append(request)
-        return PrefillOnlySchedulerOutput(scheduled_requests=scheduled_requests, ignored_requests=ignored_requests)
+        return PrefillOnlySchedulerOutput(scheduled_requests=admitted, ignored_requests=too_long)
