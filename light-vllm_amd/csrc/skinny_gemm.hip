@@ -55,6 +55,16 @@ __device__ __forceinline__ g_f32x4_t gemm_mfma_fp8(uint32_t a0, uint32_t a1, uin
 }
 
 constexpr int kGemmWaves = 8;
+#ifdef LVLLM_GEMM_TRACE  // diagnosis build only (tools/trace_gemm.py): per-workgroup phase timestamps
+__device__ unsigned long long g_gemm_trace[8 * 4096];
+#define GEMM_TRACE(p)                                                                     \
+  do {                                                                                    \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024)                  \
+      g_gemm_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (p)] = wall_clock64();     \
+  } while (0)
+#else
+#define GEMM_TRACE(p)
+#endif
 constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load returns 0
 #ifndef LVLLM_GEMM_AUX
 #define LVLLM_GEMM_AUX 2  // nt: weights are read once per launch
@@ -79,6 +89,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles,
     const float* __restrict__ x_scale, const float* __restrict__ w_scale) {
   using S = typename T::store_t;
+  GEMM_TRACE(0);
   const float out_scale = W8 ? x_scale[0] * w_scale[0] : 1.f;
   constexpr int HALF = KSTEPS / 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -103,14 +114,31 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2);
 
   const int my_tiles_ld = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // Loads that must return zeros (k-steps past K, tiles past the workgroup's last) get an offset of
+  // ~0: out of the descriptor's range, no memory access, no branch.  The masks are wave-uniform
+  // and passed through an empty asm: when the compiler can see the conditions it turns the
+  // selects into control flow -- two arms of loads writing the same registers with
+  // s_waitcnt vmcnt(0) between them, which left two loads in flight per wave instead of sixteen.
+  auto opaque = [](unsigned v) __attribute__((always_inline)) {
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    asm("" : "+s"(v));
+    return v;
+  };
+  unsigned kmask[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) kmask[s] = opaque(s < nvalid ? 0u : ~0u);
   auto load_unit = [&](g_u32x4_t (&a)[HALF], const int i, const int h) __attribute__((always_inline)) {
-    const int t = blockIdx.x + i * gridDim.x;  // n-tile; h: which half of the wave's k-steps
-    const bool row_ok = i < my_tiles_ld && 16 * t + c < N;
+    const int t = blockIdx.x + i * gridDim.x;  // n-tile (N is a multiple of 16: valid as a whole)
+    const unsigned tmask = opaque(i < my_tiles_ld ? 0u : ~0u);
     const unsigned base = lane_off + (unsigned)t * tile_stride;
 #pragma unroll
     for (int s = 0; s < HALF; ++s) {
-      const int ks = h * HALF + s;
-      const unsigned off = (row_ok && ks < nvalid) ? base + (unsigned)ks * step_stride : kOutOfRange;
+      const int ks = h * HALF + s;  // h: which half of the wave's k-steps
+#if defined(LVLLM_GEMM_EXP) && LVLLM_GEMM_EXP == 2  // diagnosis: no weight stream
+      const unsigned off = kOutOfRange;
+#else
+      const unsigned off = (base + (unsigned)ks * step_stride) | tmask | kmask[ks];
+#endif
       a[s] = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, LVLLM_GEMM_AUX);
     }
   };
@@ -222,60 +250,119 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   // after it is consumed, so 8-16 KiB per wave stay in flight, 16 KiB across a wave meeting
   // (the meeting otherwise drains the memory pipeline: measured 2.4 us per meeting).
   g_u32x4_t a0[HALF], a1[HALF];
-  load_unit(a0, 0, 0);
-  load_unit(a1, 0, 1);
-  // the first weight loads (HBM) are in flight before the activations (L2) are requested
   // ---- X fragments: X[m = 16 mt + c][k = 32 (step0 + s) + 8 g ..], kept for the whole launch ----
+  // Read in fragment order, lane (g, c) fetches 16 bytes of row c: a wave-wide load then touches 64
+  // separate 16-byte pieces, the texture addresser takes ~64 clocks for it, and with 256 such
+  // loads per workgroup the activations (256 KiB out of L2) cost as much as a 33 MB weight stream
+  // (tools/trace_gemm.py: 6.5 us of a 15 us o_proj).  So the plain 16-bit path reads ROW order --
+  // 64 lanes x 16 bytes = whole 256/512-byte row segments, all of a wave's loads in flight at once,
+  // landing in the registers that will hold the fragments -- and turns each (m-tile, k-half) pass
+  // into fragment order through a wave-private 4/8 KiB LDS scratch.  Chunk q of row r sits at
+  // position q ^ r, so the 16 rows of a fragment read hit 16 different bank groups.
+  bool staged = false;
+  if constexpr (!W8) {
+    if (act == 0) {
+      staged = true;
+      constexpr int NCH = HALF * 4;  // 16-byte chunks of one row in one pass
+      constexpr int RPI = 64 / NCH;  // rows per wave-wide load
+      __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)x, 0, (int)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
+      const int b = lane / NCH, pos = lane % NCH;
+#if defined(LVLLM_GEMM_XORDER) && LVLLM_GEMM_XORDER == 1
+      load_unit(a0, 0, 0);
+      load_unit(a1, 0, 1);
+#endif
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mt * 16 + c;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
-      if constexpr (W8) {
-        if (m < M && s < nvalid) {
-          // 16 consecutive k of row m: k = 64 (step0 + s) + 16 g ..  (K here is K/2, see above)
-          const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 64 + 16 * g;
-          S e[16];
-          *reinterpret_cast<g_u32x4_t*>(e) = *reinterpret_cast<const g_u32x4_t*>(src);
-          *reinterpret_cast<g_u32x4_t*>(e + 8) = *reinterpret_cast<const g_u32x4_t*>(src + 8);
-          const float inv = 1.0f / x_scale[0];
-          uint32_t q[4];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int d4 = 0; d4 < 4; ++d4) {
-            float f[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) f[r] = fmaxf(-448.f, fminf(T::to_float(e[4 * d4 + r]) * inv, 448.f));
-            uint32_t wq = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
-            q[d4] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wq, true);
+          for (int i = 0; i < HALF; ++i) {
+            const int r = i * RPI + b, q = pos ^ r;
+            const int ks = h * HALF + (q >> 2), m = mt * 16 + r;
+            const unsigned off = (m < M && ks < nvalid)
+                                     ? (unsigned)(((int64_t)m * ldx + (int64_t)(step0 + ks) * 32 + (q & 3) * 8) * 2)
+                                     : kOutOfRange;
+            xf[mt][h * HALF + i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
           }
-          xf[mt][s] = g_u32x4_t{q[0], q[1], q[2], q[3]};
+#if !defined(LVLLM_GEMM_XORDER) || LVLLM_GEMM_XORDER == 0
+      load_unit(a0, 0, 0);  // the first weights follow the activations into the queue
+      load_unit(a1, 0, 1);
+#endif
+      char* xs = reinterpret_cast<char*>(stage + (size_t)stage_tiles * MT * 64) + wave * (16 * NCH * 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < HALF; ++i)
+            *reinterpret_cast<g_u32x4_t*>(xs + i * 1024 + lane * 16) = xf[mt][h * HALF + i];
+#pragma unroll
+          for (int s2 = 0; s2 < HALF; ++s2)
+            xf[mt][h * HALF + s2] =
+                *reinterpret_cast<const g_u32x4_t*>(xs + c * (NCH * 16) + (((4 * s2 + g) ^ c) * 16));
         }
-      } else if (m < M && s < nvalid) {
-        const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
-        g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
-        if (act == 1) {
-          // fused SwiGLU gate: the row holds [gate (K) | up (K)]; X = T(T(silu(gate)) * up), the
-          // roundings of silu_and_mul (activation.hip), so the fused path is bit-identical
-          const g_u32x4_t u = *reinterpret_cast<const g_u32x4_t*>(src + K);
+    }
+  }
+  if (!staged) {
+    load_unit(a0, 0, 0);
+    load_unit(a1, 0, 1);
+    // the first weight loads (HBM) are in flight before the activations (L2) are requested
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t out = 0;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + c;
 #pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-              const S gs = (S)((v[q] >> (16 * hlf)) & 0xffffu), us = (S)((u[q] >> (16 * hlf)) & 0xffffu);
-              const float gf = T::to_float(gs);
-              const S a = T::from_float(gf / (1.0f + expf(-gf)));
-              out |= (uint32_t)T::from_float(T::to_float(a) * T::to_float(us)) << (16 * hlf);
+      for (int s = 0; s < KSTEPS; ++s) {
+        xf[mt][s] = g_u32x4_t{0, 0, 0, 0};
+        if constexpr (W8) {
+          if (m < M && s < nvalid) {
+            // 16 consecutive k of row m: k = 64 (step0 + s) + 16 g ..  (K here is K/2, see above)
+            const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 64 + 16 * g;
+            S e[16];
+            *reinterpret_cast<g_u32x4_t*>(e) = *reinterpret_cast<const g_u32x4_t*>(src);
+            *reinterpret_cast<g_u32x4_t*>(e + 8) = *reinterpret_cast<const g_u32x4_t*>(src + 8);
+            const float inv = 1.0f / x_scale[0];
+            uint32_t q[4];
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+              float f[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) f[r] = fmaxf(-448.f, fminf(T::to_float(e[4 * d4 + r]) * inv, 448.f));
+              uint32_t wq = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+              q[d4] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wq, true);
             }
-            v[q] = out;
+            xf[mt][s] = g_u32x4_t{q[0], q[1], q[2], q[3]};
           }
+        } else if (m < M && s < nvalid) {
+          const S* src = x + (int64_t)m * ldx + (int64_t)(step0 + s) * 32 + 8 * g;
+          g_u32x4_t v = *reinterpret_cast<const g_u32x4_t*>(src);
+          if (act == 1) {
+            // fused SwiGLU gate: the row holds [gate (K) | up (K)]; X = T(T(silu(gate)) * up), the
+            // roundings of silu_and_mul (activation.hip), so the fused path is bit-identical
+            const g_u32x4_t u = *reinterpret_cast<const g_u32x4_t*>(src + K);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              uint32_t out = 0;
+#pragma unroll
+              for (int hlf = 0; hlf < 2; ++hlf) {
+                const S gs = (S)((v[q] >> (16 * hlf)) & 0xffffu), us = (S)((u[q] >> (16 * hlf)) & 0xffffu);
+                const float gf = T::to_float(gs);
+                const S a = T::from_float(gf / (1.0f + expf(-gf)));
+                out |= (uint32_t)T::from_float(T::to_float(a) * T::to_float(us)) << (16 * hlf);
+              }
+              v[q] = out;
+            }
+          }
+          xf[mt][s] = v;
         }
-        xf[mt][s] = v;
       }
     }
   }
 
+#ifdef LVLLM_GEMM_TRACE
+  __builtin_amdgcn_s_waitcnt(0);  // X and the first two units have arrived
+  GEMM_TRACE(1);
+#endif
   for (int grp = 0; grp < ngroups; ++grp) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -287,8 +374,13 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     }
     finish_group(grp);
   }
+  GEMM_TRACE(2);
 #ifndef LVLLM_GEMM_NOREDUCE
   flush_stage(my_tiles);  // all weights have been streamed: now the stores
+#endif
+#ifdef LVLLM_GEMM_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  GEMM_TRACE(3);
 #endif
 }
 
@@ -330,10 +422,12 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
   // output stage: as many tiles as the workgroup owns, capped by what is left of the 160 KiB LDS
   const int tiles_per_wg = (ntiles + groups - 1) / groups;
   int stage_tiles = ((tiles_per_wg + NT - 1) / NT) * NT;
-  const int cap = (int)((160 * 1024 - red_bytes) / ((size_t)MT * 1024) / NT) * NT;
+  // wave-private scratch that turns row-order activation loads into fragments (16-bit path only)
+  const size_t xs_bytes = W8 ? 0 : (size_t)kGemmWaves * 16 * (KSTEPS / 2) * 64;
+  const int cap = (int)((160 * 1024 - red_bytes - xs_bytes) / ((size_t)MT * 1024) / NT) * NT;
   if (stage_tiles > cap) stage_tiles = cap;
   if (stage_tiles < NT) stage_tiles = NT;
-  const size_t smem = red_bytes + (size_t)stage_tiles * MT * 64 * sizeof(g_f32x4_t);
+  const size_t smem = red_bytes + (size_t)stage_tiles * MT * 64 * sizeof(g_f32x4_t) + xs_bytes;
   auto go = [&](auto kern) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -348,6 +442,12 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
     else go(skinny_gemm_kernel<T, MT, KSTEPS, false, NT, false>);
   }
 }
+
+#ifdef LVLLM_GEMM_TRACE
+extern "C" int lvllm_gemm_trace_read(void* host_dst, int nwords) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_trace), (size_t)nwords * 8);
+}
+#endif
 
 // W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
 __global__ void pack_weight_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t nchunks,
@@ -414,6 +514,7 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   if (M <= 0 || N <= 0) return 0;
   if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 32) != 0 || (N % 16) != 0 ||
       (int64_t)N * K * 2 >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
+      ((int64_t)(M - 1) * ldx + (act == 1 ? 2 : 1) * (int64_t)K) * 2 >= ((int64_t)1 << 31) ||
       ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0)) {
     set_error("lvllm_skinny_gemm: shape outside the kernel's envelope");
     return 3;

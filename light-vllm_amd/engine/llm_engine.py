@@ -6,6 +6,7 @@ flight, legal because scheduled groups are marked busy).
 One engine = one GPU (replica).  Multi-GPU serving replicates engines, one process per GPU,
 with no collective on the kernel path.
 """
+import os
 import queue
 import threading
 import time
@@ -162,7 +163,8 @@ class LLMEngine:
                                                   scheduler_config.max_num_batched_tokens) if mixed else 0)
         # with steps on several streams every decode GEMM takes half the CUs and leaves the rest
         # to the other step's kernel (measured: +10 % tokens/s at two steps in flight)
-        torch.ops._C_amd.set_tuning("gemm_workgroups", 128 if self.num_slots > 1 else 256)
+        gemm_wgs = int(os.environ.get("LVLLM_ENGINE_GEMM_WGS", "0")) or (128 if self.num_slots > 1 else 256)
+        torch.ops._C_amd.set_tuning("gemm_workgroups", gemm_wgs)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
         if num_gpu is None:
             num_gpu, auto_cpu = self.worker.determine_num_available_blocks()
