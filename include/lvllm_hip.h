@@ -190,6 +190,8 @@ int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, i
 int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream);
 /* As lvllm_skinny_gemm, plus: act = 1 -> X rows are [gate | up] (2K wide) and the kernel
  * multiplies by T(T(silu(gate)) * up) (silu_and_mul fused into the down projection);
+ * act = 2 -> W rows are [gate (N/2) | up (N/2)] and y is [M, N/2] = silu_and_mul of the projection,
+ * applied in the epilogue (N % 32 == 0, K not split over workgroups, no partial_out);
  * partial_out != 0 -> the fp32 partial sums [ksplit, M, N] stay in `workspace` (at least
  * max(ksplit,1)*M*N*4 bytes), y is not written, *ksplit_out = number of partials. */
 int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,

@@ -113,7 +113,17 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   const unsigned step_stride = PACKED ? 1024u : 64u;
   const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2);
 
-  const int my_tiles_ld = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // Which n-tiles this workgroup owns.  Plain: tile blockIdx.x + i * gridDim.x for local index i.
+  // glu (act == 2, W = [gate rows | up rows]): the workgroup owns PAIRS -- local tiles 2j and 2j+1
+  // are the gate tile and the up tile of pair blockIdx.x + j * gridDim.x -- so that the epilogue
+  // can apply silu(gate) * up before anything is written (no [M, N] intermediate, no second kernel).
+  const bool glu = act == 2;
+  const int nunits = glu ? ntiles >> 1 : ntiles;  // tiles or pairs handed out round-robin
+  const int my_units = nunits > (int)blockIdx.x ? (nunits - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int my_tiles_ld = glu ? 2 * my_units : my_units;
+  auto tile_of = [&](const int i) __attribute__((always_inline)) {
+    return glu ? (int)(blockIdx.x + (i >> 1) * gridDim.x) + (i & 1) * nunits : (int)(blockIdx.x + i * gridDim.x);
+  };
   // Loads that must return zeros (k-steps past K, tiles past the workgroup's last) get an offset of
   // ~0: out of the descriptor's range, no memory access, no branch.  The masks are wave-uniform
   // and passed through an empty asm: when the compiler can see the conditions it turns the
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) kmask[s] = opaque(s < nvalid ? 0u : ~0u);
   auto load_unit = [&](g_u32x4_t (&a)[HALF], const int i, const int h) __attribute__((always_inline)) {
-    const int t = blockIdx.x + i * gridDim.x;  // n-tile (N is a multiple of 16: valid as a whole)
+    const int t = tile_of(i);  // n-tile (N is a multiple of 16: valid as a whole)
     const unsigned tmask = opaque(i < my_tiles_ld ? 0u : ~0u);
     const unsigned base = lane_off + (unsigned)t * tile_stride;
 #pragma unroll
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[j][mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int my_tiles = my_tiles_ld;
   const int ngroups = (my_tiles + NT - 1) / NT;
 
   // Output staging.  A global store inside the streaming loop costs far more than its bytes:
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 
   auto store_slab = [&](const int i, const int mt, g_f32x4_t sum) __attribute__((always_inline)) {
     // lane (g, c): rows n = n0 + 4g + r of column m = 16 mt + c
-    const int t = blockIdx.x + i * gridDim.x;
+    const int t = tile_of(i);
     const int n0 = 16 * t + 4 * g;
     const int m = mt * 16 + c;
     if (m < M && n0 < N) {
@@ -185,12 +195,51 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     }
   };
 
+  // glu: one output slab per (pair, m-tile): y[m, 16 p + 4 g + r] = T(T(silu(gate)) * up) with gate and up
+  // rounded to T first -- the rounding points of the projection followed by silu_and_mul
+  // (activation.hip), so the fused launch is bit-identical to the two it replaces
+  auto store_pair = [&](const int i, const int mt, g_f32x4_t gs, g_f32x4_t us) __attribute__((always_inline)) {
+    const int pr = blockIdx.x + (i >> 1) * gridDim.x;
+    const int n0 = 16 * pr + 4 * g, m = mt * 16 + c;
+    const int half_n = N >> 1;
+    if (m < M && n0 < half_n) {
+      if constexpr (W8) { gs *= out_scale; us *= out_scale; }
+      if (bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gs[r] += T::to_float(bias[n0 + r]);
+          us[r] += T::to_float(bias[half_n + n0 + r]);
+        }
+      }
+      S o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gf = T::to_float(T::from_float(gs[r]));
+        const S a = T::from_float(gf / (1.0f + expf(-gf)));
+        o[r] = T::from_float(T::to_float(a) * T::to_float(T::from_float(us[r])));
+      }
+      uint2 ov;
+      ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+      ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+      *reinterpret_cast<uint2*>(y + (int64_t)m * half_n + n0) = ov;
+    }
+  };
+
   auto flush_stage = [&](const int end_tile) __attribute__((always_inline)) {
     __syncthreads();  // every reducer's slab is in the stage
-    const int nslabs = (end_tile - stage_base) * MT;
-    for (int sl = wave; sl < nslabs; sl += kGemmWaves) {
-      const int i = stage_base + sl / MT, mt = sl % MT;
-      store_slab(i, mt, stage[(size_t)sl * 64 + lane]);
+    if (glu) {  // stage_base and end_tile are even: pairs are never split across two flushes
+      const int nslabs = ((end_tile - stage_base) >> 1) * MT;
+      for (int sl = wave; sl < nslabs; sl += kGemmWaves) {
+        const int pl = sl / MT, mt = sl % MT;
+        store_pair(stage_base + 2 * pl, mt, stage[((size_t)(2 * pl) * MT + mt) * 64 + lane],
+                   stage[((size_t)(2 * pl + 1) * MT + mt) * 64 + lane]);
+      }
+    } else {
+      const int nslabs = (end_tile - stage_base) * MT;
+      for (int sl = wave; sl < nslabs; sl += kGemmWaves) {
+        const int i = stage_base + sl / MT, mt = sl % MT;
+        store_slab(i, mt, stage[(size_t)sl * 64 + lane]);
+      }
     }
     stage_base = end_tile;
     __syncthreads();  // the stage may be overwritten again
@@ -261,7 +310,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   // position q ^ r, so the 16 rows of a fragment read hit 16 different bank groups.
   bool staged = false;
   if constexpr (!W8) {
-    if (act == 0) {
+    if (act != 1) {
       staged = true;
       constexpr int NCH = HALF * 4;  // 16-byte chunks of one row in one pass
       constexpr int RPI = 64 / NCH;  // rows per wave-wide load
@@ -420,13 +469,15 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
   constexpr int NT = LVLLM_GEMM_NT / MT > 0 ? LVLLM_GEMM_NT / MT : 1;  // NT * MT slabs per meeting
   const size_t red_bytes = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
   // output stage: as many tiles as the workgroup owns, capped by what is left of the 160 KiB LDS
-  const int tiles_per_wg = (ntiles + groups - 1) / groups;
+  const bool glu = act == 2;  // tiles are handed out in (gate, up) pairs
+  const int tiles_per_wg = glu ? 2 * ((ntiles / 2 + groups - 1) / groups) : (ntiles + groups - 1) / groups;
   int stage_tiles = ((tiles_per_wg + NT - 1) / NT) * NT;
   // wave-private scratch that turns row-order activation loads into fragments (16-bit path only)
   const size_t xs_bytes = W8 ? 0 : (size_t)kGemmWaves * 16 * (KSTEPS / 2) * 64;
   const int cap = (int)((160 * 1024 - red_bytes - xs_bytes) / ((size_t)MT * 1024) / NT) * NT;
   if (stage_tiles > cap) stage_tiles = cap;
   if (stage_tiles < NT) stage_tiles = NT;
+  if (glu) stage_tiles = stage_tiles < 2 ? 2 : (stage_tiles & ~1);  // a flush never splits a pair
   const size_t smem = red_bytes + (size_t)stage_tiles * MT * 64 * sizeof(g_f32x4_t) + xs_bytes;
   auto go = [&](auto kern) {
     if (smem > 64 * 1024)
@@ -494,7 +545,9 @@ extern "C" int lvllm_pack_weight(void* dst, const void* src, int N, int K, int d
 }
 
 // `act` = 1: X rows are [gate (K) | up (K)] and the kernel multiplies W by silu(gate)*up
-// (the SwiGLU activation fused into the down projection); `partial_out` != 0: leave the fp32
+// (the SwiGLU activation fused into the down projection); `act` = 2: W rows are [gate (N/2) | up (N/2)]
+// and y [M, N/2] = silu(X.gate^T) * (X.up^T), the activation applied in the epilogue (the gate_up
+// projection and silu_and_mul in one launch, bit-identical to the pair); `partial_out` != 0: leave the fp32
 // split-K partials in `workspace` ([ksplit, M, N]) and do not write y (the caller's next kernel
 // sums them: lvllm_fused_add_rms_norm_splitk).  *ksplit_out receives the number of partials.
 extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
@@ -532,6 +585,11 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   int groups = gemm_cus / ksplit;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
+  if (act == 2) {  // SwiGLU epilogue: y is [M, N / 2]
+    LV_CHECK(N % 32 == 0 && ksplit == 1 && !partial_out,
+             "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup (K <= 4096 at M <= 32)");
+    if (groups > ntiles / 2) groups = ntiles / 2;
+  }
   if (ksplit_out) *ksplit_out = ksplit;
   LV_CHECK(!(partial_out && bias != nullptr), "partial_out leaves the bias to the caller");
   float* partial = nullptr;

@@ -304,6 +304,30 @@ torch::Tensor skinny_linear_packed(const torch::Tensor& x, const torch::Tensor& 
   return y;
 }
 
+// gate_up projection + silu_and_mul in one launch: w_packed holds [gate rows | up rows] ([N, K]
+// packed), the result is [M, N / 2].  Bit-identical to skinny_linear_packed followed by silu_and_mul.
+torch::Tensor skinny_linear_packed_swiglu(const torch::Tensor& x, const torch::Tensor& w_packed,
+                                          const std::optional<torch::Tensor>& bias, int64_t N, int64_t K) {
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && w_packed.numel() == N * K && N % 32 == 0,
+              "skinny_linear_packed_swiglu: bad shapes");
+  TORCH_CHECK(skinny_ok(x, w_packed, bias), "skinny_linear_packed_swiglu: M <= 64 rows of bf16/f16 on the GPU only");
+  const int64_t M = x.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto y = torch::empty({M, N / 2}, x.options());
+  if (lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K) > 0) {
+    // K is split over workgroups at this M: the two launches the epilogue would have replaced
+    auto gate_up = skinny_linear_impl(x, w_packed, bias, true, N, K);
+    TORCH_CHECK(gate_up.defined(), lvllm_last_error());
+    check(lvllm_silu_and_mul(y.data_ptr(), gate_up.data_ptr(), M, (int)(N / 2), dtype_code(x, "silu_and_mul"),
+                             current_stream(x)));
+    return y;
+  }
+  check(lvllm_skinny_gemm_ex(y.data_ptr(), x.data_ptr(), w_packed.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                             (int)M, (int)N, (int)K, x.stride(0), dtype_code(x, "skinny_linear_packed_swiglu"), 1, 2,
+                             0, nullptr, nullptr, 0, current_stream(x)));
+  return y;
+}
+
 // A projection that leaves its fp32 split-K partials [S, M, N] for fused_add_rms_norm_splitk
 // instead of reducing them itself.  swiglu: x = [gate | up] ([M, 2K]) and the activation is applied
 // while loading x (bit-identical to silu_and_mul, but every workgroup redoes it for its K slice:
@@ -656,6 +680,8 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_packed", torch::kCUDA, &skinny_linear_packed);
   amd.def("pack_weight(Tensor w) -> Tensor");
   amd.impl("pack_weight", torch::kCUDA, &pack_weight);
+  amd.def("skinny_linear_packed_swiglu(Tensor x, Tensor w_packed, Tensor? bias, int N, int K) -> Tensor");
+  amd.impl("skinny_linear_packed_swiglu", torch::kCUDA, &skinny_linear_packed_swiglu);
   amd.def("skinny_linear_packed_partials(Tensor x, Tensor w_packed, int N, int K, bool swiglu) -> Tensor");
   amd.impl("skinny_linear_packed_partials", torch::kCUDA, &skinny_linear_packed_partials);
   amd.def("fused_add_rms_norm_splitk(Tensor! out, Tensor! residual, Tensor partials, Tensor weight, "

@@ -7,6 +7,7 @@ Follows light_vllm/decode_only/modelzoo/qwen2.py:144-292: per layer
 Dense projections are plain torch GEMMs (hipBLASLt / MFMA); everything else is a gfx950
 kernel of this package.  Weights are random-initialised: no checkpoint is available offline.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -68,6 +69,7 @@ def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) ->
 
 
 _CALIBRATING = False
+_SWIGLU_EPILOGUE = os.environ.get("LVLLM_SWIGLU_EPILOGUE", "1") != "0"  # A/B switch
 
 
 def build_cos_sin_cache(head_dim: int, max_pos: int, base: float, dtype, device) -> torch.Tensor:
@@ -215,9 +217,15 @@ class DecoderModel:
                                              attn_metadata)
             hidden = linear(attn_out, lw.o)
             hidden = self._add_norm(hidden, residual, lw.post_norm)
-            gate_up = linear(hidden, lw.gate_up)
-            act = torch.empty(T, cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
-            ops.silu_and_mul(act, gate_up)
+            if (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.packed is not None and lw.gate_up.N % 32 == 0
+                    and not _CALIBRATING):
+                # gate_up projection with silu_and_mul in its epilogue: one launch, no [T, 2 inter] round trip
+                act = torch.ops._C_amd.skinny_linear_packed_swiglu(hidden, lw.gate_up.packed, None,
+                                                                   lw.gate_up.N, lw.gate_up.K)
+            else:
+                gate_up = linear(hidden, lw.gate_up)
+                act = torch.empty(T, cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
+                ops.silu_and_mul(act, gate_up)
             if decode_only and lw.down.packed is not None and lw.down.w8_t is None:
                 # [S, T, hidden] fp32 split-K partial sums; the next add+norm adds them up
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(act, lw.down.packed, lw.down.N,

@@ -105,3 +105,26 @@ def test_fused_decode_ops_are_bit_identical_to_the_unfused_sequence(ops, dtype):
         torch.ops._C_amd.fused_add_rms_norm_splitk(out_b, res_b, partials, nw, 1e-5)
         assert torch.equal(res_a.view(torch.int16), res_b.view(torch.int16))
         assert torch.equal(y.view(torch.int16), out_b.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,inter,K", [(32, 14336, 4096), (1, 512, 256), (17, 1040, 1024), (64, 2048, 2048),
+                                       (33, 11008, 4096), (5, 48, 64), (32, 16, 32)])
+@pytest.mark.parametrize("wgs", [256, 128, 9])
+def test_swiglu_epilogue_is_bit_identical_to_projection_then_silu_and_mul(ops, dtype, M, inter, K, wgs):
+    g = torch.Generator(device=DEV).manual_seed(M + inter + K)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(2 * inter, K, generator=g, device=DEV) * 0.05).to(dtype)
+    b = (torch.randn(2 * inter, generator=g, device=DEV) * 0.5).to(dtype)
+    wp = torch.ops._C_amd.pack_weight(w)
+    torch.ops._C_amd.set_tuning("gemm_workgroups", wgs)
+    try:
+        for bias in (None, b):
+            gate_up = torch.ops._C_amd.skinny_linear_packed(x, wp, bias, 2 * inter, K)
+            ref = torch.empty(M, inter, dtype=dtype, device=DEV)
+            ops.silu_and_mul(ref, gate_up)
+            out = torch.ops._C_amd.skinny_linear_packed_swiglu(x, wp, bias, 2 * inter, K)
+            assert out.shape == (M, inter)
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    finally:
+        torch.ops._C_amd.set_tuning("gemm_workgroups", 256)
