@@ -4,3 +4,5 @@
 namespace lvllm {
 template int launch_mfma_hs<BF16>(const AttnParams&, int, int, int, int, int, hipStream_t);
 }  // namespace lvllm
+
+LVLLM_TRACE_READER(lvllm_trace_read_attn)

@@ -34,6 +34,7 @@
 // (attention_kernels.cu:398-400) -- here un-normalised exp values, the
 // normaliser 1/(sum+1e-6) is applied in fp32 at the end.
 #pragma once
+#include "trace.h"
 #include <float.h>
 
 #include <type_traits>
@@ -157,6 +158,7 @@ template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8>
 __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
     const AttnParams p) {
   using S = typename T::store_t;
+  LVLLM_TRACE_BEGIN();
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
   static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
   static_assert(NBUF >= 1 && NBUF <= 3, "register sets per wave");
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       p.exp_sums[row] = L;
     }
   }
+  LVLLM_TRACE_END(2);
 }
 
 // ---- host side: instantiation ladder (head size x block size x waves) ----

@@ -9,6 +9,7 @@
 // One workgroup per token row; 16-byte loads; the row is kept in registers
 // between the variance pass and the scaling pass (one HBM read per element).
 #include "common.h"
+#include "trace.h"
 
 namespace lvllm {
 
@@ -20,6 +21,7 @@ __global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUS
                                     const typename T::store_t* in,
                                     const typename T::store_t* __restrict__ weight,
                                     const float epsilon, const int hidden_size) {
+  LVLLM_TRACE_BEGIN();
   using V = Vec16<T>;
   constexpr int N = V::N;
   __shared__ float red[16];
@@ -77,6 +79,7 @@ __global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUS
     }
     out_v[i] = o;
   }
+  LVLLM_TRACE_END(3);
 }
 
 // fused_add_rms_norm whose `input` arrives as fp32 split-K partials [S, M, hidden] of the
@@ -89,6 +92,7 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
                                                  const int64_t partial_stride,  // M * hidden
                                                  const typename T::store_t* __restrict__ weight,
                                                  const float epsilon, const int hidden_size) {
+  LVLLM_TRACE_BEGIN();
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
   __shared__ float red[16];
@@ -150,6 +154,7 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
     }
     out_v[i] = o;
   }
+  LVLLM_TRACE_END(4);
 }
 
 // element-wise path for rows that are not 16-byte friendly
@@ -257,3 +262,5 @@ extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const 
   LV_LAUNCH_CHECK();
   return 0;
 }
+
+LVLLM_TRACE_READER(lvllm_trace_read_norm)

@@ -10,6 +10,7 @@
 // Launch: one workgroup per token; NeoX rows are processed in 16-byte chunks
 // (8 rotation pairs of bf16 per thread: 4 dwordx4 loads, 2 dwordx4 stores).
 #include "common.h"
+#include "trace.h"
 
 namespace lvllm {
 
@@ -108,6 +109,7 @@ __global__ void rotary_embedding_and_cache_kernel(
     void* __restrict__ value_cache_v, const int64_t* __restrict__ slot_mapping,
     const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
     const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale) {
+  LVLLM_TRACE_BEGIN();
   using S = typename T::store_t;
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
@@ -197,6 +199,7 @@ __global__ void rotary_embedding_and_cache_kernel(
       }
     }
   }
+  LVLLM_TRACE_END(5);
 }
 
 template <typename T>
@@ -302,3 +305,5 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
   LV_LAUNCH_CHECK();
   return 0;
 }
+
+LVLLM_TRACE_READER(lvllm_trace_read_rope)

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "trace.h"
 
 namespace lvllm {
 
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles,
     const float* __restrict__ x_scale, const float* __restrict__ w_scale) {
   using S = typename T::store_t;
+  LVLLM_TRACE_BEGIN();
   GEMM_TRACE(0);
   const float out_scale = W8 ? x_scale[0] * w_scale[0] : 1.f;
   constexpr int HALF = KSTEPS / 2;
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   __builtin_amdgcn_s_waitcnt(0);
   GEMM_TRACE(3);
 #endif
+  LVLLM_TRACE_END(1);
 }
 
 // out[m, n] = T(sum_s partial[s, m, n] + bias[n])
@@ -499,6 +502,8 @@ extern "C" int lvllm_gemm_trace_read(void* host_dst, int nwords) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_trace), (size_t)nwords * 8);
 }
 #endif
+
+LVLLM_TRACE_READER(lvllm_trace_read_gemm)
 
 // W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
 __global__ void pack_weight_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t nchunks,
