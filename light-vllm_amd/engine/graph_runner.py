@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ..attention.backend import PagedAttnMetadata
+from .input_builder import DecodeStepArrays
 
 
 class DecodeGraph:
@@ -27,11 +28,19 @@ class DecodeGraph:
         self.max_blocks_per_seq = max_blocks_per_seq
         self.block_size = block_size
         dev = torch.device(device)
-        self.input_ids = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.positions = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.slot_mapping = torch.full((batch_size,), -1, dtype=torch.int64, device=dev)
-        self.block_tables = torch.zeros(batch_size, max_blocks_per_seq, dtype=torch.int32, device=dev)
-        self.seq_lens = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        # the five static inputs are views of one device buffer, mirrored by one pinned staging
+        # buffer on the host: a step's inputs arrive with a single copy (DecodeStepArrays)
+        B, W = batch_size, max_blocks_per_seq
+        o_ids, o_pos, o_slot, o_len, o_bt, total = DecodeStepArrays.layout(B, W)
+        self.packed = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.input_ids = self.packed[o_ids:o_pos].view(torch.int64)
+        self.positions = self.packed[o_pos:o_slot].view(torch.int64)
+        self.slot_mapping = self.packed[o_slot:o_len].view(torch.int64)
+        self.seq_lens = self.packed[o_len:o_bt].view(torch.int32)
+        self.block_tables = self.packed[o_bt:].view(torch.int32).view(B, W)
+        self.slot_mapping.fill_(-1)
+        self.host = torch.zeros(total, dtype=torch.uint8, pin_memory=dev.type == "cuda")
+        self.staging = DecodeStepArrays(B, W, block_size, self.host.numpy())
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.hidden: Optional[torch.Tensor] = None
         self.next_tokens: Optional[torch.Tensor] = None
@@ -77,6 +86,10 @@ class DecodeGraph:
         if n < self.batch_size:  # padding rows: no cache write, empty context
             self.slot_mapping[n:].fill_(-1)
             self.seq_lens[n:].zero_()
+
+    def load_staged(self) -> None:
+        """The step written into `staging` (DecodeStepArrays.fill) goes to the device in one copy."""
+        self.packed.copy_(self.host, non_blocking=True)
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()

@@ -10,6 +10,7 @@ present); the executor moves them with non-blocking copies on its stream.
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 from .config import CacheConfig, SchedulerConfig
@@ -184,3 +185,86 @@ class ModelInputBuilder:
     def __call__(self, out: SchedulerOutput) -> ExecuteInput:
         return ExecuteInput(worker_input=self.prepare_worker_input(out),
                             model_input=self.prepare_model_input(out.seq_group_metadata_list))
+
+
+class DecodeStepArrays:
+    """The five arrays a captured decode step reads -- token ids, positions, slot mapping, sequence
+    lengths, block tables -- as numpy views of ONE staging buffer, filled straight from the scheduler's
+    metadata.  Same values as ModelInputBuilder + the attention metadata builder produce for a step
+    that holds only decode tokens of single-sequence groups without a sliding window
+    (model_input_builder.py:212-378 with is_prompt == False: token = last token, position =
+    seq_len - 1, slot = table[(seq_len - 1) // block_size] * block_size + (seq_len - 1) % block_size;
+    backends/utils.py:31-75), checked against that path by tests/test_input_builder.py; what it
+    skips is the Python-list and torch.tensor traffic: the engine thread's turnaround between a
+    step's result and the launch of the group's next step is time one stream spends alone on the
+    GPU.  Block-table rows are rewritten only when the sequence's table differs from the list this
+    row held last time (exact list comparison, so any reallocation -- swap, fork, recompute -- is seen).
+    """
+
+    def __init__(self, batch_size: int, max_blocks_per_seq: int, block_size: int, buffer: Optional[np.ndarray] = None):
+        B, W = batch_size, max_blocks_per_seq
+        self.batch_size, self.width, self.block_size = B, W, block_size
+        self.nbytes = self.layout(B, W)[-1]
+        buf = np.zeros(self.nbytes, dtype=np.uint8) if buffer is None else buffer
+        assert buf.dtype == np.uint8 and buf.size == self.nbytes
+        o_ids, o_pos, o_slot, o_len, o_bt, _ = self.layout(B, W)
+        self.buffer = buf
+        self.input_ids = buf[o_ids:o_pos].view(np.int64)
+        self.positions = buf[o_pos:o_slot].view(np.int64)
+        self.slot_mapping = buf[o_slot:o_len].view(np.int64)
+        self.seq_lens = buf[o_len:o_bt].view(np.int32)
+        self.block_tables = buf[o_bt:].view(np.int32).reshape(B, W)
+        self.slot_mapping[:] = -1
+        self._rows: List[Optional[List[int]]] = [None] * B  # the table each row holds
+        self._arange = np.arange(B)
+
+    @staticmethod
+    def layout(B: int, W: int):
+        """Byte offsets of (input_ids i64[B], positions i64[B], slot_mapping i64[B], seq_lens i32[B],
+        block_tables i32[B, W]) and the total size."""
+        return 0, 8 * B, 16 * B, 24 * B, 28 * B, 28 * B + 4 * B * W
+
+    @staticmethod
+    def eligible(metas, worker_lists_empty: bool, sliding_window) -> bool:
+        if not worker_lists_empty or sliding_window is not None or not metas:
+            return False
+        for m in metas:
+            if m.is_prompt or not m.do_sample or len(m.seq_data) != 1 or not m.block_tables:
+                return False
+        return True
+
+    def fill(self, metas) -> List[int]:
+        """Writes the step into the staging arrays (rows past len(metas) become padding: slot -1,
+        length 0) and returns the sequence ids in row order."""
+        n = len(metas)
+        assert n <= self.batch_size
+        seq_ids: List[int] = []
+        lens: List[int] = []
+        toks: List[int] = []
+        bt, rows, W = self.block_tables, self._rows, self.width
+        for i, m in enumerate(metas):
+            (seq_id, data), = m.seq_data.items()
+            table = m.block_tables[seq_id]
+            old = rows[i]
+            if old is None or table != old:
+                k = len(table)
+                assert k <= W, "block table wider than the captured step"
+                if old is not None and k == len(old) + 1 and table[:-1] == old:
+                    bt[i, k - 1] = table[-1]
+                else:
+                    bt[i, :k] = table
+                rows[i] = table
+            seq_ids.append(seq_id)
+            lens.append(data.get_len())
+            toks.append(data.get_last_token_id())
+        L = np.asarray(lens, dtype=np.int64)
+        pos = L - 1
+        self.input_ids[:n] = toks
+        self.positions[:n] = pos
+        self.seq_lens[:n] = L
+        blk = bt[self._arange[:n], pos // self.block_size].astype(np.int64)
+        self.slot_mapping[:n] = blk * self.block_size + pos % self.block_size
+        if n < self.batch_size:
+            self.slot_mapping[n:] = -1
+            self.seq_lens[n:] = 0
+        return seq_ids

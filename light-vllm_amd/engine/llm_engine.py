@@ -138,6 +138,30 @@ class Worker:
         return ExecuteOutput(out, mi.sample_seq_ids)
 
 
+    @torch.inference_mode()
+    def execute_decode(self, metas, slot: int = 0) -> Optional[ExecuteOutput]:
+        """A step of decode tokens only, taken straight from the scheduler's metadata to the captured
+        graph's staging buffer (DecodeStepArrays): same inputs as `execute(input_builder(...))`, a
+        fraction of the host time.  None when the step does not fit the captured shapes."""
+        graphs = self.graph_pools[slot] if self.graph_pools is not None else None
+        if graphs is None or self.capture_logits:
+            return None
+        n = len(metas)
+        width = 0
+        for m in metas:
+            for t in m.block_tables.values():
+                width = max(width, len(t))
+        if width > graphs.max_blocks_per_seq:
+            return None
+        g = graphs.get(n)
+        seq_ids = g.staging.fill(metas)
+        g.load_staged()
+        tokens = g.replay()[:n]
+        out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
+        out.copy_(tokens, non_blocking=True)
+        return ExecuteOutput(out, seq_ids)
+
+
 class LLMEngine:
 
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig,
@@ -193,6 +217,7 @@ class LLMEngine:
         self._done_qs: List["queue.Queue"] = [queue.Queue() for _ in range(self.num_slots)]
         self.executor_out: "queue.Queue" = queue.Queue()
         self.num_on_the_fly = 0
+        self.fast_decode_inputs = os.environ.get("LVLLM_FAST_DECODE_INPUTS", "1") != "0"
         self.step_returns_outputs = True
 
     # ---- requests ----
@@ -236,13 +261,17 @@ class LLMEngine:
                 results.append(RequestOutput(g.request_id, [], g.is_finished()))
         for g in sched.ignored_seq_groups:
             results.append(RequestOutput(g.request_id, [], True, "length"))
-        self.scheduler.free_finished_request([s.seq_group.request_id for s in sched.scheduled_seq_groups])
-        for r in results:
-            if r.finished:
-                g = self.groups.pop(r.request_id, None)
-                if g is not None:
-                    for seq in g.seqs:
-                        self.seq_to_group.pop(seq.seq_id, None)
+        if any(r.finished for r in results):
+            self.scheduler.free_finished_request([s.seq_group.request_id for s in sched.scheduled_seq_groups])
+            for r in results:
+                if r.finished:
+                    g = self.groups.pop(r.request_id, None)
+                    if g is not None:
+                        for seq in g.seqs:
+                            self.seq_to_group.pop(seq.seq_id, None)
+        else:  # nobody left: free_finished_request would only clear the busy flags of this step's groups
+            for s in sched.scheduled_seq_groups:
+                s.seq_group.busy = False
         return results
 
     # ---- synchronous step (core/llm_engine.py:119-130) ----
@@ -252,14 +281,25 @@ class LLMEngine:
             if sched is not None and sched.ignored_seq_groups:
                 return self._process(sched, ExecuteOutput(None, []))
             return []
-        ei = self.input_builder(sched)
         with torch.cuda.stream(self.stream):
-            out = self.worker.execute(ei)
+            out = self._execute(sched, 0)
         self.stream.synchronize()
         return self._process(sched, out)
 
     # ---- asynchronous step (core/llm_engine.py:132-176) ----
-    def _launch(self, sched: SchedulerOutput, ei: ExecuteInput) -> None:
+    def _execute(self, sched: SchedulerOutput, slot: int) -> ExecuteOutput:
+        """Decode-only steps go from the scheduler's metadata to the captured graph directly; every
+        other step through the general input builder."""
+        if self.fast_decode_inputs:
+            from .input_builder import DecodeStepArrays
+            plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
+            if DecodeStepArrays.eligible(sched.seq_group_metadata_list, plain, self.cache_config.sliding_window):
+                out = self.worker.execute_decode(sched.seq_group_metadata_list, slot)
+                if out is not None:
+                    return out
+        return self.worker.execute(self.input_builder(sched), slot)
+
+    def _launch(self, sched: SchedulerOutput) -> None:
         """What the reference's async_execute_loop does per task (core/executor.py:62-93): take a
         stream from the pool, launch the step on it without waiting for the previous one -- so up
         to `max_num_on_the_fly` steps overlap on the GPU -- and leave the waiting to a helper.
@@ -273,7 +313,7 @@ class LLMEngine:
             t0 = time.perf_counter()
             stream = self.streams[slot]
             with torch.cuda.stream(stream):
-                out = self.worker.execute(ei, slot)
+                out = self._execute(sched, slot)
                 ev = torch.cuda.Event()
                 ev.record(stream)
             out.execute_begin_ts = t0
@@ -313,7 +353,7 @@ class LLMEngine:
             sched = self.scheduler.schedule()
             if sched is None or sched.is_empty():
                 break
-            self._launch(sched, self.input_builder(sched))
+            self._launch(sched)
             self.num_on_the_fly += 1
         if self.num_on_the_fly == 0:
             return []

@@ -123,6 +123,20 @@ def test_graph_replay_and_async_give_the_same_tokens():
     assert eager == asyn
 
 
+def test_decode_fast_path_gives_the_tokens_of_the_general_input_builder():
+    """Decode-only steps bypass ModelInputBuilder (DecodeStepArrays -> one staged copy); the same
+    run with the bypass off must produce the same tokens, sync and async, also under swap preemption."""
+    for kw, use_async in ((dict(), False), (dict(scheduling="async", max_seqs=3), True),
+                          (dict(num_blocks=20, preemption_mode="swap"), False)):
+        runs = []
+        for fast in (True, False):
+            e = make_engine(graph=True, **kw)
+            e.fast_decode_inputs = fast
+            runs.append(run_to_completion(e, max_tokens=24, use_async=use_async))
+        assert all(len(t) == 24 for t in runs[0])
+        assert runs[0] == runs[1], kw
+
+
 def test_preemption_under_memory_pressure_keeps_results():
     """A pool too small for all sequences forces preemption-by-recompute; generation still
     completes with the tokens of an unconstrained run (greedy decoding is deterministic)."""

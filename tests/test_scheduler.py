@@ -201,3 +201,62 @@ def test_prefix_cache_hit_skips_computed_blocks():
     mi = builder(out).model_input
     assert mi.input_tokens.tolist() == [50, 51, 52] and mi.input_positions.tolist() == [8, 9, 10]
     assert mi.attn_metadata.context_lens == [8] and mi.attn_metadata.query_lens == [3]
+
+
+def test_decode_step_arrays_equal_the_general_input_builder():
+    """The staging arrays of the decode fast path (DecodeStepArrays) against ModelInputBuilder +
+    the attention metadata builder, step by step over a run with admissions, preemptions under
+    memory pressure, finishing sequences and changing batch composition: bit-equal every step."""
+    import random
+
+    import numpy as np
+
+    from light_vllm_amd.engine.input_builder import DecodeStepArrays
+    for version in (False, True):
+        rng = random.Random(5)
+        cc = CacheConfig(block_size=4, num_gpu_blocks=40, num_cpu_blocks=16)
+        sc = SchedulerConfig(max_num_batched_tokens=64, max_num_seqs=6, max_model_len=256,
+                             use_v2_block_manager=version, preemption_mode="swap")
+        s = DecodingScheduler(sc, cc)
+        builder = ModelInputBuilder(sc, cc, PagedAttnBackend())
+        arrays = DecodeStepArrays(8, 64, 4)
+        next_id, checked = 0, 0
+        for step in range(300):
+            if rng.random() < 0.15 and next_id < 40:
+                add(s, next_id, rng.randint(1, 14), max_tokens=rng.randint(2, 30))
+                next_id += 1
+            out = s.schedule()
+            if out is None or out.is_empty():
+                continue
+            metas = out.seq_group_metadata_list
+            plain = not (out.blocks_to_swap_in or out.blocks_to_swap_out or out.blocks_to_copy)
+            if DecodeStepArrays.eligible(metas, plain, None):
+                ids = arrays.fill(metas)
+                mi = builder(out).model_input
+                n = len(metas)
+                md = mi.attn_metadata
+                assert ids == mi.sample_seq_ids
+                assert np.array_equal(arrays.input_ids[:n], mi.input_tokens.numpy())
+                assert np.array_equal(arrays.positions[:n], mi.input_positions.numpy())
+                assert np.array_equal(arrays.slot_mapping[:n], md.slot_mapping.numpy())
+                assert np.array_equal(arrays.seq_lens[:n], md.seq_lens_tensor.numpy())
+                w = md.block_tables.shape[1]
+                lens = md.seq_lens_tensor.numpy()
+                for i in range(n):  # entries a kernel may read: the blocks the sequence owns
+                    k = (int(lens[i]) + 3) // 4
+                    assert np.array_equal(arrays.block_tables[i, :k], md.block_tables[i, :k].numpy()), (step, i)
+                assert (arrays.slot_mapping[n:] == -1).all() and (arrays.seq_lens[n:] == 0).all()
+                assert w <= 64
+                checked += 1
+            # finish the step: random tokens, sequences end at max_tokens
+            for sg in out.scheduled_seq_groups:
+                g = sg.seq_group
+                g.update_num_computed_tokens(sg.token_chunk_size)
+                if not g.is_prefill():
+                    for seq in g.get_seqs(status=SequenceStatus.RUNNING):
+                        seq.append_token_id(rng.randint(0, 999))
+                        if seq.get_output_len() >= g.max_tokens:
+                            seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                            s.free_seq(seq)
+            s.free_finished_request([sg.seq_group.request_id for sg in out.scheduled_seq_groups])
+        assert checked > 100, checked
