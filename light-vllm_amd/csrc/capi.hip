@@ -11,6 +11,7 @@ Tuning& tuning() {
     Tuning v;
     if (const char* e = getenv("LVLLM_GEMM_CUS")) v.gemm_workgroups = atoi(e);
     if (const char* e = getenv("LVLLM_GEMM_CUS_WIDE")) v.gemm_workgroups_wide = atoi(e);
+    if (const char* e = getenv("LVLLM_GEMM_WIDE_MIN_TILES")) v.gemm_wide_min_tiles = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     return v;
@@ -29,6 +30,9 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "gemm_workgroups_wide") {
     LV_CHECK(value >= 0 && value <= 1024, "gemm_workgroups_wide must be in [0, 1024]");
     lvllm::tuning().gemm_workgroups_wide = value;
+  } else if (k == "gemm_wide_min_tiles") {
+    LV_CHECK(value >= 1, "gemm_wide_min_tiles must be positive");
+    lvllm::tuning().gemm_wide_min_tiles = value;
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;

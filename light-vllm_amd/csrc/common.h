@@ -24,7 +24,8 @@ void set_error(const std::string& msg);
 //   prefill_lds      1 | 0, see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
-  int gemm_workgroups_wide = 0;  // for projections with >= 1024 n-tiles (gate_up, lm_head); 0 = as above
+  int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
+  int gemm_wide_min_tiles = 1024;  // 1024: gate_up and lm_head of an 8B model; 4096: lm_head only
   int attn_waves = 8;
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
 };

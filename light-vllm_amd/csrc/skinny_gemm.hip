@@ -585,7 +585,7 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   const int ntiles = N / 16;
   // one workgroup (8 waves, ~236 VGPRs: nothing else fits beside it) per CU by default; a host
   // running steps on several streams asks for fewer (common.h Tuning)
-  const int gemm_cus = (ntiles >= 1024 && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
+  const int gemm_cus = (ntiles >= tuning().gemm_wide_min_tiles && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
                                                                             : tuning().gemm_workgroups;
   int groups = gemm_cus / ksplit;
   if (groups < 1) groups = 1;
@@ -668,7 +668,7 @@ extern "C" int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_pack
   const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
   const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;
   const int ntiles = N / 16;
-  int groups = ((ntiles >= 1024 && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
+  int groups = ((ntiles >= tuning().gemm_wide_min_tiles && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
                                                                       : tuning().gemm_workgroups) / ksplit;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
