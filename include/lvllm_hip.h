@@ -306,6 +306,12 @@ int64_t lvllm_skinny_gemm_w8a8_workspace_bytes(int M, int N, int K);
 int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const void* bias,
                            const float* x_scale, const float* w_scale, int M, int N, int K, int64_t ldx,
                            int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+/* As lvllm_skinny_gemm_w8a8 with act = 0; act = 2: W rows are [gate (N/2) | up (N/2)] and y is [M, N/2],
+ * silu_and_mul applied in the epilogue (N % 32 == 0, K not split over workgroups). */
+int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
+                              const float* x_scale, const float* w_scale, int M, int N, int K,
+                              int64_t ldx, int dtype, int act, void* workspace,
+                              int64_t workspace_bytes, void* stream);
 
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);

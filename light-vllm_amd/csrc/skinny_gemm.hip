@@ -355,6 +355,82 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         }
     }
   }
+  if constexpr (W8 && MT * KSTEPS < 32) {
+    // The same for W8A8 (variants whose fragments leave 64 registers for two landing sets; the
+    // others -- K beyond 4096, more than 32 rows -- keep the fragment-order loads below): X arrives in T, 16 consecutive k (32 bytes) of a row per lane and k-step.
+    // A pass is 16 rows x 4 k-steps (512 bytes per row: the geometry of the 16-bit path above), two
+    // passes are in flight in two landing sets, and the values are quantised between the transpose
+    // and the fragment registers with the arithmetic of static_scaled_fp8_quant.
+    staged = true;
+    constexpr int NPASS = MT * (KSTEPS / 4);
+    static_assert(KSTEPS % 4 == 0, "passes are 4 k-steps");
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)x, 0, (int)(((int64_t)(M - 1) * ldx + 2 * (int64_t)K) * 2), 0x00020000);
+    const int b = lane >> 5, pos = lane & 31;
+    const float inv = 1.0f / x_scale[0];
+    char* xs = reinterpret_cast<char*>(stage + (size_t)stage_tiles * MT * 64) + wave * (16 * 512);
+    auto quant8 = [&](const g_u32x4_t v, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[2 * j] = fmaxf(-448.f, fminf(T::to_float((S)(v[j] & 0xffffu)) * inv, 448.f));
+        f[2 * j + 1] = fmaxf(-448.f, fminf(T::to_float((S)(v[j] >> 16)) * inv, 448.f));
+      }
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+    };
+    // two landing sets of 8 loads (one pass each) are in flight; the first weights are requested
+    // right behind the first activations
+    auto stage_x = [&](auto& L0, auto& L1, const bool early_weights) __attribute__((always_inline)) {
+      constexpr int LI = (int)(sizeof(L0) / sizeof(L0[0]));
+      constexpr int SUB = 8 / LI;  // landing sets per pass
+      constexpr int NUNITS = NPASS * SUB;
+      auto issue = [&](const int u, auto& dst) __attribute__((always_inline)) {
+        const int p = u / SUB, i0 = (u % SUB) * LI;
+        const int mt = p / (KSTEPS / 4), sp = p % (KSTEPS / 4);
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+          const int r = 2 * (i0 + i) + b, q = pos ^ r;  // chunk q of the row's 512 bytes sits at position q ^ r
+          const int ks = 4 * sp + (q >> 3), m = mt * 16 + r;
+          const unsigned off = (m < M && ks < nvalid)
+                                   ? (unsigned)(((int64_t)m * ldx + (int64_t)(step0 + ks) * 64 + (q & 7) * 8) * 2)
+                                   : kOutOfRange;
+          dst[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+        }
+      };
+      issue(0, L0);
+      if constexpr (NUNITS > 1) issue(1, L1);
+      if (early_weights) {
+        load_unit(a0, 0, 0);
+        load_unit(a1, 0, 1);
+      }
+#pragma unroll
+      for (int u = 0; u < NUNITS; ++u) {
+        const int p = u / SUB, i0 = (u % SUB) * LI;
+        const int mt = p / (KSTEPS / 4), sp = p % (KSTEPS / 4);
+#pragma unroll
+        for (int i = 0; i < LI; ++i)
+          *reinterpret_cast<g_u32x4_t*>(xs + (i0 + i) * 1024 + lane * 16) = (u & 1) ? L1[i] : L0[i];
+        if (u + 2 < NUNITS) {
+          if (u & 1) issue(u + 2, L1); else issue(u + 2, L0);
+        }
+        if ((u % SUB) == SUB - 1) {  // the pass's 16 rows are in the scratch
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const int q0 = 8 * s2 + 2 * g;
+            uint32_t o0, o1, o2, o3;
+            const g_u32x4_t v0 = *reinterpret_cast<const g_u32x4_t*>(xs + c * 512 + ((q0 ^ c) * 16));
+            quant8(v0, o0, o1);
+            const g_u32x4_t v1 = *reinterpret_cast<const g_u32x4_t*>(xs + c * 512 + (((q0 + 1) ^ c) * 16));
+            quant8(v1, o2, o3);
+            xf[mt][4 * sp + s2] = g_u32x4_t{o0, o1, o2, o3};
+          }
+        }
+      }
+    };
+    g_u32x4_t l0[8], l1[8];
+    stage_x(l0, l1, true);
+  }
   if (!staged) {
     load_unit(a0, 0, 0);
     load_unit(a1, 0, 1);
@@ -476,7 +552,8 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
   const int tiles_per_wg = glu ? 2 * ((ntiles / 2 + groups - 1) / groups) : (ntiles + groups - 1) / groups;
   int stage_tiles = ((tiles_per_wg + NT - 1) / NT) * NT;
   // wave-private scratch that turns row-order activation loads into fragments (16-bit path only)
-  const size_t xs_bytes = W8 ? 0 : (size_t)kGemmWaves * 16 * (KSTEPS / 2) * 64;
+  const size_t xs_bytes = W8 ? (MT * KSTEPS < 32 ? (size_t)kGemmWaves * 16 * 512 : 0)
+                             : (size_t)kGemmWaves * 16 * (KSTEPS / 2) * 64;
   const int cap = (int)((160 * 1024 - red_bytes - xs_bytes) / ((size_t)MT * 1024) / NT) * NT;
   if (stage_tiles > cap) stage_tiles = cap;
   if (stage_tiles < NT) stage_tiles = NT;
@@ -649,11 +726,26 @@ extern "C" int64_t lvllm_skinny_gemm_w8a8_workspace_bytes(int M, int N, int K) {
   return lvllm_skinny_gemm_workspace_bytes(M, N, K / 2);
 }
 
+extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
+                                         const float* x_scale, const float* w_scale, int M, int N, int K,
+                                         int64_t ldx, int dtype, int act, void* workspace,
+                                         int64_t workspace_bytes, void* stream);
+
 extern "C" int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const void* bias,
                                       const float* x_scale, const float* w_scale, int M, int N, int K,
                                       int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
                                       void* stream) {
+  return lvllm_skinny_gemm_w8a8_ex(y, x, w_packed, bias, x_scale, w_scale, M, N, K, ldx, dtype, 0, workspace,
+                                   workspace_bytes, stream);
+}
+
+// act = 2: W rows are [gate | up], y [M, N/2] = silu_and_mul of the projection (see lvllm_skinny_gemm_ex)
+extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
+                                         const float* x_scale, const float* w_scale, int M, int N, int K,
+                                         int64_t ldx, int dtype, int act, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0) return 0;
+  LV_CHECK(act == 0 || act == 2, "lvllm_skinny_gemm_w8a8_ex: act must be 0 or 2");
   LV_CHECK(x_scale != nullptr && w_scale != nullptr, "scales are device pointers to one float each");
   if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 64) != 0 || (N % 16) != 0 ||
       (int64_t)N * K >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
@@ -672,6 +764,10 @@ extern "C" int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_pack
                                                                       : tuning().gemm_workgroups) / ksplit;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
+  if (act == 2) {
+    LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
+    if (groups > ntiles / 2) groups = ntiles / 2;
+  }
   float* partial = nullptr;
   if (ksplit > 1) {
     LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
@@ -685,10 +781,10 @@ extern "C" int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_pack
   do {                                                                                                    \
     if (k8 || MT_ == 4)                                                                                   \
       launch_skinny<T_, MT_, 8, true>(y, partial, x, w_packed, bias, M, N, K2, ldx, steps_per_wave, ntiles, \
-                                      groups, ksplit, true, 0, s, x_scale, w_scale);                      \
+                                      groups, ksplit, true, act, s, x_scale, w_scale);                    \
     else                                                                                                  \
       launch_skinny<T_, MT_, (MT_ == 4 ? 8 : 16), true>(y, partial, x, w_packed, bias, M, N, K2, ldx,       \
-                                                       steps_per_wave, ntiles, groups, ksplit, true, 0, s, \
+                                                       steps_per_wave, ntiles, groups, ksplit, true, act, s, \
                                                        x_scale, w_scale);                                 \
   } while (0)
 #define LV_SG8_MT(T_)          \

@@ -560,6 +560,37 @@ torch::Tensor skinny_linear_w8a8(const torch::Tensor& x, const torch::Tensor& w_
   return y;
 }
 
+// W8A8 gate_up projection + silu_and_mul in one launch ([M, N / 2]); falls back to the two launches
+// when K is split over workgroups at this M.  Bit-identical to skinny_linear_w8a8 + silu_and_mul.
+torch::Tensor skinny_linear_w8a8_swiglu(const torch::Tensor& x, const torch::Tensor& w_packed,
+                                        const torch::Tensor& w_scale, const torch::Tensor& x_scale, int64_t N,
+                                        int64_t K, const std::optional<torch::Tensor>& bias) {
+  TORCH_CHECK(N % 32 == 0, "skinny_linear_w8a8_swiglu: N must be a multiple of 32");
+  const int64_t M = x.size(0);
+  auto y = torch::empty({M, N / 2}, x.options());
+  if (lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K) > 0) {
+    auto gate_up = skinny_linear_w8a8(x, w_packed, w_scale, x_scale, N, K, bias);
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+    check(lvllm_silu_and_mul(y.data_ptr(), gate_up.data_ptr(), M, (int)(N / 2), dtype_code(x, "silu_and_mul"),
+                             current_stream(x)));
+    return y;
+  }
+  LV_CHECK_DEVICE(x);
+  LV_CHECK_DEVICE(w_packed);
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1, "skinny_linear_w8a8_swiglu: x must be [M, K]");
+  TORCH_CHECK(w_packed.is_contiguous() && w_packed.numel() * w_packed.element_size() == N * K,
+              "skinny_linear_w8a8_swiglu: w_packed must hold N*K fp8 bytes");
+  TORCH_CHECK(w_scale.scalar_type() == at::kFloat && x_scale.scalar_type() == at::kFloat && w_scale.is_cuda() &&
+                  x_scale.is_cuda() && w_scale.numel() == 1 && x_scale.numel() == 1,
+              "skinny_linear_w8a8_swiglu: per-tensor float32 scales on the device");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  check(lvllm_skinny_gemm_w8a8_ex(y.data_ptr(), x.data_ptr(), w_packed.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                                  x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N, (int)K,
+                                  x.stride(0), dtype_code(x, "skinny_linear_w8a8_swiglu"), 2, nullptr, 0,
+                                  current_stream(x)));
+  return y;
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -699,6 +730,9 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("skinny_linear_w8a8(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
           "Tensor? bias) -> Tensor");
   amd.impl("skinny_linear_w8a8", torch::kCUDA, &skinny_linear_w8a8);
+  amd.def("skinny_linear_w8a8_swiglu(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
+          "Tensor? bias) -> Tensor");
+  amd.impl("skinny_linear_w8a8_swiglu", torch::kCUDA, &skinny_linear_w8a8_swiglu);
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });

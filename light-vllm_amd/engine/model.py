@@ -217,7 +217,11 @@ class DecoderModel:
                                              attn_metadata)
             hidden = linear(attn_out, lw.o)
             hidden = self._add_norm(hidden, residual, lw.post_norm)
-            if (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.packed is not None and lw.gate_up.N % 32 == 0
+            if (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.w8_packed is not None and lw.gate_up.N % 32 == 0
+                    and T <= 64):
+                g = lw.gate_up
+                act = torch.ops._C_amd.skinny_linear_w8a8_swiglu(hidden, g.w8_packed, g.w_scale, g.x_scale, g.N, g.K, None)
+            elif (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.packed is not None and lw.gate_up.N % 32 == 0
                     and not _CALIBRATING):
                 # gate_up projection with silu_and_mul in its epilogue: one launch, no [T, 2 inter] round trip
                 act = torch.ops._C_amd.skinny_linear_packed_swiglu(hidden, lw.gate_up.packed, None,

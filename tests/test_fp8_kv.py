@@ -294,6 +294,28 @@ def test_convert_fp8_both_directions(ops, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,inter,K", [(32, 14336, 4096), (1, 256, 128), (17, 1040, 1024), (64, 2048, 2048),
+                                       (33, 512, 8192)])
+def test_w8a8_swiglu_epilogue_is_bit_identical_to_the_two_launches(ops, dtype, M, inter, K):
+    from light_vllm_amd.quantization import pack_fp8_weight, skinny_fp8_linear
+    g = torch.Generator(device=DEV).manual_seed(M + inter + K)
+    x = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    w = torch.randn(2 * inter, K, generator=g, device=DEV) * 0.05
+    bias = torch.randn(2 * inter, generator=g, device=DEV).to(dtype)
+    w_scale = (w.abs().max() / 448.0).reshape(1).float()
+    wp = pack_fp8_weight((w / w_scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+    x_scale = (x.float().abs().max() / 448.0).reshape(1)
+    for b in (None, bias):
+        gate_up = skinny_fp8_linear(x, wp, w_scale, x_scale, 2 * inter, K, b)
+        ref = torch.empty(M, inter, dtype=dtype, device=DEV)
+        ops.silu_and_mul(ref, gate_up)
+        out = torch.ops._C_amd.skinny_linear_w8a8_swiglu(x, wp, w_scale, x_scale, 2 * inter, K, b)
+        assert out.shape == (M, inter)
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 7, 16, 32, 64])
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (256, 14336), (512, 64), (48, 8192)])
 def test_skinny_w8a8_vs_dequantised_matmul(ops, dtype, M, N, K):
