@@ -188,6 +188,14 @@ int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, i
                       int64_t workspace_bytes, void* stream);
 /* Reorders row-major W[N,K] into the packed order (out of place; N % 16 == 0, K % 32 == 0). */
 int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream);
+/* The same product for 1 <= M <= 256 rows (meant for 65..256: a large decode batch, a prefill chunk):
+ * X goes through LDS, the waves of a workgroup split N, K is split over workgroups where N alone
+ * would not fill the GPU (fp32 partials in `workspace`, lvllm_stream_gemm_workspace_bytes).
+ * W packed by lvllm_pack_weight.  Returns 3 outside the envelope (M > 256, K % 32, N % 16, W >= 4 GiB). */
+int64_t lvllm_stream_gemm_workspace_bytes(int M, int N, int K);
+int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, const void* bias, int M, int N,
+                      int K, int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 /* As lvllm_skinny_gemm, plus: act = 1 -> X rows are [gate | up] (2K wide) and the kernel
  * multiplies by T(T(silu(gate)) * up) (silu_and_mul fused into the down projection);
  * act = 2 -> W rows are [gate (N/2) | up (N/2)] and y is [M, N/2] = silu_and_mul of the projection,

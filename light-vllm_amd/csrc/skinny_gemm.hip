@@ -580,6 +580,152 @@ extern "C" int lvllm_gemm_trace_read(void* host_dst, int nwords) {
 }
 #endif
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight-streaming GEMM for 65..256 rows (a decode step of a large batch, a prefill chunk):
+//   Y[M,N] = X[M,K] . W[N,K]^T (+ bias), W packed as above, bf16/f16, fp32 accumulate.
+// With this many rows the activations no longer fit a wave's registers, so the roles are turned
+// round: the 8 waves of a workgroup split N -- wave w owns n-tile 8 G + w of tile group G and walks
+// the whole K range of the workgroup -- and X goes through LDS, shared by the 8 waves: a chunk of
+// KC k-steps x (16 MT) rows (64 KiB) is copied L2 -> LDS by the DMA path (buffer_load ... lds,
+// row order, XOR-swizzled like the scratch of the small kernel), double-buffered, one barrier per
+// chunk.  W still goes HBM -> VGPR -> MFMA A operand, 1 KiB per wave load, a chunk ahead.  No
+// cross-wave reduction.  Small N (qkv, o, down: 32-48 tile groups) would leave most CUs idle, so K is
+// also split over workgroups (blockIdx.y) there; the fp32 partials are summed by the reduce kernel
+// above.  One pass over W.  Measured against hipBLASLt at M = 128 (tools/bench_stream_gemm.py): down
+// 39 vs 76 us, o 22 vs 24, qkv 27 vs 26, gate_up 62 vs 56 -- every wave reads every activation from
+// LDS (8 bytes of LDS per byte of W), which is what bounds the wide shapes; a 32x32x16-MFMA variant
+// (half the LDS reads, W fetched by two waves) was correct and slower (gate_up 80 us).  The engine
+// uses this kernel where it wins: K >= 8192 (the down projection).
+template <typename T, int MT, int KC>
+__global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
+    typename T::store_t* __restrict__ y, float* __restrict__ partial,
+    const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
+    const typename T::store_t* __restrict__ bias, const int M, const int N, const int K, const int64_t ldx,
+    const int ntiles, const int steps_per_split) {
+  LVLLM_TRACE_BEGIN();
+  constexpr int ROWS = 16 * MT;       // rows of X held in LDS (rows >= M are zero)
+  constexpr int RB = KC * 64;         // bytes of one row in one chunk
+  constexpr int NCH = KC * 4;         // 16-byte chunks per row and chunk
+  constexpr int RPI = 1024 / RB;      // rows one wave-wide DMA covers
+  constexpr int DMA = ROWS / RPI / kGemmWaves;  // DMA instructions per wave and chunk
+  static_assert(NCH >= 16 && ROWS % (RPI * kGemmWaves) == 0, "chunk geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [2][ROWS][RB]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int total_steps = K >> 5;
+  const int s_begin = blockIdx.y * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+  const int nchunks = (s_end - s_begin + KC - 1) / KC;
+
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)N * K * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
+  const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2);
+  auto opaque = [](unsigned v) __attribute__((always_inline)) {
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    asm("" : "+s"(v));
+    return v;
+  };
+
+  // X chunk ci -> LDS buffer ci & 1.  Wave-wide copy j of this wave covers rows RPI (DMA wave + j) ..;
+  // chunk q of row r lands at position q ^ (r & 15)
+  const int xb = lane / NCH, xpos = lane % NCH;
+  auto issue_x = [&](const int ci) __attribute__((always_inline)) {
+    char* buf = smem_raw + (size_t)(ci & 1) * ROWS * RB;
+    const int step0 = s_begin + ci * KC;
+#pragma unroll
+    for (int j = 0; j < DMA; ++j) {
+      const int i = wave * DMA + j;
+      const int r = i * RPI + xb, q = xpos ^ (r & 15);
+      const int ks = step0 + (q >> 2);
+      const unsigned off = (r < M && ks < s_end) ? (unsigned)(((int64_t)r * ldx + (int64_t)ks * 32 + (q & 3) * 8) * 2)
+                                                 : kOutOfRange;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, off,
+                                               0, 0, 0);
+    }
+  };
+  auto issue_w = [&](g_u32x4_t (&a)[KC], const int t, const unsigned tmask, const int ci) __attribute__((always_inline)) {
+    const int step0 = s_begin + ci * KC;
+    const unsigned base = (unsigned)(lane * 16) + (unsigned)t * tile_stride;
+#pragma unroll
+    for (int s = 0; s < KC; ++s) {
+      const unsigned kmask = opaque(step0 + s < s_end ? 0u : ~0u);
+      a[s] = __builtin_amdgcn_raw_buffer_load_b128(wr, (base + (unsigned)(step0 + s) * 1024u) | tmask | kmask, 0,
+                                                   LVLLM_GEMM_AUX);
+    }
+  };
+  auto compute = [&](const g_u32x4_t (&a)[KC], g_f32x4_t (&acc)[MT], const int ci) __attribute__((always_inline)) {
+    const char* buf = smem_raw + (size_t)(ci & 1) * ROWS * RB;
+#pragma unroll
+    for (int s = 0; s < KC; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const g_u32x4_t xb4 =
+            *reinterpret_cast<const g_u32x4_t*>(buf + (16 * mt + c) * RB + (((4 * s + g) ^ c) * 16));
+        acc[mt] = gemm_mfma<T>(a[s], xb4, acc[mt]);
+      }
+  };
+  constexpr int kWaitAll = 0 | (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0): the DMA copies are not tracked by the compiler
+
+  const int ngroups_total = (ntiles + kGemmWaves - 1) / kGemmWaves;
+  for (int grp = blockIdx.x; grp < ngroups_total; grp += gridDim.x) {
+    const int t = grp * kGemmWaves + wave;
+    const unsigned tmask = opaque(t < ntiles ? 0u : ~0u);
+    g_f32x4_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    g_u32x4_t a0[KC], a1[KC];
+    __syncthreads();  // the previous group's readers are done with both LDS buffers
+    issue_x(0);
+    issue_w(a0, t, tmask, 0);
+    for (int ci = 0; ci < nchunks; ci += 2) {
+      __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __syncthreads();  // chunk ci is in LDS; everyone is past chunk ci - 1
+      if (ci + 1 < nchunks) {
+        issue_x(ci + 1);
+        issue_w(a1, t, tmask, ci + 1);
+      }
+      compute(a0, acc, ci);
+      if (ci + 1 < nchunks) {
+        __builtin_amdgcn_s_waitcnt(kWaitAll);
+        __syncthreads();
+        if (ci + 2 < nchunks) {
+          issue_x(ci + 2);
+          issue_w(a0, t, tmask, ci + 2);
+        }
+        compute(a1, acc, ci + 1);
+      }
+    }
+    // lane (g, c): rows n = 16 t + 4 g + r of column m = 16 mt + c
+    const int n0 = 16 * t + 4 * g;
+    if (t < ntiles) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + c;
+        if (m < M) {
+          g_f32x4_t sum = acc[mt];
+          if (partial != nullptr) {
+            *reinterpret_cast<g_f32x4_t*>(partial + ((int64_t)blockIdx.y * M + m) * N + n0) = sum;
+          } else {
+            if (bias != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sum[r] += T::to_float(bias[n0 + r]);
+            }
+            uint2 o;
+            o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
+            o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
+            *reinterpret_cast<uint2*>(y + (int64_t)m * N + n0) = o;
+          }
+        }
+      }
+    }
+  }
+  LVLLM_TRACE_END(6);
+}
+
 LVLLM_TRACE_READER(lvllm_trace_read_gemm)
 
 // W[N,K] row-major -> packed [N/16][K/32][4][16][8]; one thread per 16-byte chunk
@@ -806,6 +952,82 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
     else
       hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
                          (const uint16_t*)bias, MN, N, ksplit, x_scale, w_scale);
+    LV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- 65..256 rows --------------------------------------------------------------------------
+static inline int stream_gemm_ksplit(int M, int N, int K) {
+  const int KC = M <= 128 ? 8 : 4;
+  const int total_steps = K / 32;
+  const int groups = (N / 16 + kGemmWaves - 1) / kGemmWaves;
+  int ksplit = tuning().gemm_workgroups / groups;  // fill the CUs the host allows
+  const int max_split = (total_steps + 2 * KC - 1) / (2 * KC);  // at least two chunks per workgroup
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit > 16) ksplit = 16;
+  if (ksplit < 1) ksplit = 1;
+  return ksplit;
+}
+
+extern "C" int64_t lvllm_stream_gemm_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K < 32) return 0;
+  const int ksplit = stream_gemm_ksplit(M, N, K);
+  return ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0;
+}
+
+// Y[M,N] = X[M,K] . W[N,K]^T (+ bias[N]) for 1 <= M <= 256 rows (meant for 65..256; the register-resident
+// kernel above is faster below).  W packed by lvllm_pack_weight.  Returns 3 outside the envelope.
+extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, const void* bias, int M, int N,
+                                 int K, int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 256 || (K % 32) != 0 || (N % 16) != 0 ||
+      (int64_t)N * K * 2 >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
+      ((int64_t)(M - 1) * ldx + K) * 2 >= ((int64_t)1 << 31) ||
+      ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) & 15) != 0)) {
+    set_error("lvllm_stream_gemm: shape outside the kernel's envelope");
+    return 3;
+  }
+  const int ntiles = N / 16;
+  const int groups_total = (ntiles + kGemmWaves - 1) / kGemmWaves;
+  const int ksplit = stream_gemm_ksplit(M, N, K);
+  const int total_steps = K / 32;
+  const int KC = M <= 128 ? 8 : 4;
+  int steps_per_split = (total_steps + ksplit - 1) / ksplit;
+  steps_per_split = (steps_per_split + KC - 1) / KC * KC;  // whole chunks
+  float* partial = nullptr;
+  if (ksplit > 1) {
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
+             "workspace too small (see lvllm_stream_gemm_workspace_bytes)");
+    partial = (float*)workspace;
+  }
+  int groups = tuning().gemm_workgroups / ksplit;
+  if (groups < 1) groups = 1;
+  if (groups > groups_total) groups = groups_total;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t smem = (size_t)2 * 128 * 512;  // [2][ROWS][RB]: 128 x 512 or 256 x 256 bytes
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, s, (uint16_t*)y, partial,
+                       (const uint16_t*)x, (const uint16_t*)w_packed, (const uint16_t*)bias, M, N, K, ldx, ntiles,
+                       steps_per_split);
+  };
+  if (dtype == LVLLM_BF16) {
+    if (M <= 128) go(stream_gemm_kernel<BF16, 8, 8>); else go(stream_gemm_kernel<BF16, 16, 4>);
+  } else {
+    if (M <= 128) go(stream_gemm_kernel<F16, 8, 8>); else go(stream_gemm_kernel<F16, 16, 4>);
+  }
+  LV_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const int64_t MN = (int64_t)M * N;
+    const int grid = (int)((MN / 4 + 255) / 256);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<BF16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit);
     LV_LAUNCH_CHECK();
   }
   return 0;

@@ -304,6 +304,27 @@ torch::Tensor skinny_linear_packed(const torch::Tensor& x, const torch::Tensor& 
   return y;
 }
 
+// 65..256 rows (large decode batches, prefill chunks): X through LDS, see lvllm_stream_gemm
+torch::Tensor stream_linear_packed(const torch::Tensor& x, const torch::Tensor& w_packed,
+                                   const std::optional<torch::Tensor>& bias, int64_t N, int64_t K) {
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && w_packed.numel() == N * K && x.stride(1) == 1,
+              "stream_linear_packed: bad shapes");
+  TORCH_CHECK(x.is_cuda() && w_packed.is_cuda() && w_packed.is_contiguous() && x.size(0) >= 1 && x.size(0) <= 256 &&
+                  (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kHalf) &&
+                  w_packed.scalar_type() == x.scalar_type() && (!bias || bias->is_contiguous()),
+              "stream_linear_packed: 1..256 rows of bf16/f16 on the GPU");
+  const int64_t M = x.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto y = torch::empty({M, N}, x.options());
+  const int64_t ws_bytes = lvllm_stream_gemm_workspace_bytes((int)M, (int)N, (int)K);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
+  check(lvllm_stream_gemm(y.data_ptr(), x.data_ptr(), w_packed.data_ptr(), bias ? bias->data_ptr() : nullptr, (int)M,
+                          (int)N, (int)K, x.stride(0), dtype_code(x, "stream_linear_packed"),
+                          ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, current_stream(x)));
+  return y;
+}
+
 // gate_up projection + silu_and_mul in one launch: w_packed holds [gate rows | up rows] ([N, K]
 // packed), the result is [M, N / 2].  Bit-identical to skinny_linear_packed followed by silu_and_mul.
 torch::Tensor skinny_linear_packed_swiglu(const torch::Tensor& x, const torch::Tensor& w_packed,
@@ -711,6 +732,8 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_packed", torch::kCUDA, &skinny_linear_packed);
   amd.def("pack_weight(Tensor w) -> Tensor");
   amd.impl("pack_weight", torch::kCUDA, &pack_weight);
+  amd.def("stream_linear_packed(Tensor x, Tensor w_packed, Tensor? bias, int N, int K) -> Tensor");
+  amd.impl("stream_linear_packed", torch::kCUDA, &stream_linear_packed);
   amd.def("skinny_linear_packed_swiglu(Tensor x, Tensor w_packed, Tensor? bias, int N, int K) -> Tensor");
   amd.impl("skinny_linear_packed_swiglu", torch::kCUDA, &skinny_linear_packed_swiglu);
   amd.def("skinny_linear_packed_partials(Tensor x, Tensor w_packed, int N, int K, bool swiglu) -> Tensor");

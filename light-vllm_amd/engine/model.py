@@ -65,10 +65,16 @@ def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) ->
     if x.shape[0] <= 64 and x.is_cuda:
         if w.packed is not None:
             return torch.ops._C_amd.skinny_linear_packed(x, w.packed, bias, w.N, w.K)
+    elif (x.shape[0] <= _STREAM_GEMM_MAX_ROWS and w.K >= 8192 and x.is_cuda and w.packed is not None
+          and x.stride(1) == 1):
+        # 65..256 rows of a long-K projection (down): X through LDS, one pass over the packed weights;
+        # 39 us against the library's 76 at M = 128 (tools/bench_stream_gemm.py)
+        return torch.ops._C_amd.stream_linear_packed(x, w.packed, bias, w.N, w.K)
     return F.linear(x, w.w, bias)
 
 
 _CALIBRATING = False
+_STREAM_GEMM_MAX_ROWS = int(os.environ.get("LVLLM_STREAM_GEMM_MAX_ROWS", "256"))
 _SWIGLU_EPILOGUE = os.environ.get("LVLLM_SWIGLU_EPILOGUE", "1") != "0"  # A/B switch
 
 

@@ -128,3 +128,32 @@ def test_swiglu_epilogue_is_bit_identical_to_projection_then_silu_and_mul(ops, d
             assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
     finally:
         torch.ops._C_amd.set_tuning("gemm_workgroups", 256)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(128, 6144, 4096), (128, 4096, 14336), (65, 28672, 4096), (96, 4096, 4096),
+                                   (129, 4096, 4096), (256, 6144, 4096), (200, 1536, 8960), (1, 4096, 4096),
+                                   (77, 48, 64), (128, 16, 32), (130, 272, 1056), (64, 128256, 4096)])
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_stream_linear_matches_fp32_matmul(ops, dtype, M, N, K, use_bias):
+    """The 65..256-row weight-streaming kernel (X through LDS, K split over workgroups for small N)
+    against the fp32 product of the same operands; strided rows as the engine passes them."""
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    big = (torch.randn(M, K + 64, generator=g, device=DEV) * 0.5).to(dtype)
+    x = big[:, 32:32 + K]  # a strided view
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype)
+    b = (torch.randn(N, generator=g, device=DEV) * 0.5).to(dtype) if use_bias else None
+    wp = torch.ops._C_amd.pack_weight(w)
+    for wgs in (256, 128):
+        torch.ops._C_amd.set_tuning("gemm_workgroups", wgs)
+        try:
+            y = torch.ops._C_amd.stream_linear_packed(x, wp, b, N, K)
+        finally:
+            torch.ops._C_amd.set_tuning("gemm_workgroups", 256)
+        ref = x.float() @ w.float().T
+        if b is not None:
+            ref = ref + b.float()
+        assert y.shape == (M, N) and y.dtype == dtype
+        err = (y.float() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9) * scale + 1e-3, (err, scale, wgs)
