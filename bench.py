@@ -133,6 +133,45 @@ def kernel_leg(engine, B, iters):
     return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P)
 
 
+def gemm_leg(engine, B):
+    """The other HBM stream of a decode step: the four weight-streaming projections of a layer
+    (csrc/skinny_gemm.hip), timed on the engine's own packed weights -- trains of one launch per layer
+    (32 different weight matrices per train, >> the Infinity Cache) with HIP events on the launch
+    stream, at the workgroup count a lone step would use (256).  Returns None when the engine's
+    weights are not the packed 16-bit ones (library GEMM, fp8)."""
+    model = engine.worker.model
+    layers = model.layers
+    if any(l.qkv.packed is None for l in layers):
+        return None
+    dev = engine.device
+    cfg = engine.model_config
+    torch.ops._C_amd.set_tuning("gemm_workgroups", 256)
+    try:
+        per_shape, tot_bytes, tot_s = {}, 0, 0.0
+        for name in ("qkv", "o", "gate_up", "down"):
+            ws = [getattr(l, name) for l in layers]
+            N, K = ws[0].N, ws[0].K
+            x = (torch.randn(B, K, device=dev) * 0.5).to(cfg.dtype)
+            for w in ws[:4]:
+                torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
+            torch.cuda.synchronize(dev)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+            for a, b in evs:
+                a.record()
+                for w in ws:
+                    torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
+                b.record()
+            torch.cuda.synchronize(dev)
+            t = min(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(ws)
+            by = N * K * 2 + B * K * 2 + B * N * 2  # weights once + activations in + result out
+            per_shape[name] = {"us": round(t * 1e6, 2), "GB/s": round(by / t / 1e9, 1)}
+            tot_bytes += by
+            tot_s += t
+        return dict(per_shape=per_shape, bytes_per_layer=tot_bytes, s_per_layer=tot_s)
+    finally:
+        torch.ops._C_amd.set_tuning("gemm_workgroups", 128 if engine.num_slots > 1 else 256)
+
+
 def cpu_baseline_leg(engine, B, budget_s=20.0):
     """paged_attention_v2 of the same shapes on the host cores: the reference's own csrc/cpu
     backend (oracle/_ref, kind "reference") when it is present and the CPU has AVX512, else
@@ -248,6 +287,7 @@ def main():
     value = group.sum(tokens) / elapsed      # whole-job tokens/s
 
     k = kernel_leg(engine, B, a.kernel_iters)
+    gm = gemm_leg(engine, B) if B <= 64 else None
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
         cpu = cpu_baseline_leg(engine, B)
@@ -287,6 +327,14 @@ def main():
                          "avg_launch_us": round(k["avg_s"] * 1e6, 2), "min_launch_us": round(k["min_s"] * 1e6, 2)},
             "cpu_baseline": cpu,
         }
+        if gm is not None:  # the second HBM stream of the step: one layer's four projections
+            g_ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
+            line["roofline_projections"] = {
+                "bound": "hbm", "kernel": "skinny_gemm_kernel (qkv, o, gate_up + SwiGLU input, down of one layer, M = "
+                                          f"{B}, 256 workgroups)",
+                "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
+                "us_per_layer": round(gm["s_per_layer"] * 1e6, 2), "per_shape": gm["per_shape"]}
         print(json.dumps(line), flush=True)
     group.shutdown()
 
