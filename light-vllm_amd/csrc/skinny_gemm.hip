@@ -587,17 +587,19 @@ extern "C" int lvllm_gemm_trace_read(void* host_dst, int nwords) {
 // With this many rows the activations no longer fit a wave's registers, so the roles are turned
 // round: the 8 waves of a workgroup split N -- wave w owns n-tile 8 G + w of tile group G and walks
 // the whole K range of the workgroup -- and X goes through LDS, shared by the 8 waves: a chunk of
-// KC k-steps x (16 MT) rows (64 KiB) is copied L2 -> LDS by the DMA path (buffer_load ... lds,
-// row order, XOR-swizzled like the scratch of the small kernel), double-buffered, one barrier per
-// chunk.  W still goes HBM -> VGPR -> MFMA A operand, 1 KiB per wave load, a chunk ahead.  No
+// KC k-steps x (16 MT) rows (32 KiB at M <= 128) is copied L2 -> LDS by the DMA path (buffer_load ...
+// lds, row order, XOR-swizzled like the scratch of the small kernel) into a ring of three chunks
+// (two at M > 128), one barrier per chunk, counted vmcnt waits so that the next chunk stays in
+// flight across the barrier.  W goes HBM -> VGPR -> MFMA A operand, 1 KiB per wave load, in step
+// with the ring.  No
 // cross-wave reduction.  Small N (qkv, o, down: 32-48 tile groups) would leave most CUs idle, so K is
 // also split over workgroups (blockIdx.y) there; the fp32 partials are summed by the reduce kernel
 // above.  One pass over W.  Measured against hipBLASLt at M = 128 (tools/bench_stream_gemm.py): down
-// 39 vs 76 us, o 22 vs 24, qkv 27 vs 26, gate_up 62 vs 56 -- every wave reads every activation from
+// 37 vs 76 us, o 21 vs 24, qkv 26 vs 27, gate_up 59 vs 55 -- every wave reads every activation from
 // LDS (8 bytes of LDS per byte of W), which is what bounds the wide shapes; a 32x32x16-MFMA variant
 // (half the LDS reads, W fetched by two waves) was correct and slower (gate_up 80 us).  The engine
 // uses this kernel where it wins: K >= 8192 (the down projection).
-template <typename T, int MT, int KC>
+template <typename T, int MT, int KC, int NST>  // NST: chunks in the ring (2 or 3)
 __global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
     typename T::store_t* __restrict__ y, float* __restrict__ partial,
     const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
@@ -630,11 +632,11 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
     return v;
   };
 
-  // X chunk ci -> LDS buffer ci & 1.  Wave-wide copy j of this wave covers rows RPI (DMA wave + j) ..;
+  // X chunk ci -> LDS stage ci % NST.  Wave-wide copy j of this wave covers rows RPI (DMA wave + j) ..;
   // chunk q of row r lands at position q ^ (r & 15)
   const int xb = lane / NCH, xpos = lane % NCH;
   auto issue_x = [&](const int ci) __attribute__((always_inline)) {
-    char* buf = smem_raw + (size_t)(ci & 1) * ROWS * RB;
+    char* buf = smem_raw + (size_t)(ci % NST) * ROWS * RB;
     const int step0 = s_begin + ci * KC;
 #pragma unroll
     for (int j = 0; j < DMA; ++j) {
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
     }
   };
   auto compute = [&](const g_u32x4_t (&a)[KC], g_f32x4_t (&acc)[MT], const int ci) __attribute__((always_inline)) {
-    const char* buf = smem_raw + (size_t)(ci & 1) * ROWS * RB;
+    const char* buf = smem_raw + (size_t)(ci % NST) * ROWS * RB;
 #pragma unroll
     for (int s = 0; s < KC; ++s)
 #pragma unroll
@@ -668,7 +670,6 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
         acc[mt] = gemm_mfma<T>(a[s], xb4, acc[mt]);
       }
   };
-  constexpr int kWaitAll = 0 | (7 << 4) | (15 << 8);  // s_waitcnt vmcnt(0): the DMA copies are not tracked by the compiler
 
   const int ngroups_total = (ntiles + kGemmWaves - 1) / kGemmWaves;
   for (int grp = blockIdx.x; grp < ngroups_total; grp += gridDim.x) {
@@ -677,27 +678,41 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void stream_gemm_kernel(
     g_f32x4_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = g_f32x4_t{0.f, 0.f, 0.f, 0.f};
-    g_u32x4_t a0[KC], a1[KC];
-    __syncthreads();  // the previous group's readers are done with both LDS buffers
-    issue_x(0);
-    issue_w(a0, t, tmask, 0);
-    for (int ci = 0; ci < nchunks; ci += 2) {
-      __builtin_amdgcn_s_waitcnt(kWaitAll);
-      __syncthreads();  // chunk ci is in LDS; everyone is past chunk ci - 1
-      if (ci + 1 < nchunks) {
-        issue_x(ci + 1);
-        issue_w(a1, t, tmask, ci + 1);
+    // A ring of NST chunks: chunk ci is consumed while chunks ci+1 .. ci+NST-2 are in flight.  (With two
+    // stages the wait for chunk ci+1 starts one chunk's MFMAs after its loads were issued: the memory
+    // pipeline drains at every boundary, 3.9 us per 128 KiB chunk where the stream alone needs 2.)
+    g_u32x4_t a[NST][KC];
+    constexpr int kOps = DMA + KC;  // vector-memory operations one chunk costs a wave
+    static_assert((NST - 2) * kOps < 64, "vmcnt range");
+    __syncthreads();  // the previous group's readers are done with the LDS ring
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k)
+      if (k < nchunks) {
+        issue_x(k);
+        issue_w(a[k], t, tmask, k);
       }
-      compute(a0, acc, ci);
-      if (ci + 1 < nchunks) {
-        __builtin_amdgcn_s_waitcnt(kWaitAll);
-        __syncthreads();
-        if (ci + 2 < nchunks) {
-          issue_x(ci + 2);
-          issue_w(a0, t, tmask, ci + 2);
-        }
-        compute(a1, acc, ci + 1);
+    auto step = [&](const int ci, const g_u32x4_t (&cur)[KC], g_u32x4_t (&nxt)[KC]) __attribute__((always_inline)) {
+      // vmcnt retires in order: once only the younger chunks' operations are outstanding, chunk ci
+      // (its DMA copies, which the compiler does not track, and its weight registers) has landed
+      const int younger = (nchunks - 1 - ci) < (NST - 2) ? (nchunks - 1 - ci) : (NST - 2);
+      if (younger <= 0) {
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+      } else {
+        constexpr int n1 = kOps;
+        __builtin_amdgcn_s_waitcnt((n1 & 15) | (7 << 4) | (15 << 8) | ((n1 >> 4) << 14));
       }
+      __syncthreads();  // chunk ci is in LDS for everyone; everyone is past chunk ci - 1
+      if (ci + NST - 1 < nchunks) {
+        issue_x(ci + NST - 1);
+        issue_w(nxt, t, tmask, ci + NST - 1);
+      }
+      compute(cur, acc, ci);
+    };
+    static_assert(NST == 2 || NST == 3, "the wait above covers one younger chunk at most");
+    for (int ci = 0; ci < nchunks; ci += NST) {
+#pragma unroll
+      for (int k = 0; k < NST; ++k)
+        if (ci + k < nchunks) step(ci + k, a[k], a[(k + NST - 1) % NST]);
     }
     // lane (g, c): rows n = 16 t + 4 g + r of column m = 16 mt + c
     const int n0 = 16 * t + 4 * g;
@@ -959,7 +974,7 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
 
 // ---- 65..256 rows --------------------------------------------------------------------------
 static inline int stream_gemm_ksplit(int M, int N, int K) {
-  const int KC = M <= 128 ? 8 : 4;
+  const int KC = 4;
   const int total_steps = K / 32;
   const int groups = (N / 16 + kGemmWaves - 1) / kGemmWaves;
   int ksplit = tuning().gemm_workgroups / groups;  // fill the CUs the host allows
@@ -993,7 +1008,7 @@ extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, c
   const int groups_total = (ntiles + kGemmWaves - 1) / kGemmWaves;
   const int ksplit = stream_gemm_ksplit(M, N, K);
   const int total_steps = K / 32;
-  const int KC = M <= 128 ? 8 : 4;
+  const int KC = 4;
   int steps_per_split = (total_steps + ksplit - 1) / ksplit;
   steps_per_split = (steps_per_split + KC - 1) / KC * KC;  // whole chunks
   float* partial = nullptr;
@@ -1006,7 +1021,7 @@ extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, c
   if (groups < 1) groups = 1;
   if (groups > groups_total) groups = groups_total;
   hipStream_t s = (hipStream_t)stream;
-  const size_t smem = (size_t)2 * 128 * 512;  // [2][ROWS][RB]: 128 x 512 or 256 x 256 bytes
+  const size_t smem = M > 128 ? (size_t)2 * 256 * 256 : (size_t)3 * 128 * 256;  // [NST][ROWS][RB]
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, s, (uint16_t*)y, partial,
@@ -1014,9 +1029,9 @@ extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, c
                        steps_per_split);
   };
   if (dtype == LVLLM_BF16) {
-    if (M <= 128) go(stream_gemm_kernel<BF16, 8, 8>); else go(stream_gemm_kernel<BF16, 16, 4>);
+    if (M <= 128) go(stream_gemm_kernel<BF16, 8, 4, 3>); else go(stream_gemm_kernel<BF16, 16, 4, 2>);
   } else {
-    if (M <= 128) go(stream_gemm_kernel<F16, 8, 8>); else go(stream_gemm_kernel<F16, 16, 4>);
+    if (M <= 128) go(stream_gemm_kernel<F16, 8, 4, 3>); else go(stream_gemm_kernel<F16, 16, 4, 2>);
   }
   LV_LAUNCH_CHECK();
   if (ksplit > 1) {
