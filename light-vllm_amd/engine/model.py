@@ -65,10 +65,10 @@ def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) ->
     if x.shape[0] <= 64 and x.is_cuda:
         if w.packed is not None:
             return torch.ops._C_amd.skinny_linear_packed(x, w.packed, bias, w.N, w.K)
-    elif (x.shape[0] <= _STREAM_GEMM_MAX_ROWS and w.K >= 8192 and x.is_cuda and w.packed is not None
-          and x.stride(1) == 1):
-        # 65..256 rows of a long-K projection (down): X through LDS, one pass over the packed weights;
-        # 39 us against the library's 76 at M = 128 (tools/bench_stream_gemm.py)
+    elif (x.shape[0] <= _STREAM_GEMM_MAX_ROWS and x.is_cuda and w.packed is not None and x.stride(1) == 1
+          and (w.K >= 8192 or (x.shape[0] <= 128 and w.N <= 8192))):
+        # 65..256 rows: X through LDS, one pass over the packed weights -- where it beats the library
+        # (tools/bench_stream_gemm.py, M = 128: down 37 vs 76 us, o 21 vs 24, qkv 26 vs 27; not gate_up: 59 vs 55)
         return torch.ops._C_amd.stream_linear_packed(x, w.packed, bias, w.N, w.K)
     return F.linear(x, w.w, bias)
 
