@@ -241,8 +241,31 @@ class LLMEngine:
         sampled = out.sampled.tolist() if out.sampled is not None else []
         tok_of = dict(zip(out.sample_seq_ids, sampled))
         results: List[RequestOutput] = []
+        max_model_len = self.scheduler_config.max_model_len
         for s in sched.scheduled_seq_groups:
             g = s.seq_group
+            seqs = g.seqs
+            if len(seqs) == 1 and seqs[0].status == SequenceStatus.RUNNING and seqs[0].seq_id in tok_of:
+                # one running sequence that sampled a token: the loop below, without its lists
+                seq = seqs[0]
+                seq.data.update_num_computed_tokens(s.token_chunk_size)
+                tok = tok_of[seq.seq_id]
+                seq.append_token_id(tok, 0.0)
+                if self.eos_token_id is not None and tok == self.eos_token_id:
+                    seq.status = SequenceStatus.FINISHED_STOPPED
+                elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                elif seq.get_len() >= max_model_len:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                finished = seq.status > 2
+                if finished:
+                    self.scheduler.free_seq(seq)
+                if self.step_returns_outputs:
+                    results.append(RequestOutput(g.request_id, list(seq.get_output_token_ids()), finished,
+                                                 SequenceStatus.get_finished_reason(seq.status)))
+                else:
+                    results.append(RequestOutput(g.request_id, [], finished))
+                continue
             g.update_num_computed_tokens(s.token_chunk_size)
             for seq in g.get_seqs(status=SequenceStatus.RUNNING):
                 if seq.seq_id not in tok_of:

@@ -20,6 +20,7 @@ from dataclasses import dataclass, field
 from typing import Deque, Dict, Iterable, List, Optional, Set, Tuple
 
 from ..block_manager.interfaces import AllocStatus, BlockSpaceManager
+from ..block_manager.v1 import BlockSpaceManagerV1
 from .config import CacheConfig, SchedulerConfig
 from .sequence import Sequence, SequenceData, SequenceGroup, SequenceStatus
 
@@ -152,10 +153,11 @@ class DecodingScheduler:
     # ---- the three sources of work ----
     def _get_num_new_tokens(self, seq_group: SequenceGroup, status: SequenceStatus,
                             enable_chunking: bool, budget: SchedulingBudget) -> int:
-        num_new_tokens = sum(s.get_num_new_tokens() for s in seq_group.get_seqs(status=status))
+        seqs = seq_group.get_seqs(status=status)
+        num_new_tokens = seqs[0].get_num_new_tokens() if len(seqs) == 1 else sum(s.get_num_new_tokens() for s in seqs)
         assert num_new_tokens > 0
         # only single-sequence groups (prompts) are ever chunked (scheduler.py:1102-1132)
-        if enable_chunking and len(seq_group.get_seqs(status=status)) == 1:
+        if enable_chunking and len(seqs) == 1:
             num_new_tokens = min(num_new_tokens, budget.remaining_token_budget())
         return num_new_tokens
 
@@ -375,6 +377,10 @@ class DecodingScheduler:
         out = self._schedule_chunked_prefill() if self.chunked_prefill_enabled else self._schedule_default()
         now = time.time()
         metas: List[SequenceGroupMetadata] = []
+        # without prefix caching the manager's three cache hooks below are no-ops (v1: block_manager_v1.py
+        # :640-707 all start with `if self.enable_caching`): skip the calls, not the semantics
+        bm = self.block_manager
+        hooks = not (isinstance(bm, BlockSpaceManagerV1) and not bm.enable_caching)
         for sched in out.scheduled_seq_groups:
             g = sched.seq_group
             g.maybe_set_first_scheduled_time(now)
@@ -384,9 +390,10 @@ class DecodingScheduler:
             running = g.get_seqs(status=SequenceStatus.RUNNING)
             for seq in running:
                 seq_data[seq.seq_id] = seq.data
-                block_tables[seq.seq_id] = self.block_manager.get_block_table(seq)
-                self.block_manager.access_all_blocks_in_seq(seq, now)
-            common = list(self.block_manager.get_common_computed_block_ids(running))
+                block_tables[seq.seq_id] = bm.get_block_table(seq)
+                if hooks:
+                    bm.access_all_blocks_in_seq(seq, now)
+            common = list(bm.get_common_computed_block_ids(running)) if hooks else []
             do_sample = True
             if g.is_prefill():
                 seqs = g.get_seqs()
@@ -398,8 +405,9 @@ class DecodingScheduler:
                 request_id=g.request_id, is_prompt=g.is_prefill(), seq_data=seq_data,
                 block_tables=block_tables, do_sample=do_sample,
                 token_chunk_size=sched.token_chunk_size, computed_block_nums=common))
-        for sched in out.scheduled_seq_groups:
-            self.block_manager.mark_blocks_as_computed(sched.seq_group)
+        if hooks:
+            for sched in out.scheduled_seq_groups:
+                bm.mark_blocks_as_computed(sched.seq_group)
         out.seq_group_metadata_list = metas
         return out
 

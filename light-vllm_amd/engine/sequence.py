@@ -165,7 +165,7 @@ class Sequence:
         return self.data.output_token_ids
 
     def is_finished(self) -> bool:
-        return SequenceStatus.is_finished(self.status)
+        return self.status > 2  # SequenceStatus.SWAPPED: every later state is a finished one
 
     def fork(self, new_seq_id: int) -> "Sequence":
         child = Sequence(new_seq_id, list(self.data.prompt_token_ids), self.block_size, self.eos_token_id)
@@ -216,12 +216,20 @@ class SequenceGroup:
     def get_max_num_running_seqs(self) -> int:
         """Upper bound of sequences that run in parallel for the rest of this request's
         lifetime (sequence.py:487-498)."""
-        if self.n > self.num_seqs():
+        seqs = self.seqs
+        if len(seqs) == 1 and self.n <= 1:  # the common case, answered without building lists
+            return 0 if seqs[0].status > 2 else 1
+        if self.n > len(seqs):
             return self.n  # still in the prompt stage: n sequences will be forked
         return self.num_unfinished_seqs()
 
     def get_seqs(self, status: Optional[SequenceStatus] = None) -> List[Sequence]:
-        return self.seqs if status is None else [s for s in self.seqs if s.status == status]
+        seqs = self.seqs
+        if status is None:
+            return seqs
+        if len(seqs) == 1:
+            return seqs if seqs[0].status == status else []
+        return [s for s in seqs if s.status == status]
 
     def is_encoder_decoder(self) -> bool:
         return False
@@ -265,7 +273,10 @@ class SequenceGroup:
         self.seqs.remove(seq)
 
     def is_finished(self) -> bool:
-        return all(s.is_finished() for s in self.seqs)
+        seqs = self.seqs
+        if len(seqs) == 1:
+            return seqs[0].status > 2
+        return all(s.status > 2 for s in seqs)
 
     def is_prefill(self) -> bool:
         return self.seqs[0].is_prefill()  # all sequences of a group share the stage
