@@ -369,7 +369,7 @@ class LLMEngine:
                 self.executor_out.put(e)
 
     def ensure_start_execute_loop(self) -> None:
-        if not self._done_threads:
+        if not self._done_threads and not self.poll_completion:
             self._done_threads = [threading.Thread(target=self._done_loop, args=(q,), daemon=True)
                                   for q in self._done_qs]
             for t in self._done_threads:

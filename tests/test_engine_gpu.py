@@ -118,9 +118,13 @@ def test_graph_replay_and_async_give_the_same_tokens():
     eager = run_to_completion(make_engine(graph=False))
     graph = run_to_completion(make_engine(graph=True))
     asyn = run_to_completion(make_engine(graph=True, scheduling="async", max_seqs=3), use_async=True)
+    waiter = make_engine(graph=True, scheduling="async", max_seqs=3)
+    waiter.poll_completion = False  # completion handed back by the per-slot waiter threads instead
+    asyn_waiter = run_to_completion(waiter, use_async=True)
     assert all(len(t) == 12 for t in eager)
     assert eager == graph
     assert eager == asyn
+    assert eager == asyn_waiter
 
 
 def test_decode_fast_path_gives_the_tokens_of_the_general_input_builder():
