@@ -188,6 +188,13 @@ int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, i
                       int64_t workspace_bytes, void* stream);
 /* Reorders row-major W[N,K] into the packed order (out of place; N % 16 == 0, K % 32 == 0). */
 int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream);
+/* Greedy sampling fused into a projection (the lm_head of a decode step): tokens[m] = argmax over n of
+ * (X . W^T)[m, n], compared after rounding to the element type (what torch.argmax of the projection's
+ * output sees; ties go to the smaller n), without writing the [M, N] result.  M <= 64, K <= 4096 at
+ * M <= 32 (K within one workgroup), packed weights, no bias.  tokens: int64 [M] on the device. */
+int64_t lvllm_skinny_gemm_argmax_workspace_bytes(int M);
+int lvllm_skinny_gemm_argmax(int64_t* tokens, const void* x, const void* w_packed, int M, int N, int K,
+                             int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same product for 1 <= M <= 256 rows (meant for 65..256: a large decode batch, a prefill chunk):
  * X goes through LDS, the waves of a workgroup split N, K is split over workgroups where N alone
  * would not fill the GPU (fp32 partials in `workspace`, lvllm_stream_gemm_workspace_bytes).

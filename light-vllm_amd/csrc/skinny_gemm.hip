@@ -227,6 +227,35 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     }
   };
 
+  // act == 3 (greedy sampling fused into the lm_head projection): no logits are written.  Every lane
+  // keeps the best (value rounded to T, row n) it has seen per m-tile in a wave-private LDS slot --
+  // the scratch of the activation transpose, idle after the prologue -- the workgroup merges its
+  // lanes at the end and writes one candidate per row of X to the workspace behind `y`
+  // ([gridDim.x][M] {float value, int n}); skinny_argmax_reduce_kernel picks the winner.  Ties go to
+  // the smaller n, as torch.argmax does.
+  const bool amax = act == 3;
+  float* amax_v = reinterpret_cast<float*>(reinterpret_cast<char*>(stage + (size_t)stage_tiles * MT * 64) +
+                                           wave * (W8 ? 16 * 512 : 16 * HALF * 64));  // [MT][64]
+  int* amax_i = reinterpret_cast<int*>(amax_v + MT * 64);
+  auto amax_update = [&](const int i, const int mt, g_f32x4_t sum) __attribute__((always_inline)) {
+    const int n0 = 16 * tile_of(i) + 4 * g;
+    if (mt * 16 + c < M && n0 < N) {
+      if constexpr (W8) sum *= out_scale;
+      float bv = amax_v[mt * 64 + lane];
+      int bi = amax_i[mt * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = T::to_float(T::from_float(sum[r]));
+        if (v > bv || (v == bv && n0 + r < bi)) {
+          bv = v;
+          bi = n0 + r;
+        }
+      }
+      amax_v[mt * 64 + lane] = bv;
+      amax_i[mt * 64 + lane] = bi;
+    }
+  };
+
   auto flush_stage = [&](const int end_tile) __attribute__((always_inline)) {
     __syncthreads();  // every reducer's slab is in the stage
     if (glu) {  // stage_base and end_tile are even: pairs are never split across two flushes
@@ -240,7 +269,8 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
       const int nslabs = (end_tile - stage_base) * MT;
       for (int sl = wave; sl < nslabs; sl += kGemmWaves) {
         const int i = stage_base + sl / MT, mt = sl % MT;
-        store_slab(i, mt, stage[(size_t)sl * 64 + lane]);
+        if (amax) amax_update(i, mt, stage[(size_t)sl * 64 + lane]);
+        else store_slab(i, mt, stage[(size_t)sl * 64 + lane]);
       }
     }
     stage_base = end_tile;
@@ -486,6 +516,13 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     }
   }
 
+  if (amax) {  // this wave's transposes are done: its scratch becomes its arg-max slots
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      amax_v[mt * 64 + lane] = -__builtin_inff();
+      amax_i[mt * 64 + lane] = 0x7fffffff;
+    }
+  }
 #ifdef LVLLM_GEMM_TRACE
   __builtin_amdgcn_s_waitcnt(0);  // X and the first two units have arrived
   GEMM_TRACE(1);
@@ -505,6 +542,29 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
 #ifndef LVLLM_GEMM_NOREDUCE
   flush_stage(my_tiles);  // all weights have been streamed: now the stores
 #endif
+  if (amax) {  // flush_stage ended with a barrier: every wave's slots are final
+    const int m = threadIdx.x;
+    if (m < M) {
+      const char* region = reinterpret_cast<const char*>(stage + (size_t)stage_tiles * MT * 64);
+      float bv = -__builtin_inff();
+      int bi = 0x7fffffff;
+      for (int w2 = 0; w2 < kGemmWaves; ++w2) {
+        const float* v = reinterpret_cast<const float*>(region + w2 * (W8 ? 16 * 512 : 16 * HALF * 64));
+        const int* ix = reinterpret_cast<const int*>(v + MT * 64);
+#pragma unroll
+        for (int g2 = 0; g2 < 4; ++g2) {
+          const int e = (m >> 4) * 64 + g2 * 16 + (m & 15);
+          if (v[e] > bv || (v[e] == bv && ix[e] < bi)) {
+            bv = v[e];
+            bi = ix[e];
+          }
+        }
+      }
+      float* dst = reinterpret_cast<float*>(y) + ((int64_t)blockIdx.x * M + m) * 2;
+      dst[0] = bv;
+      reinterpret_cast<int*>(dst)[1] = bi;
+    }
+  }
 #ifdef LVLLM_GEMM_TRACE
   __builtin_amdgcn_s_waitcnt(0);
   GEMM_TRACE(3);
@@ -537,6 +597,39 @@ __global__ void skinny_gemm_reduce_kernel(typename T::store_t* __restrict__ y,
   o.x = (uint32_t)T::from_float(sum[0]) | ((uint32_t)T::from_float(sum[1]) << 16);
   o.y = (uint32_t)T::from_float(sum[2]) | ((uint32_t)T::from_float(sum[3]) << 16);
   *reinterpret_cast<uint2*>(y + i) = o;
+}
+
+// tokens[m] = the n of the best candidate over the workgroups' [groups][M] {value, n} (ties: smaller n)
+__global__ void skinny_argmax_reduce_kernel(int64_t* __restrict__ tokens, const float* __restrict__ cand,
+                                            const int groups, const int M) {
+  const int m = blockIdx.x;
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int gidx = threadIdx.x; gidx < groups; gidx += blockDim.x) {
+    const float v = cand[((int64_t)gidx * M + m) * 2];
+    const int ix = reinterpret_cast<const int*>(cand)[((int64_t)gidx * M + m) * 2 + 1];
+    if (v > bv || (v == bv && ix < bi)) {
+      bv = v;
+      bi = ix;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s2 = blockDim.x / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) {
+      const float v = sv[threadIdx.x + s2];
+      const int ix = si[threadIdx.x + s2];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = ix;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tokens[m] = si[0];
 }
 
 template <typename T, int MT, int KSTEPS, bool W8 = false>
@@ -787,6 +880,22 @@ extern "C" int lvllm_pack_weight(void* dst, const void* src, int N, int K, int d
   return 0;
 }
 
+// Greedy sampling fused into a projection: tokens[m] = argmax_n (X . W^T)[m, n] over the values rounded
+// to the element type (what torch.argmax of the projection's output sees; ties: the smaller n), without
+// writing the [M, N] result.  workspace: lvllm_skinny_gemm_argmax_workspace_bytes(M) bytes.
+extern "C" int64_t lvllm_skinny_gemm_argmax_workspace_bytes(int M) { return (int64_t)1024 * (M > 0 ? M : 1) * 8; }
+
+extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
+                                    int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
+                                    int* ksplit_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+extern "C" int lvllm_skinny_gemm_argmax(int64_t* tokens, const void* x, const void* w_packed, int M, int N, int K,
+                                        int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  return lvllm_skinny_gemm_ex(tokens, x, w_packed, nullptr, M, N, K, ldx, dtype, 1, 3, 0, nullptr, workspace,
+                              workspace_bytes, stream);
+}
+
 // `act` = 1: X rows are [gate (K) | up (K)] and the kernel multiplies W by silu(gate)*up
 // (the SwiGLU activation fused into the down projection); `act` = 2: W rows are [gate (N/2) | up (N/2)]
 // and y [M, N/2] = silu(X.gate^T) * (X.up^T), the activation applied in the epilogue (the gate_up
@@ -833,6 +942,13 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
              "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup (K <= 4096 at M <= 32)");
     if (groups > ntiles / 2) groups = ntiles / 2;
   }
+  void* const tokens_out = y;
+  if (act == 3) {  // arg-max epilogue: y is int64 [M]; the workgroups' candidates go through `workspace`
+    LV_CHECK(ksplit == 1 && !partial_out && bias == nullptr, "the arg-max epilogue needs K within one workgroup and no bias");
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)groups * M * 8,
+             "workspace too small (see lvllm_skinny_gemm_argmax_workspace_bytes)");
+    y = workspace;
+  }
   if (ksplit_out) *ksplit_out = ksplit;
   LV_CHECK(!(partial_out && bias != nullptr), "partial_out leaves the bias to the caller");
   float* partial = nullptr;
@@ -865,6 +981,12 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
 #undef LV_SG_MT
 #undef LV_SG
   LV_LAUNCH_CHECK();
+  if (act == 3) {
+    hipLaunchKernelGGL(skinny_argmax_reduce_kernel, dim3(M), dim3(256), 0, s, (int64_t*)tokens_out, (const float*)y,
+                       groups, M);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
   if (ksplit > 1 && !partial_out) {
     const int64_t MN = (int64_t)M * N;
     const int threads = 256;

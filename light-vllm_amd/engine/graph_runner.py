@@ -56,8 +56,7 @@ class DecodeGraph:
 
     def _step(self):
         hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, self._metadata())
-        logits = self.model.compute_logits(hidden)
-        return hidden, torch.argmax(logits, dim=-1)  # greedy sampling stays on the device
+        return hidden, self.model.greedy_tokens(hidden)  # greedy sampling stays on the device
 
     def capture(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         s = stream or torch.cuda.Stream()
@@ -122,8 +121,7 @@ class MixedGraph:
     def _step(self):
         unified = (self.block_tables, self.seq_lens, self.query_start_loc, self.max_tokens, self.slot_mapping)
         hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, None, unified=unified)
-        logits = self.model.compute_logits(hidden[self.sample_rows])
-        return torch.argmax(logits, dim=-1)
+        return self.model.greedy_tokens(hidden[self.sample_rows])
 
     def capture(self) -> None:
         s = torch.cuda.Stream()

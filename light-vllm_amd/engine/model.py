@@ -75,6 +75,7 @@ def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) ->
 
 _CALIBRATING = False
 _STREAM_GEMM_MAX_ROWS = int(os.environ.get("LVLLM_STREAM_GEMM_MAX_ROWS", "256"))
+_ARGMAX_EPILOGUE = os.environ.get("LVLLM_ARGMAX_EPILOGUE", "1") != "0"  # A/B switch
 _SWIGLU_EPILOGUE = os.environ.get("LVLLM_SWIGLU_EPILOGUE", "1") != "0"  # A/B switch
 
 
@@ -246,3 +247,11 @@ class DecoderModel:
 
     def compute_logits(self, hidden: torch.Tensor) -> torch.Tensor:
         return linear(hidden, self.lm_head)
+
+    def greedy_tokens(self, hidden: torch.Tensor) -> torch.Tensor:
+        """argmax of the logits, [T] int64.  Decode batches take it from the lm_head projection's
+        epilogue (no [T, vocab] tensor, no separate arg-max launch; same tokens as the two ops)."""
+        w = self.lm_head
+        if _ARGMAX_EPILOGUE and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.packed is not None:
+            return torch.ops._C_amd.skinny_linear_packed_argmax(hidden, w.packed, w.N, w.K)
+        return torch.argmax(self.compute_logits(hidden), dim=-1)

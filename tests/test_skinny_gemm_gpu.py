@@ -157,3 +157,35 @@ def test_stream_linear_matches_fp32_matmul(ops, dtype, M, N, K, use_bias):
         err = (y.float() - ref).abs().max().item()
         scale = ref.abs().max().item()
         assert err <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -9) * scale + 1e-3, (err, scale, wgs)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(32, 128256, 4096), (1, 512, 256), (17, 32000, 1024), (64, 4096, 2048),
+                                   (33, 1040, 8192), (5, 48, 64), (32, 16, 32)])
+@pytest.mark.parametrize("wgs", [256, 128, 9])
+def test_argmax_epilogue_gives_torch_argmax_of_the_projection(ops, dtype, M, N, K, wgs):
+    """tokens = argmax of the rounded logits, ties to the smaller index -- also with many exact ties
+    (duplicated weight rows give bit-equal logits in different workgroups, waves and lanes)."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype)
+    if N >= 48:  # copies of the strongest rows scattered over the vocabulary: exact ties across tiles
+        top = (x.float() @ w.float().T).argmax(-1)
+        for j, t in enumerate(top.tolist()[:8]):
+            for dst in ((t + 16 * (j + 1)) % N, (t * 7 + 3) % N, N - 1 - j):
+                w[dst] = w[t]
+    wp = torch.ops._C_amd.pack_weight(w)
+    torch.ops._C_amd.set_tuning("gemm_workgroups", wgs)
+    try:
+        logits = torch.ops._C_amd.skinny_linear_packed(x, wp, None, N, K)
+        tokens = torch.ops._C_amd.skinny_linear_packed_argmax(x, wp, N, K)
+    finally:
+        torch.ops._C_amd.set_tuning("gemm_workgroups", 256)
+    want = torch.argmax(logits, dim=-1)
+    # torch.argmax documents "first maximal value"; compare values too in case a backend differs
+    assert tokens.dtype == torch.int64 and tokens.shape == (M,)
+    picked = logits.gather(1, tokens[:, None])[:, 0]
+    assert torch.equal(picked, logits.max(dim=-1).values)
+    first = (logits == logits.max(dim=-1, keepdim=True).values).float().argmax(-1)
+    assert torch.equal(tokens, first)
+    assert torch.equal(first, want), "torch.argmax no longer returns the first maximal index on this backend"
