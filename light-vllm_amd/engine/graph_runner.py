@@ -41,6 +41,10 @@ class DecodeGraph:
         self.slot_mapping.fill_(-1)
         self.host = torch.zeros(total, dtype=torch.uint8, pin_memory=dev.type == "cuda")
         self.staging = DecodeStepArrays(B, W, block_size, self.host.numpy())
+        # pinned landing buffers of the sampled tokens: a result is read by the host right after its step
+        # completes, long before the same graph has run four more steps
+        self._host_tokens = [torch.empty(B, dtype=torch.int64, pin_memory=dev.type == "cuda") for _ in range(4)]
+        self._host_tokens_next = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.hidden: Optional[torch.Tensor] = None
         self.next_tokens: Optional[torch.Tensor] = None
@@ -85,6 +89,11 @@ class DecodeGraph:
         if n < self.batch_size:  # padding rows: no cache write, empty context
             self.slot_mapping[n:].fill_(-1)
             self.seq_lens[n:].zero_()
+
+    def next_host_tokens(self) -> torch.Tensor:
+        t = self._host_tokens[self._host_tokens_next]
+        self._host_tokens_next = (self._host_tokens_next + 1) % len(self._host_tokens)
+        return t
 
     def load_staged(self) -> None:
         """The step written into `staging` (DecodeStepArrays.fill) goes to the device in one copy."""

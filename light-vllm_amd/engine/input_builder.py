@@ -233,9 +233,10 @@ class DecodeStepArrays:
                 return False
         return True
 
-    def fill(self, metas) -> List[int]:
+    def fill(self, metas) -> Optional[List[int]]:
         """Writes the step into the staging arrays (rows past len(metas) become padding: slot -1,
-        length 0) and returns the sequence ids in row order."""
+        length 0) and returns the sequence ids in row order; None when a block table is wider than
+        the arrays (the caller then takes the general path)."""
         n = len(metas)
         assert n <= self.batch_size
         seq_ids: List[int] = []
@@ -248,7 +249,9 @@ class DecodeStepArrays:
             old = rows[i]
             if old is None or table != old:
                 k = len(table)
-                assert k <= W, "block table wider than the captured step"
+                if k > W:
+                    rows[i] = None  # whatever the row holds now is not a table any more
+                    return None
                 if old is not None and k == len(old) + 1 and table[:-1] == old:
                     bt[i, k - 1] = table[-1]
                 else:

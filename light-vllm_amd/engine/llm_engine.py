@@ -147,17 +147,13 @@ class Worker:
         if graphs is None or self.capture_logits:
             return None
         n = len(metas)
-        width = 0
-        for m in metas:
-            for t in m.block_tables.values():
-                width = max(width, len(t))
-        if width > graphs.max_blocks_per_seq:
-            return None
         g = graphs.get(n)
         seq_ids = g.staging.fill(metas)
+        if seq_ids is None:  # a block table wider than the captured step
+            return None
         g.load_staged()
         tokens = g.replay()[:n]
-        out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
+        out = g.next_host_tokens()[:n]
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, seq_ids)
 
