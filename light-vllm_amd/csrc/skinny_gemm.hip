@@ -1005,8 +1005,20 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
 // W8A8: Y[M,N] = T((fp8(X / x_scale) . W8^T) * x_scale * w_scale + bias).  X [M, K] in T (ldx apart),
 // W8 = fp8 weights [N, K] packed by lvllm_pack_weight on their [N, K/2] 16-bit view, per-tensor
 // scales on the device (w8a8_utils.py:103-156 of the reference with a static activation scale).
+// W8A8 waves own at most 8 k-steps (64 k each): the variant whose activations take the row-order +
+// LDS-transpose route (its fragments leave room for the landing registers); longer K is split over more
+// workgroups instead.  LVLLM_W8_STEPS=16 restores the old split for A/B runs.
+static inline int w8_max_steps_per_wave(int M) {
+  static const int forced = getenv("LVLLM_W8_STEPS") ? atoi(getenv("LVLLM_W8_STEPS")) : 0;
+  if (forced == 16) return max_steps_per_wave(M);
+  return 8;
+}
+
 extern "C" int64_t lvllm_skinny_gemm_w8a8_workspace_bytes(int M, int N, int K) {
-  return lvllm_skinny_gemm_workspace_bytes(M, N, K / 2);
+  const int total_steps = (K / 2) / 32;
+  const int cap = kGemmWaves * w8_max_steps_per_wave(M);
+  const int ksplit = (total_steps + cap - 1) / cap;
+  return ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0;
 }
 
 extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
@@ -1038,7 +1050,7 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
   }
   const int K2 = K / 2;  // the kernel's K: 16-bit units of the weight rows
   const int total_steps = K2 / 32;
-  const int cap = kGemmWaves * max_steps_per_wave(M);
+  const int cap = kGemmWaves * w8_max_steps_per_wave(M);
   const int ksplit = (total_steps + cap - 1) / cap;
   const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
   const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;
