@@ -212,11 +212,11 @@ def test_decode_step_arrays_equal_the_general_input_builder():
     import numpy as np
 
     from light_vllm_amd.engine.input_builder import DecodeStepArrays
-    for version in (False, True):
+    for version, mode in ((False, "swap"), (True, "swap"), (False, None), (True, "recompute")):
         rng = random.Random(5)
         cc = CacheConfig(block_size=4, num_gpu_blocks=40, num_cpu_blocks=16)
         sc = SchedulerConfig(max_num_batched_tokens=64, max_num_seqs=6, max_model_len=256,
-                             use_v2_block_manager=version, preemption_mode="swap")
+                             use_v2_block_manager=version, preemption_mode=mode)
         s = DecodingScheduler(sc, cc)
         builder = ModelInputBuilder(sc, cc, PagedAttnBackend())
         arrays = DecodeStepArrays(8, 64, 4)
