@@ -182,7 +182,9 @@ class LLMEngine:
                              mixed_graph_seqs=min(scheduler_config.max_num_seqs,
                                                   scheduler_config.max_num_batched_tokens) if mixed else 0)
         # with steps on several streams every decode GEMM takes half the CUs and leaves the rest
-        # to the other step's kernel (measured: +10 % tokens/s at two steps in flight)
+        # to the other step's kernel (+10 % tokens/s when measured first; since the GEMM's activation
+        # path was fixed a lone 128-workgroup GEMM is as fast as a 256-workgroup one and the setting
+        # is worth +-1.5 %: profiles/r01_tuning.md)
         gemm_wgs = int(os.environ.get("LVLLM_ENGINE_GEMM_WGS", "0")) or (128 if self.num_slots > 1 else 256)
         torch.ops._C_amd.set_tuning("gemm_workgroups", gemm_wgs)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
