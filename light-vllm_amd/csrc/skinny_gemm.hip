@@ -7,7 +7,8 @@
 // paged-attention kernel instead:
 //   * the activations live in REGISTERS: wave w of a workgroup owns a fixed K slice (up to 16
 //     k-steps of 32) and keeps its X fragments (B operand of v_mfma_f32_16x16x32) for the whole
-//     launch; they are read once per workgroup from L2;
+//     launch; they are read once per workgroup from L2, in row order, and transposed into
+//     fragment order through a wave-private LDS scratch (see the kernel);
 //   * W goes HBM -> VGPR -> MFMA A operand with no LDS staging: lane (g, c) of a wave loads the
 //     16 bytes W[n0 + c][k0 + 8g ..], which is its A fragment; 8 such loads per unit, two units in
 //     flight per wave, 8 waves per CU;
@@ -15,8 +16,12 @@
 //     (double-buffered, one barrier per n-tile) and MT waves write the bf16 result;
 //   * K > 4096 is split over workgroups as well (blockIdx.y); partials go to an fp32 workspace and
 //     a small second kernel adds them (and the bias).
-// Loads outside the problem (k-steps past K, rows past N) use an out-of-range buffer offset and
+// Loads outside the problem (k-steps past K, tiles past N) use an out-of-range buffer offset and
 // return zeros without touching memory, so the loop is branch-free.
+// Epilogues (act): 0 plain (+ bias); 2 SwiGLU over (gate, up) tile pairs -> [M, N/2]; 3 greedy arg-max
+// over N -> int64 [M] (no logits written); act = 1 applies SwiGLU while loading X (kept for small shapes).
+// The same file holds the W8A8 variant (fp8 weights, X quantised while the fragments are built) and,
+// at the end, the 65..256-row kernel that moves X through LDS instead of registers.
 //
 // Weight layouts.  With row-major W[N,K] a wave-wide fragment load touches 16 rows x 64 bytes
 // (half cache lines): correct, but the texture addresser works twice per byte and the stream tops
