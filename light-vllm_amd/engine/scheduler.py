@@ -398,6 +398,14 @@ class DecodingScheduler:
             g = sched.seq_group
             g.maybe_set_first_scheduled_time(now)
             g.busy = True
+            seqs = g.seqs
+            if not hooks and len(seqs) == 1 and seqs[0].status == SequenceStatus.RUNNING and not seqs[0].is_prefill():
+                seq = seqs[0]  # one decoding sequence, no prefix-cache hooks: the record below, directly
+                metas.append(SequenceGroupMetadata(
+                    request_id=g.request_id, is_prompt=False, seq_data={seq.seq_id: seq.data},
+                    block_tables={seq.seq_id: bm.get_block_table(seq)}, do_sample=True,
+                    token_chunk_size=sched.token_chunk_size, computed_block_nums=[]))
+                continue
             seq_data: Dict[int, SequenceData] = {}
             block_tables: Dict[int, List[int]] = {}
             running = g.get_seqs(status=SequenceStatus.RUNNING)
