@@ -34,6 +34,18 @@ def wrap(obj, name, label):
         acc.setdefault(label, []).append(time.perf_counter() - t)
         return r
     setattr(obj, name, w)
+from light_vllm_amd.engine.graph_runner import DecodeGraph
+from light_vllm_amd.engine.input_builder import DecodeStepArrays
+for cls, name, label in ((DecodeStepArrays, "fill", "staging fill"), (DecodeGraph, "load_staged", "staged H2D copy"),
+                         (DecodeGraph, "replay", "graph replay (launch)")):
+    def mk(f, label):
+        def w(self, *a, **k):
+            t = time.perf_counter()
+            r = f(self, *a, **k)
+            acc.setdefault(label, []).append(time.perf_counter() - t)
+            return r
+        return w
+    setattr(cls, name, mk(getattr(cls, name), label))
 wrap(engine.scheduler, "schedule", "schedule")
 wrap(engine, "_process", "process")
 wrap(engine.worker, "execute", "launch (load + replay + d2h enqueue)")
