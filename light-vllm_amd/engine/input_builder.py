@@ -256,7 +256,7 @@ class DecodeStepArrays:
                     bt[i, k - 1] = table[-1]
                 else:
                     bt[i, :k] = table
-                rows[i] = table
+                rows[i] = list(table)  # a private copy: the comparison must not depend on who owns `table`
             seq_ids.append(seq_id)
             lens.append(data.get_len())
             toks.append(data.get_last_token_id())
