@@ -329,11 +329,21 @@ def main():
         }
         if gm is not None:  # the second HBM stream of the step: one layer's four projections
             g_ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
+            gm_traffic = None
+            try:  # PMC passes of the same kernels at the same shapes (tools/pmc_gemm.py), M = 32 only
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")) as f:
+                    pm = json.load(f)
+                if B == pm["M"] and not a.tiny:
+                    gm_traffic = sum(v["hbm_bytes_per_launch"] for v in pm["shapes"].values())
+            except (OSError, KeyError, ValueError):
+                pass
             line["roofline_projections"] = {
                 "bound": "hbm", "kernel": "skinny_gemm_kernel (qkv, o, gate_up + SwiGLU input, down of one layer, M = "
                                           f"{B}, 256 workgroups)",
                 "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
+                "traffic": gm_traffic, "traffic_source": "profiles/r01_pmc_gemm.json (2*FETCH_SIZE + WRITE_SIZE per launch, "
+                                                         "the four shapes summed; M = 32)",
+                "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
                 "us_per_layer": round(gm["s_per_layer"] * 1e6, 2), "per_shape": gm["per_shape"]}
         print(json.dumps(line), flush=True)
     group.shutdown()
