@@ -57,10 +57,12 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_leg(engine, B, iters):
+def kernel_leg(engine, B, iters, seq_len=None):
     """Per-launch time of paged_attention_v2's partition pass (the dominant hot-path kernel) on
     the engine's own KV caches: HIP events on the launch stream, one layer's cache per launch so
-    that consecutive launches read 32 different 134 MB caches (>> the 256 MiB Infinity Cache)."""
+    that consecutive launches read 32 different 134 MB caches (>> the 256 MiB Infinity Cache).
+    `seq_len`: attend to exactly that many tokens of every sequence (the metric's seq = 1024; the
+    sequences have grown past it during the timed steps), None = their current lengths."""
     from light_vllm_amd import _native
     from light_vllm_amd.paged_attn import PagedAttention
     lib = _native.load_hip_library()
@@ -73,6 +75,9 @@ def kernel_leg(engine, B, iters):
     groups = list(engine.scheduler.running)[:B]
     seqs = [g.seqs[0] for g in groups]
     lens = [s.get_len() for s in seqs]
+    if seq_len is not None:
+        assert min(lens) >= seq_len
+        lens = [seq_len] * len(seqs)
     tables = [bm.get_block_table(s) for s in seqs]
     width = max(len(t) for t in tables)
     bt = torch.zeros(len(seqs), width, dtype=torch.int32)
@@ -129,7 +134,7 @@ def kernel_leg(engine, B, iters):
     avg = sum(ts) / len(ts)
     esz = 2
     algo_bytes = (2 * sum(lens) * KVH * D * (1 if kv_fp8 else esz) + 2 * len(seqs) * H * D * esz +
-                  len(seqs) * width * 4 + len(seqs) * 4)
+                  len(seqs) * ((max_len + BS - 1) // BS) * 4 + len(seqs) * 4)
     return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P)
 
 
@@ -286,7 +291,7 @@ def main():
     elapsed = group.max(elapsed)            # slowest replica's clock
     value = group.sum(tokens) / elapsed      # whole-job tokens/s
 
-    k = kernel_leg(engine, B, a.kernel_iters)
+    k = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
     gm = gemm_leg(engine, B) if B <= 64 else None
     cpu = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
@@ -319,7 +324,8 @@ def main():
                                    f"attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "
                                    "random-init weights, synthetic KV",
                        "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)"},
-            "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 partition pass (paged_attn_mfma_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 partition pass (paged_attn_mfma_kernel), "
+                                                      f"seq_lens = {ctx} for all {B} sequences",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_attn.json (2*FETCH_SIZE + WRITE_SIZE per launch, scaled)",
