@@ -322,7 +322,9 @@ int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const v
                            const float* x_scale, const float* w_scale, int M, int N, int K, int64_t ldx,
                            int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* As lvllm_skinny_gemm_w8a8 with act = 0; act = 2: W rows are [gate (N/2) | up (N/2)] and y is [M, N/2],
- * silu_and_mul applied in the epilogue (N % 32 == 0, K not split over workgroups). */
+ * silu_and_mul applied in the epilogue (N % 32 == 0, K not split over workgroups); act = 3: y is int64 [M],
+ * the arg-max over n of the rounded result (as lvllm_skinny_gemm_argmax; workspace of
+ * lvllm_skinny_gemm_argmax_workspace_bytes(M), no bias, K not split over workgroups). */
 int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
                               const float* x_scale, const float* w_scale, int M, int N, int K,
                               int64_t ldx, int dtype, int act, void* workspace,

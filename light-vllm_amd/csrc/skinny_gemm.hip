@@ -1045,7 +1045,7 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
                                          int64_t ldx, int dtype, int act, void* workspace,
                                          int64_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0) return 0;
-  LV_CHECK(act == 0 || act == 2, "lvllm_skinny_gemm_w8a8_ex: act must be 0 or 2");
+  LV_CHECK(act == 0 || act == 2 || act == 3, "lvllm_skinny_gemm_w8a8_ex: act must be 0, 2 or 3");
   LV_CHECK(x_scale != nullptr && w_scale != nullptr, "scales are device pointers to one float each");
   if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 64) != 0 || (N % 16) != 0 ||
       (int64_t)N * K >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
@@ -1067,6 +1067,13 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
   if (act == 2) {
     LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
     if (groups > ntiles / 2) groups = ntiles / 2;
+  }
+  void* const tokens_out = y;
+  if (act == 3) {  // arg-max epilogue (see lvllm_skinny_gemm_argmax): y is int64 [M], candidates via `workspace`
+    LV_CHECK(ksplit == 1 && bias == nullptr && M <= 32,
+             "the W8A8 arg-max epilogue needs M <= 32, K within one workgroup and no bias");  // its LDS slots: see kernel
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)groups * M * 8, "workspace too small");
+    y = workspace;
   }
   float* partial = nullptr;
   if (ksplit > 1) {
@@ -1097,6 +1104,12 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
 #undef LV_SG8_MT
 #undef LV_SG8
   LV_LAUNCH_CHECK();
+  if (act == 3) {
+    hipLaunchKernelGGL(skinny_argmax_reduce_kernel, dim3(M), dim3(256), 0, s, (int64_t*)tokens_out, (const float*)y,
+                       groups, M);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
   if (ksplit > 1) {
     const int64_t MN = (int64_t)M * N;
     const int grid = (int)((MN / 4 + 255) / 256);

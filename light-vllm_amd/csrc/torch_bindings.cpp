@@ -633,6 +633,32 @@ torch::Tensor skinny_linear_w8a8_swiglu(const torch::Tensor& x, const torch::Ten
   return y;
 }
 
+// W8A8 lm_head + greedy sampling in one launch (see skinny_linear_packed_argmax)
+torch::Tensor skinny_linear_w8a8_argmax(const torch::Tensor& x, const torch::Tensor& w_packed, const torch::Tensor& w_scale,
+                                        const torch::Tensor& x_scale, int64_t N, int64_t K) {
+  const int64_t M = x.size(0);
+  if (M > 32 || lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K) > 0)  // outside the epilogue's envelope
+    return at::argmax(skinny_linear_w8a8(x, w_packed, w_scale, x_scale, N, K, std::nullopt), -1);
+  LV_CHECK_DEVICE(x);
+  LV_CHECK_DEVICE(w_packed);
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && M >= 1 && M <= 64,
+              "skinny_linear_w8a8_argmax: x must be [M <= 64, K]");
+  TORCH_CHECK(w_packed.is_contiguous() && w_packed.numel() * w_packed.element_size() == N * K,
+              "skinny_linear_w8a8_argmax: w_packed must hold N*K fp8 bytes");
+  TORCH_CHECK(w_scale.scalar_type() == at::kFloat && x_scale.scalar_type() == at::kFloat && w_scale.is_cuda() &&
+                  x_scale.is_cuda() && w_scale.numel() == 1 && x_scale.numel() == 1,
+              "skinny_linear_w8a8_argmax: per-tensor float32 scales on the device");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto tokens = torch::empty({M}, x.options().dtype(torch::kLong));
+  const int64_t ws_bytes = lvllm_skinny_gemm_argmax_workspace_bytes((int)M);
+  auto ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
+  check(lvllm_skinny_gemm_w8a8_ex(tokens.data_ptr(), x.data_ptr(), w_packed.data_ptr(), nullptr,
+                                  x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N, (int)K,
+                                  x.stride(0), dtype_code(x, "skinny_linear_w8a8_argmax"), 3, ws.data_ptr(), ws_bytes,
+                                  current_stream(x)));
+  return tokens;
+}
+
 torch::Tensor pack_weight(const torch::Tensor& w) {
   TORCH_CHECK(w.is_cuda() && w.dim() == 2 && w.is_contiguous(), "pack_weight: contiguous [N,K] GPU tensor");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(w));
@@ -779,6 +805,8 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("skinny_linear_w8a8_swiglu(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
           "Tensor? bias) -> Tensor");
   amd.impl("skinny_linear_w8a8_swiglu", torch::kCUDA, &skinny_linear_w8a8_swiglu);
+  amd.def("skinny_linear_w8a8_argmax(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K) -> Tensor");
+  amd.impl("skinny_linear_w8a8_argmax", torch::kCUDA, &skinny_linear_w8a8_argmax);
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });

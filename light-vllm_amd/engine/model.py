@@ -254,4 +254,6 @@ class DecoderModel:
         w = self.lm_head
         if _ARGMAX_EPILOGUE and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.packed is not None:
             return torch.ops._C_amd.skinny_linear_packed_argmax(hidden, w.packed, w.N, w.K)
+        if _ARGMAX_EPILOGUE and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.w8_packed is not None:
+            return torch.ops._C_amd.skinny_linear_w8a8_argmax(hidden, w.w8_packed, w.w_scale, w.x_scale, w.N, w.K)
         return torch.argmax(self.compute_logits(hidden), dim=-1)

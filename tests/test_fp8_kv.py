@@ -294,6 +294,25 @@ def test_convert_fp8_both_directions(ops, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(32, 128256, 4096), (1, 256, 128), (17, 32000, 1024), (64, 4096, 2048), (33, 512, 8192)])
+def test_w8a8_argmax_epilogue_gives_torch_argmax_of_the_projection(ops, dtype, M, N, K):
+    from light_vllm_amd.quantization import pack_fp8_weight, skinny_fp8_linear
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    w[N // 2] = w[3]  # an exact tie between two tiles
+    w[N - 1] = w[3]
+    w_scale = (w.abs().max() / 448.0).reshape(1).float()
+    wp = pack_fp8_weight((w / w_scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+    x_scale = (x.float().abs().max() / 448.0).reshape(1)
+    logits = skinny_fp8_linear(x, wp, w_scale, x_scale, N, K, None)
+    tokens = torch.ops._C_amd.skinny_linear_w8a8_argmax(x, wp, w_scale, x_scale, N, K)
+    first = (logits == logits.max(dim=-1, keepdim=True).values).float().argmax(-1)
+    assert tokens.dtype == torch.int64 and torch.equal(tokens, first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,inter,K", [(32, 14336, 4096), (1, 256, 128), (17, 1040, 1024), (64, 2048, 2048),
                                        (33, 512, 8192)])
 def test_w8a8_swiglu_epilogue_is_bit_identical_to_the_two_launches(ops, dtype, M, inter, K):
