@@ -637,6 +637,47 @@ __global__ void skinny_argmax_reduce_kernel(int64_t* __restrict__ tokens, const 
   if (threadIdx.x == 0) tokens[m] = si[0];
 }
 
+// out[m, n] = silu_and_mul of T(sum_s partial[s, m, n] + bias[n]) and T(sum_s partial[s, m, N/2 + n] + bias[N/2 + n]):
+// the SwiGLU epilogue for shapes whose K is split over workgroups (roundings of the reduce kernel followed
+// by silu_and_mul, so the result is bit-identical to the separate launches)
+template <typename T>
+__global__ void skinny_gemm_reduce_swiglu_kernel(typename T::store_t* __restrict__ y, const float* __restrict__ partial,
+                                                 const typename T::store_t* __restrict__ bias, const int M,
+                                                 const int N, const int ksplit) {
+  using S = typename T::store_t;
+  const int half_n = N >> 1;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;  // index into [M, N/2]
+  if (i >= (int64_t)M * half_n) return;
+  const int m = (int)(i / half_n), n = (int)(i - (int64_t)m * half_n);
+  const int64_t MN = (int64_t)M * N;
+  g_f32x4_t gs = g_f32x4_t{0.f, 0.f, 0.f, 0.f}, us = gs;
+  for (int sp = 0; sp < ksplit; ++sp) {
+    const float* row = partial + (int64_t)sp * MN + (int64_t)m * N;
+    const g_f32x4_t a = *reinterpret_cast<const g_f32x4_t*>(row + n);
+    const g_f32x4_t b = *reinterpret_cast<const g_f32x4_t*>(row + half_n + n);
+    if (sp == 0) { gs = a; us = b; }
+    else { gs[0] += a[0]; gs[1] += a[1]; gs[2] += a[2]; gs[3] += a[3]; us[0] += b[0]; us[1] += b[1]; us[2] += b[2]; us[3] += b[3]; }
+  }
+  if (bias != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gs[r] += T::to_float(bias[n + r]);
+      us[r] += T::to_float(bias[half_n + n + r]);
+    }
+  }
+  S o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float gf = T::to_float(T::from_float(gs[r]));
+    const S a = T::from_float(gf / (1.0f + expf(-gf)));
+    o[r] = T::from_float(T::to_float(a) * T::to_float(T::from_float(us[r])));
+  }
+  uint2 ov;
+  ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+  ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+  *reinterpret_cast<uint2*>(y + i) = ov;
+}
+
 template <typename T, int MT, int KSTEPS, bool W8 = false>
 static void launch_skinny(void* y, float* partial, const void* x, const void* w, const void* bias, int M,
                           int N, int K, int64_t ldx, int steps_per_wave, int ntiles, int groups, int ksplit,
@@ -942,10 +983,11 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   int groups = gemm_cus / ksplit;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
-  if (act == 2) {  // SwiGLU epilogue: y is [M, N / 2]
-    LV_CHECK(N % 32 == 0 && ksplit == 1 && !partial_out,
-             "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup (K <= 4096 at M <= 32)");
-    if (groups > ntiles / 2) groups = ntiles / 2;
+  const bool glu_reduce = act == 2 && ksplit > 1;  // K split over workgroups: SwiGLU inside the reduce pass
+  if (act == 2) {  // SwiGLU: y is [M, N / 2]
+    LV_CHECK(N % 32 == 0 && !partial_out, "the SwiGLU epilogue needs N % 32 == 0 and writes y itself");
+    if (glu_reduce) act = 0;  // plain tiles into the fp32 partials
+    else if (groups > ntiles / 2) groups = ntiles / 2;
   }
   void* const tokens_out = y;
   if (act == 3) {  // arg-max epilogue: y is int64 [M]; the workgroups' candidates go through `workspace`
@@ -989,6 +1031,17 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   if (act == 3) {
     hipLaunchKernelGGL(skinny_argmax_reduce_kernel, dim3(M), dim3(256), 0, s, (int64_t*)tokens_out, (const float*)y,
                        groups, M);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
+  if (glu_reduce) {
+    const int grid = (int)(((int64_t)M * (N / 2) / 4 + 255) / 256);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_swiglu_kernel<BF16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, M, N, ksplit);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_swiglu_kernel<F16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, M, N, ksplit);
     LV_LAUNCH_CHECK();
     return 0;
   }

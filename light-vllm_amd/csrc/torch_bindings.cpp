@@ -356,17 +356,13 @@ torch::Tensor skinny_linear_packed_swiglu(const torch::Tensor& x, const torch::T
   const int64_t M = x.size(0);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
   auto y = torch::empty({M, N / 2}, x.options());
-  if (lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K) > 0) {
-    // K is split over workgroups at this M: the two launches the epilogue would have replaced
-    auto gate_up = skinny_linear_impl(x, w_packed, bias, true, N, K);
-    TORCH_CHECK(gate_up.defined(), lvllm_last_error());
-    check(lvllm_silu_and_mul(y.data_ptr(), gate_up.data_ptr(), M, (int)(N / 2), dtype_code(x, "silu_and_mul"),
-                             current_stream(x)));
-    return y;
-  }
+  // K split over workgroups at this M: the fp32 partials are summed and activated by one reduce launch
+  const int64_t ws_bytes = lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
   check(lvllm_skinny_gemm_ex(y.data_ptr(), x.data_ptr(), w_packed.data_ptr(), bias ? bias->data_ptr() : nullptr,
                              (int)M, (int)N, (int)K, x.stride(0), dtype_code(x, "skinny_linear_packed_swiglu"), 1, 2,
-                             0, nullptr, nullptr, 0, current_stream(x)));
+                             0, nullptr, ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, current_stream(x)));
   return y;
 }
 
