@@ -241,6 +241,9 @@ def main():
 
     B, ctx = a.batch_size, a.context
     on_the_fly = max(1, a.on_the_fly) if a.scheduling == "async" else 1
+    # the timed region holds exactly K steps with an empty pipeline on both sides: it cannot keep more
+    # steps in flight than it has steps (nor can the warm-up loop)
+    on_the_fly = max(1, min(on_the_fly, a.steps, a.warmup if a.warmup > 0 else on_the_fly))
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
