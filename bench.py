@@ -242,8 +242,8 @@ def main():
     B, ctx = a.batch_size, a.context
     on_the_fly = max(1, a.on_the_fly) if a.scheduling == "async" else 1
     # the timed region holds exactly K steps with an empty pipeline on both sides: it cannot keep more
-    # steps in flight than it has steps (nor can the warm-up loop)
-    on_the_fly = max(1, min(on_the_fly, a.steps, a.warmup if a.warmup > 0 else on_the_fly))
+    # steps in flight than it has steps
+    on_the_fly = max(1, min(on_the_fly, a.steps))
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
@@ -266,6 +266,9 @@ def main():
         prompt = torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist()
         engine.add_request(str(i), prompt, max_tokens=total_steps + 100)
     engine.prefill_synthetic(seed=rank)
+    # set-up, not a step: every stream's HIP graph of the step is captured now, so that the timed region
+    # replays graphs whatever W is (capture otherwise happens at a slot's first step)
+    engine.capture_decode_graphs(B)
     if a.scheduling == "async":
         def step(i, n):
             # the last (on_the_fly - 1) calls only collect: the pipeline is empty on both sides

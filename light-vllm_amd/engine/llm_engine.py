@@ -222,6 +222,18 @@ class LLMEngine:
         self._pending: List[Tuple[int, torch.cuda.Event, SchedulerOutput, ExecuteOutput]] = []
         self.step_returns_outputs = True
 
+    def capture_decode_graphs(self, batch_size: int) -> None:
+        """Set-up: capture every slot's HIP graph of a decode step of `batch_size` sequences now rather than
+        at the slot's first step.  Each capture runs under the slot's own stream, as the first step would:
+        captured from the default stream the two steps in flight lose 27 % (measured; the null stream's
+        implicit synchronisation is the suspect)."""
+        if self.worker.graph_pools is None:
+            return
+        for slot, pool in enumerate(self.worker.graph_pools):
+            with torch.cuda.stream(self.streams[slot]):
+                pool.get(batch_size)
+        torch.cuda.synchronize(self.device)
+
     # ---- requests ----
     def add_request(self, request_id: str, prompt_token_ids: List[int], max_tokens: int = 16) -> None:
         seq = Sequence(self.seq_counter, list(prompt_token_ids), self.cache_config.block_size, self.eos_token_id)
