@@ -1,7 +1,9 @@
 #!/bin/bash
 # Diagnosis builds of the weight-streaming GEMM: build/trace_e<N>/liblvllm_hip.so with
-# -DLVLLM_GEMM_TRACE -DLVLLM_GEMM_EXP=<N>  (0 = shipped order, 1 = no activation loads,
-# 2 = no weight stream, 3 = activations first); tools/trace_gemm.py reads the timestamps.
+# -DLVLLM_GEMM_TRACE -DLVLLM_GEMM_EXP=<N>  (0 = shipped kernel, 2 = no weight stream; the variants 1 = no
+# activation loads and 3 = activations first of profiles/r01_tuning.md belonged to the fragment-order
+# activation path that the trace replaced; EXTRA=-DLVLLM_GEMM_XORDER=1 requests the weights before X);
+# tools/trace_gemm.py reads the timestamps.
 set -e
 cd "$(dirname "$0")/.."
 objs=$(ls build/obj/*.o | grep -v skinny_gemm)
