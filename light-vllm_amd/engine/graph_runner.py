@@ -200,8 +200,18 @@ class DecodeGraphPool:
         p = self.padded(batch_size)
         g = self.graphs.get(p)
         if g is None:
-            g = DecodeGraph(self.model, self.kv_caches, p, self.max_blocks_per_seq, self.block_size,
-                            self.device)
-            g.capture()
+            # Never build a graph from the default stream: two graphs built there replay one after the
+            # other even on different streams (two steps in flight measured 27 % slower, as fast as one).
+            cur = torch.cuda.current_stream(self.device)
+            side = None
+            if cur == torch.cuda.default_stream(self.device):
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(cur)
+            with torch.cuda.stream(side if side is not None else cur):
+                g = DecodeGraph(self.model, self.kv_caches, p, self.max_blocks_per_seq, self.block_size,
+                                self.device)
+                g.capture()
+            if side is not None:
+                cur.wait_stream(side)
             self.graphs[p] = g
         return g

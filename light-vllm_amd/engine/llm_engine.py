@@ -224,9 +224,8 @@ class LLMEngine:
 
     def capture_decode_graphs(self, batch_size: int) -> None:
         """Set-up: capture every slot's HIP graph of a decode step of `batch_size` sequences now rather than
-        at the slot's first step.  Each capture runs under the slot's own stream, as the first step would:
-        captured from the default stream the two steps in flight lose 27 % (measured; the null stream's
-        implicit synchronisation is the suspect)."""
+        at the slot's first step.  Each capture runs under the slot's own stream, as the first step would
+        (DecodeGraphPool.get refuses to build a graph from the default stream: see there)."""
         if self.worker.graph_pools is None:
             return
         for slot, pool in enumerate(self.worker.graph_pools):
