@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ..attention.backend import PagedAttnMetadata
-from .input_builder import DecodeStepArrays
+from .input_builder import DecodeStepArrays, MixedStepArrays
 
 
 class DecodeGraph:
@@ -117,13 +117,22 @@ class MixedGraph:
         self.max_tokens, self.max_seqs = max_tokens, max_seqs
         self.max_blocks_per_seq, self.block_size = max_blocks_per_seq, block_size
         dev = torch.device(device)
-        self.input_ids = torch.zeros(max_tokens, dtype=torch.int64, device=dev)
-        self.positions = torch.zeros(max_tokens, dtype=torch.int64, device=dev)
-        self.slot_mapping = torch.full((max_tokens,), -1, dtype=torch.int64, device=dev)
-        self.block_tables = torch.zeros(max_seqs, max_blocks_per_seq, dtype=torch.int32, device=dev)
-        self.seq_lens = torch.zeros(max_seqs, dtype=torch.int32, device=dev)
-        self.query_start_loc = torch.zeros(max_seqs + 1, dtype=torch.int32, device=dev)
-        self.sample_rows = torch.zeros(max_seqs, dtype=torch.int64, device=dev)
+        # static inputs = views of one device buffer, mirrored by one pinned staging buffer (MixedStepArrays)
+        T, S, W = max_tokens, max_seqs, max_blocks_per_seq
+        o = MixedStepArrays.layout(T, S, W)
+        self.packed = torch.zeros(o[-1], dtype=torch.uint8, device=dev)
+        self.input_ids = self.packed[o[0]:o[1]].view(torch.int64)
+        self.positions = self.packed[o[1]:o[2]].view(torch.int64)
+        self.slot_mapping = self.packed[o[2]:o[3]].view(torch.int64)
+        self.sample_rows = self.packed[o[3]:o[4]].view(torch.int64)
+        self.seq_lens = self.packed[o[4]:o[5]].view(torch.int32)
+        self.query_start_loc = self.packed[o[5]:o[6]].view(torch.int32)
+        self.block_tables = self.packed[o[6]:o[7]].view(torch.int32).view(S, W)
+        self.slot_mapping.fill_(-1)
+        self.host = torch.zeros(o[-1], dtype=torch.uint8, pin_memory=dev.type == "cuda")
+        self.staging = MixedStepArrays(T, S, W, block_size, self.host.numpy())
+        self._host_tokens = [torch.empty(S, dtype=torch.int64, pin_memory=dev.type == "cuda") for _ in range(4)]
+        self._host_tokens_next = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.next_tokens: Optional[torch.Tensor] = None
 
@@ -165,6 +174,15 @@ class MixedGraph:
         if torch.cuda.is_available():
             rows = rows.pin_memory()
         self.sample_rows.copy_(rows, non_blocking=True)
+
+    def load_staged(self) -> None:
+        """The step written into `staging` (MixedStepArrays.fill) goes to the device in one copy."""
+        self.packed.copy_(self.host, non_blocking=True)
+
+    def next_host_tokens(self) -> torch.Tensor:
+        t = self._host_tokens[self._host_tokens_next]
+        self._host_tokens_next = (self._host_tokens_next + 1) % len(self._host_tokens)
+        return t
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()

@@ -271,3 +271,109 @@ class DecodeStepArrays:
             self.slot_mapping[n:] = -1
             self.seq_lens[n:] = 0
         return seq_ids
+
+
+class MixedStepArrays:
+    """DecodeStepArrays for a step that mixes prompt chunks and decode tokens (chunked prefill under a
+    captured graph): token ids, positions, slot mapping [max_tokens]; rows to sample, sequence lengths,
+    query_start_loc, block tables [max_seqs] -- numpy views of one staging buffer, filled from the
+    scheduler's metadata with the values ModelInputBuilder + the attention metadata builder compute
+    (model_input_builder.py:212-378: a prompt chunk covers tokens [computed, min(len, computed + chunk)),
+    a decode sequence its last token; slot of position p = table[p // block_size] * block_size +
+    p % block_size; a sequence samples from the last row of its chunk).  Single-sequence groups, no
+    sliding window, no prefix-cache hit (the general builder refuses that with chunked prefill)."""
+
+    def __init__(self, max_tokens: int, max_seqs: int, max_blocks_per_seq: int, block_size: int,
+                 buffer: Optional[np.ndarray] = None):
+        T, S, W = max_tokens, max_seqs, max_blocks_per_seq
+        self.max_tokens, self.max_seqs, self.width, self.block_size = T, S, W, block_size
+        o = self.layout(T, S, W)
+        self.nbytes = o[-1]
+        buf = np.zeros(self.nbytes, dtype=np.uint8) if buffer is None else buffer
+        assert buf.dtype == np.uint8 and buf.size == self.nbytes
+        self.buffer = buf
+        self.input_ids = buf[o[0]:o[1]].view(np.int64)
+        self.positions = buf[o[1]:o[2]].view(np.int64)
+        self.slot_mapping = buf[o[2]:o[3]].view(np.int64)
+        self.sample_rows = buf[o[3]:o[4]].view(np.int64)
+        self.seq_lens = buf[o[4]:o[5]].view(np.int32)
+        self.query_start_loc = buf[o[5]:o[6]].view(np.int32)
+        self.block_tables = buf[o[6]:o[7]].view(np.int32).reshape(S, W)
+        self.slot_mapping[:] = -1
+        self._rows: List[Optional[List[int]]] = [None] * S
+
+    @staticmethod
+    def layout(T: int, S: int, W: int):
+        """Byte offsets of input_ids, positions, slot_mapping (i64[T]), sample_rows (i64[S]), seq_lens
+        (i32[S]), query_start_loc (i32[S + 1]), block_tables (i32[S, W]) and the total size."""
+        a = [0, 8 * T, 16 * T, 24 * T]
+        a.append(a[-1] + 8 * S)
+        a.append(a[-1] + 4 * S)
+        a.append(a[-1] + 4 * (S + 1))
+        a.append(a[-1] + 4 * S * W)
+        return a
+
+    @staticmethod
+    def eligible(metas, worker_lists_empty: bool, sliding_window) -> bool:
+        if not worker_lists_empty or sliding_window is not None or not metas:
+            return False
+        for m in metas:
+            if len(m.seq_data) != 1 or not m.block_tables or (m.is_prompt and m.computed_block_nums):
+                return False
+        return True
+
+    def fill(self, metas):
+        """Returns (sequence ids that sample, number of tokens) or None when the step does not fit."""
+        ns = len(metas)
+        if ns > self.max_seqs:
+            return None
+        bs, bt, rows, W = self.block_size, self.block_tables, self._rows, self.width
+        cursor = 0
+        sample_rows: List[int] = []
+        sample_ids: List[int] = []
+        qsl = self.query_start_loc
+        qsl[0] = 0
+        for i, m in enumerate(metas):
+            (seq_id, data), = m.seq_data.items()
+            table = m.block_tables[seq_id]
+            old = rows[i]
+            if old is None or table != old:
+                k = len(table)
+                if k > W:
+                    rows[i] = None
+                    return None
+                bt[i, :k] = table
+                rows[i] = list(table)
+            if m.is_prompt:
+                ctx = data.get_num_computed_tokens()
+                end = min(data.get_len(), ctx + m.token_chunk_size)
+                q = end - ctx
+                if cursor + q > self.max_tokens:
+                    return None
+                self.input_ids[cursor:cursor + q] = data.get_token_ids()[ctx:end]
+                pos = np.arange(ctx, end, dtype=np.int64)
+                self.positions[cursor:cursor + q] = pos
+                self.slot_mapping[cursor:cursor + q] = bt[i, pos // bs].astype(np.int64) * bs + pos % bs
+                self.seq_lens[i] = end
+            else:
+                L = data.get_len()
+                q = 1
+                if cursor + 1 > self.max_tokens:
+                    return None
+                self.input_ids[cursor] = data.get_last_token_id()
+                self.positions[cursor] = L - 1
+                self.slot_mapping[cursor] = int(bt[i, (L - 1) // bs]) * bs + (L - 1) % bs
+                self.seq_lens[i] = L
+            cursor += q
+            qsl[i + 1] = cursor
+            if m.do_sample:
+                sample_rows.append(cursor - 1)
+                sample_ids.append(seq_id)
+        n = cursor
+        self.slot_mapping[n:] = -1          # padding tokens write no cache
+        self.seq_lens[ns:] = 0
+        qsl[ns + 1:] = n                    # padding sequences own no tokens
+        k = len(sample_rows)
+        self.sample_rows[:k] = sample_rows
+        self.sample_rows[k:] = 0
+        return sample_ids, n

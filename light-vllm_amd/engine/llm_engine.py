@@ -158,6 +158,25 @@ class Worker:
         return ExecuteOutput(out, seq_ids)
 
 
+    @torch.inference_mode()
+    def execute_mixed(self, metas, slot: int = 0) -> Optional[ExecuteOutput]:
+        """A step of prompt chunks and decode tokens under the captured mixed graph, staged straight
+        from the scheduler's metadata (MixedStepArrays); None when it does not fit."""
+        graphs = self.graph_pools[slot] if self.graph_pools is not None else None
+        if graphs is None or self.mixed_graph_tokens <= 0 or self.capture_logits:
+            return None
+        g = graphs.get_mixed(self.mixed_graph_tokens, self.mixed_graph_seqs)
+        filled = g.staging.fill(metas)
+        if filled is None:
+            return None
+        seq_ids, _ = filled
+        g.load_staged()
+        tokens = g.replay()[:len(seq_ids)]
+        out = g.next_host_tokens()[:len(seq_ids)]
+        out.copy_(tokens, non_blocking=True)
+        return ExecuteOutput(out, seq_ids)
+
+
 class LLMEngine:
 
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig,
@@ -327,10 +346,16 @@ class LLMEngine:
         """Decode-only steps go from the scheduler's metadata to the captured graph directly; every
         other step through the general input builder."""
         if self.fast_decode_inputs:
-            from .input_builder import DecodeStepArrays
+            from .input_builder import DecodeStepArrays, MixedStepArrays
             plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
-            if DecodeStepArrays.eligible(sched.seq_group_metadata_list, plain, self.cache_config.sliding_window):
-                out = self.worker.execute_decode(sched.seq_group_metadata_list, slot)
+            metas = sched.seq_group_metadata_list
+            if DecodeStepArrays.eligible(metas, plain, self.cache_config.sliding_window):
+                out = self.worker.execute_decode(metas, slot)
+                if out is not None:
+                    return out
+            elif self.worker.mixed_graph_tokens > 0 and MixedStepArrays.eligible(metas, plain,
+                                                                                 self.cache_config.sliding_window):
+                out = self.worker.execute_mixed(metas, slot)
                 if out is not None:
                     return out
         return self.worker.execute(self.input_builder(sched), slot)

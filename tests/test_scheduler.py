@@ -260,3 +260,66 @@ def test_decode_step_arrays_equal_the_general_input_builder():
                             s.free_seq(seq)
             s.free_finished_request([sg.seq_group.request_id for sg in out.scheduled_seq_groups])
         assert checked > 100, checked
+
+
+def test_mixed_step_arrays_equal_the_general_input_builder():
+    """MixedStepArrays (chunked-prefill steps staged for the captured mixed graph) against
+    ModelInputBuilder + the attention metadata builder over a run with prompt chunks of every size,
+    decode tokens, finishing sequences and preemption: bit-equal every step."""
+    import random
+
+    import numpy as np
+
+    from light_vllm_amd.engine.input_builder import MixedStepArrays
+    for version, mode in ((False, None), (True, None), (False, "swap")):
+        rng = random.Random(11)
+        cc = CacheConfig(block_size=4, num_gpu_blocks=48, num_cpu_blocks=16)
+        sc = SchedulerConfig(max_num_batched_tokens=16, max_num_seqs=8, max_model_len=256,
+                             use_v2_block_manager=version, preemption_mode=mode, chunked_prefill_enabled=True)
+        s = DecodingScheduler(sc, cc, chunked_prefill_enabled=True)
+        builder = ModelInputBuilder(sc, cc, PagedAttnBackend(), chunked_prefill_enabled=True)
+        arrays = MixedStepArrays(16, 8, 64, 4)
+        next_id, checked, with_prompts = 0, 0, 0
+        for step in range(400):
+            if rng.random() < 0.2 and next_id < 40:
+                add(s, next_id, rng.randint(1, 40), max_tokens=rng.randint(2, 20))
+                next_id += 1
+            out = s.schedule()
+            if out is None or out.is_empty():
+                continue
+            metas = out.seq_group_metadata_list
+            plain = not (out.blocks_to_swap_in or out.blocks_to_swap_out or out.blocks_to_copy)
+            if MixedStepArrays.eligible(metas, plain, None):
+                filled = arrays.fill(metas)
+                assert filled is not None
+                ids, n = filled
+                mi = builder(out).model_input
+                md = mi.attn_metadata
+                ns = len(metas)
+                assert n == mi.input_tokens.shape[0] and ids == mi.sample_seq_ids
+                assert np.array_equal(arrays.input_ids[:n], mi.input_tokens.numpy())
+                assert np.array_equal(arrays.positions[:n], mi.input_positions.numpy())
+                assert np.array_equal(arrays.slot_mapping[:n], md.slot_mapping.numpy())
+                assert np.array_equal(arrays.seq_lens[:ns], md.seq_lens_tensor.numpy())
+                assert np.array_equal(arrays.query_start_loc[:ns + 1], md.query_start_loc.numpy())
+                assert list(arrays.sample_rows[:len(ids)]) == mi.sample_indices
+                lens = md.seq_lens_tensor.numpy()
+                for i in range(ns):
+                    k = (int(lens[i]) + 3) // 4
+                    assert np.array_equal(arrays.block_tables[i, :k], md.block_tables[i, :k].numpy()), (step, i)
+                assert (arrays.slot_mapping[n:] == -1).all() and (arrays.seq_lens[ns:] == 0).all()
+                assert (arrays.query_start_loc[ns + 1:] == n).all()
+                checked += 1
+                with_prompts += any(m.is_prompt for m in metas)
+            for sg in out.scheduled_seq_groups:
+                g = sg.seq_group
+                was_prefill = g.is_prefill()
+                g.update_num_computed_tokens(sg.token_chunk_size)
+                if not g.is_prefill():  # the chunk reached the end of the prompt, or a decode step
+                    for seq in g.get_seqs(status=SequenceStatus.RUNNING):
+                        seq.append_token_id(rng.randint(0, 999))
+                        if seq.get_output_len() >= g.max_tokens:
+                            seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                            s.free_seq(seq)
+            s.free_finished_request([sg.seq_group.request_id for sg in out.scheduled_seq_groups])
+        assert checked > 150 and with_prompts > 30, (checked, with_prompts)
