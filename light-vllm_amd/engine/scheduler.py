@@ -181,15 +181,18 @@ class DecodingScheduler:
             # The common case -- one running sequence in its decode stage, no chunking -- is the general
             # body below with n_seqs = 1 and num_running_tokens = 1, without its list building.
             seqs = seq_group.seqs
-            if (not enable_chunking and len(seqs) == 1 and seq_group.n <= 1
+            if (len(seqs) == 1 and seq_group.n <= 1
                     and seqs[0].status == SequenceStatus.RUNNING and not seqs[0].is_prefill()
                     and num_scheduled_seqs + 1 <= budget.max_num_seqs
+                    and (not enable_chunking or budget.remaining_token_budget() >= 1)
                     and self.block_manager.can_append_slots(seq_group, 0)):
                 q.popleft()
                 blocks_to_copy.extend(self.block_manager.append_slots(seqs[0], 0))
                 num_scheduled_seqs += 1
                 decodes.append(ScheduledSequenceGroup(seq_group, 1))
                 budget.add_num_batched_tokens(seq_group.request_id, 1)
+                if enable_chunking:
+                    budget.add_num_seqs(seq_group.request_id, 1)
                 continue
             # One step never carries more than max_num_seqs sequences.  The reference relies on
             # admission control for this (prompts are admitted under the same budget); here it is
