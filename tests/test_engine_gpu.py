@@ -394,3 +394,44 @@ def test_mixed_steps_replay_one_graph():
     for i, p in enumerate(ps):
         ref = dense_reference_logits(graph.worker.model, p + tg[i])
         assert int(ref[len(p) - 1].argmax()) == tg[i][0]
+
+
+def test_decode_batches_of_65_to_128_rows_take_the_stream_gemm(monkeypatch):
+    """96 sequences per decode step: the projections go through lvllm_stream_gemm (X through LDS).  The run
+    must finish every request and agree with the same run on the library GEMM wherever near-ties do not
+    flip an argmax (first tokens: the same prompt, the same weights)."""
+    import light_vllm_amd.engine.model as model_mod
+    g = torch.Generator().manual_seed(5)
+    reqs = [torch.randint(0, 512, (int(torch.randint(2, 40, (1,), generator=g)),), generator=g).tolist() for _ in range(96)]
+
+    def run(stream_rows):
+        monkeypatch.setattr(model_mod, "_STREAM_GEMM_MAX_ROWS", stream_rows)
+        e = make_engine(graph=True, num_blocks=1024, max_seqs=96, budget=4096)
+        for i, p in enumerate(reqs):
+            e.add_request(str(i), p, max_tokens=6)
+        final = {}
+        for _ in range(200):
+            for out in e.step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not e.has_unfinished_requests():
+                break
+        e.shutdown()
+        return final
+
+    calls = []
+    real = torch.ops._C_amd.stream_linear_packed
+
+    class Spy:
+        def __call__(self, *a, **k):
+            calls.append(a[0].shape[0])
+            return real(*a, **k)
+
+    monkeypatch.setattr(model_mod.torch.ops._C_amd, "stream_linear_packed", Spy(), raising=False)
+    got = run(256)
+    assert calls and max(calls) > 64, "the stream GEMM was never called with more than 64 rows"
+    want = run(0)
+    assert len(got) == len(want) == len(reqs) and all(len(t) == 6 for t in got.values())
+    same_first = sum(got[k][0] == want[k][0] for k in want)
+    same_all = sum(got[k] == want[k] for k in want)
+    assert same_first >= len(reqs) - 3 and same_all >= int(0.8 * len(reqs)), (same_first, same_all)
