@@ -61,6 +61,12 @@ class SchedulerConfig:
     max_model_len: int = 8192
     use_v2_block_manager: bool = False
     scheduling: str = "sync"          # sync | simple_async | async | double_buffer
-    max_num_on_the_fly: int = 2       # light_vllm/decoding/config.py:149-155
+    max_num_on_the_fly: Optional[int] = None  # None: 3 for "double_buffer", else 2 (decoding/config.py:149-155)
     preemption_mode: Optional[str] = None  # None | "swap" | "recompute"
     chunked_prefill_enabled: bool = False  # decoding/config.py: prompts are cut to the token budget
+
+    def __post_init__(self) -> None:
+        if self.max_num_on_the_fly is None:
+            self.max_num_on_the_fly = 3 if self.scheduling == "double_buffer" else 2
+        if self.max_num_on_the_fly < 1:  # the reference insists on >= 2 (:190-193); one step in flight is
+            raise ValueError(f"max_num_on_the_fly {self.max_num_on_the_fly} must be positive")  # allowed here
