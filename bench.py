@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--context", type=int, default=1024)
-    ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
+    ap.add_argument("--scheduling", default="async", choices=["sync", "simple_async", "async"])
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
                     help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
     ap.add_argument("--quantization", default=None, choices=["fp8"],
@@ -174,7 +174,7 @@ def gemm_leg(engine, B):
             tot_s += t
         return dict(per_shape=per_shape, bytes_per_layer=tot_bytes, s_per_layer=tot_s)
     finally:
-        torch.ops._C_amd.set_tuning("gemm_workgroups", 128 if engine.num_slots > 1 else 256)
+        torch.ops._C_amd.set_tuning("gemm_workgroups", engine.gemm_workgroups)
 
 
 def cpu_baseline_leg(engine, B, budget_s=20.0):
@@ -240,7 +240,7 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     B, ctx = a.batch_size, a.context
-    on_the_fly = max(1, a.on_the_fly) if a.scheduling == "async" else 1
+    on_the_fly = max(1, a.on_the_fly) if a.scheduling != "sync" else 1
     # the timed region holds exactly K steps with an empty pipeline on both sides: it cannot keep more
     # steps in flight than it has steps
     on_the_fly = max(1, min(on_the_fly, a.steps))
@@ -269,7 +269,7 @@ def main():
     # set-up, not a step: every stream's HIP graph of the step is captured now, so that the timed region
     # replays graphs whatever W is (capture otherwise happens at a slot's first step)
     engine.capture_decode_graphs(B)
-    if a.scheduling == "async":
+    if a.scheduling != "sync":
         def step(i, n):
             # the last (on_the_fly - 1) calls only collect: the pipeline is empty on both sides
             # of the timed region, which therefore holds exactly K steps

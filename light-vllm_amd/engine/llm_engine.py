@@ -188,8 +188,10 @@ class LLMEngine:
         self.attn_backend = PagedAttnBackend()
         # steps in flight run on separate streams (a stream per task, core/executor.py:62-93), so
         # each needs its own graph static buffers
+        # ("simple_async": the reference's executor runs the queued steps one after the other,
+        # core/executor.py:48-60 -- here they keep their own graph buffers but share one stream)
         self.num_slots = (max(1, scheduler_config.max_num_on_the_fly)
-                          if scheduler_config.scheduling in ("async", "double_buffer") else 1)
+                          if scheduler_config.scheduling in ("simple_async", "async", "double_buffer") else 1)
         # chunked prefill with a token budget the decode GEMM takes (<= 64 rows): mixed steps replay a graph
         mixed = (scheduler_config.chunked_prefill_enabled and scheduler_config.max_num_batched_tokens <= 64
                  and cache_config.sliding_window is None and model_config.fuse_decode_ops
@@ -204,7 +206,9 @@ class LLMEngine:
         # to the other step's kernel (+10 % tokens/s when measured first; since the GEMM's activation
         # path was fixed a lone 128-workgroup GEMM is as fast as a 256-workgroup one and the setting
         # is worth +-1.5 %: profiles/r01_tuning.md)
-        gemm_wgs = int(os.environ.get("LVLLM_ENGINE_GEMM_WGS", "0")) or (128 if self.num_slots > 1 else 256)
+        concurrent = self.num_slots > 1 and scheduler_config.scheduling != "simple_async"
+        gemm_wgs = int(os.environ.get("LVLLM_ENGINE_GEMM_WGS", "0")) or (128 if concurrent else 256)
+        self.gemm_workgroups = gemm_wgs
         torch.ops._C_amd.set_tuning("gemm_workgroups", gemm_wgs)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
         if num_gpu is None:
@@ -220,7 +224,10 @@ class LLMEngine:
         self.groups: Dict[str, SequenceGroup] = {}
         self.seq_to_group: Dict[int, SequenceGroup] = {}
         # async machinery (core/executor.py:48-185)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.num_slots)]
+        if scheduler_config.scheduling == "simple_async":
+            self.streams = [torch.cuda.Stream(self.device)] * self.num_slots
+        else:
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.num_slots)]
         self.stream = self.streams[0]
         self.free_slots: "queue.Queue" = queue.Queue()
         for i in range(self.num_slots):

@@ -125,6 +125,9 @@ def test_graph_replay_and_async_give_the_same_tokens():
     assert eager == graph
     assert eager == asyn
     assert eager == asyn_waiter
+    # "simple_async": two steps queued on ONE stream, each with its own graph buffers
+    simple = run_to_completion(make_engine(graph=True, scheduling="simple_async", max_seqs=3), use_async=True)
+    assert eager == simple
 
 
 def test_decode_fast_path_gives_the_tokens_of_the_general_input_builder():
