@@ -420,7 +420,8 @@ class LLMEngine:
         """schedule_more=False only collects a result (used to drain the pipeline)."""
         self.ensure_start_execute_loop()
         # keep up to max_num_on_the_fly steps queued behind the one that is executing
-        while schedule_more and self.num_on_the_fly < self.scheduler_config.max_num_on_the_fly:
+        limit = min(self.scheduler_config.max_num_on_the_fly, self.num_slots)  # a step needs a slot's buffers
+        while schedule_more and self.num_on_the_fly < limit:
             sched = self.scheduler.schedule()
             if sched is None or sched.is_empty():
                 break
