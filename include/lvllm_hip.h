@@ -212,6 +212,11 @@ int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, const void* 
 int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
                          int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
                          int* ksplit_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* LayerNorm(x + y) of the encoder models (xlm_roberta.py; torch ops in the reference): z = T(x + y),
+ * out = T((z - mean) * rsqrt(var + eps) * weight + bias), statistics in fp32.  y may be NULL (plain
+ * LayerNorm).  16-bit element types, hidden_size % 8 == 0, contiguous rows, out may alias x. */
+int lvllm_add_layer_norm(void* out, const void* x, const void* y, const void* weight, const void* bias,
+                         float epsilon, int num_tokens, int hidden_size, int dtype, void* stream);
 /* fused_add_rms_norm whose input is the fp32 split-K partials of the preceding projection:
  * x = T(sum_s partials[s]); residual = T(x + residual); out = norm(residual) * weight. */
 int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,

@@ -188,6 +188,75 @@ __global__ void rms_norm_scalar_kernel(typename T::store_t* out,
   }
 }
 
+// LayerNorm of x (+ y) for the encoder models of the prefill-only workflow (bge-m3 / XLM-RoBERTa:
+// `LayerNorm(hidden_states + input_tensor)` after the attention output and after the MLP,
+// light_vllm/encode_only/modelzoo/xlm_roberta.py; the reference leaves both to torch).  One launch
+// instead of an add and a layer_norm: z = T(float(x) + float(y)) -- the rounded sum torch's `x + y`
+// materialises -- then out = T((z - mean) * rsqrt(var + eps) * w + b) with mean and the
+// centred variance in fp32.  16-bit element types, hidden_size % 8 == 0, rows of at most
+// 8 * kMaxCached * blockDim elements stay in registers between the passes.
+template <typename T>
+__global__ void add_layer_norm_kernel(typename T::store_t* out, const typename T::store_t* x,  // may alias
+                                      const typename T::store_t* __restrict__ y,  // nullable
+                                      const typename T::store_t* __restrict__ weight,
+                                      const typename T::store_t* __restrict__ bias, const float epsilon,
+                                      const int hidden_size) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  __shared__ float red[16];
+  const int nvec = hidden_size / N;
+  const int64_t row = (int64_t)blockIdx.x * nvec;
+  const V* x_v = reinterpret_cast<const V*>(x) + row;
+  const V* y_v = y ? reinterpret_cast<const V*>(y) + row : nullptr;
+  V* out_v = reinterpret_cast<V*>(out) + row;
+  const V* w_v = reinterpret_cast<const V*>(weight);
+  const V* b_v = reinterpret_cast<const V*>(bias);
+  V cache[kMaxCached];
+  float sum = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V z = x_v[i];
+    if (y_v != nullptr) {
+      const V r = y_v[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) z.v[j] = T::from_float(T::to_float(z.v[j]) + T::to_float(r.v[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) sum += T::to_float(z.v[j]);
+#pragma unroll
+    for (int k = 0; k < kMaxCached; ++k)
+      if (c == k) cache[k] = z;
+  }
+  const float mean = block_sum(sum, red) / hidden_size;
+  float var = 0.f;
+  c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V z;
+#pragma unroll
+    for (int k = 0; k < kMaxCached; ++k)
+      if (c == k) z = cache[k];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float d = T::to_float(z.v[j]) - mean;
+      var += d * d;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(var, red) / hidden_size + epsilon);
+  c = 0;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x, ++c) {
+    V z;
+#pragma unroll
+    for (int k = 0; k < kMaxCached; ++k)
+      if (c == k) z = cache[k];
+    const V w = w_v[i], b = b_v[i];
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      o.v[j] = T::from_float((T::to_float(z.v[j]) - mean) * rstd * T::to_float(w.v[j]) + T::to_float(b.v[j]));
+    out_v[i] = o;
+  }
+}
+
 template <typename T, bool FUSED_ADD>
 static int launch_rms(void* out, void* res, const void* in, const void* weight, float eps,
                       int num_tokens, int hidden_size, hipStream_t stream) {
@@ -264,3 +333,27 @@ extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const 
 }
 
 LVLLM_TRACE_READER(lvllm_trace_read_norm)
+
+// out = LayerNorm(x + y) (y may be null: plain LayerNorm); see add_layer_norm_kernel.  out may alias x.
+extern "C" int lvllm_add_layer_norm(void* out, const void* x, const void* y, const void* weight, const void* bias,
+                                    float epsilon, int num_tokens, int hidden_size, int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit element types only");
+  LV_CHECK(hidden_size > 0 && hidden_size % 8 == 0, "hidden_size must be a positive multiple of 8");
+  LV_CHECK((((uintptr_t)out | (uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0,
+           "pointers must be 16-byte aligned");
+  const int nvec = hidden_size / 8;
+  int threads = ((nvec + 63) / 64) * 64;
+  threads = threads > 1024 ? 1024 : threads;
+  LV_CHECK(nvec <= lvllm::kMaxCached * threads, "hidden_size beyond 32768 is not supported");
+  if (dtype == LVLLM_BF16)
+    hipLaunchKernelGGL((lvllm::add_layer_norm_kernel<lvllm::BF16>), dim3(num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, (const uint16_t*)x, (const uint16_t*)y,
+                       (const uint16_t*)weight, (const uint16_t*)bias, epsilon, hidden_size);
+  else
+    hipLaunchKernelGGL((lvllm::add_layer_norm_kernel<lvllm::F16>), dim3(num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, (const uint16_t*)x, (const uint16_t*)y,
+                       (const uint16_t*)weight, (const uint16_t*)bias, epsilon, hidden_size);
+  LV_LAUNCH_CHECK();
+  return 0;
+}

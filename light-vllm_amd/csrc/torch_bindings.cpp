@@ -390,6 +390,23 @@ torch::Tensor skinny_linear_packed_partials(const torch::Tensor& gate_up, const 
   return partials;
 }
 
+void add_layer_norm(torch::Tensor& out, const torch::Tensor& x, const std::optional<torch::Tensor>& y,
+                    const torch::Tensor& weight, const torch::Tensor& bias, double epsilon) {
+  LV_CHECK_DEVICE(x);
+  TORCH_CHECK(x.is_contiguous() && out.is_contiguous() && out.sizes() == x.sizes() && out.scalar_type() == x.scalar_type(),
+              "add_layer_norm: contiguous out and x of the same shape and type");
+  TORCH_CHECK(!y || (y->is_contiguous() && y->sizes() == x.sizes() && y->scalar_type() == x.scalar_type()),
+              "add_layer_norm: y must match x");
+  const int hidden = (int)x.size(-1);
+  TORCH_CHECK(weight.numel() == hidden && bias.numel() == hidden && weight.is_contiguous() && bias.is_contiguous() &&
+                  weight.scalar_type() == x.scalar_type() && bias.scalar_type() == x.scalar_type(),
+              "add_layer_norm: weight and bias of [hidden] in x's type");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  check(lvllm_add_layer_norm(out.data_ptr(), x.data_ptr(), y ? y->data_ptr() : nullptr, weight.data_ptr(),
+                             bias.data_ptr(), (float)epsilon, (int)(x.numel() / hidden), hidden,
+                             dtype_code(x, "add_layer_norm"), current_stream(x)));
+}
+
 void fused_add_rms_norm_splitk(torch::Tensor& out, torch::Tensor& residual, const torch::Tensor& partials,
                                const torch::Tensor& weight, double epsilon) {
   TORCH_CHECK(partials.dim() == 3 && partials.scalar_type() == at::kFloat && partials.is_contiguous());
@@ -775,6 +792,8 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_packed", torch::kCUDA, &skinny_linear_packed);
   amd.def("pack_weight(Tensor w) -> Tensor");
   amd.impl("pack_weight", torch::kCUDA, &pack_weight);
+  amd.def("add_layer_norm(Tensor! out, Tensor x, Tensor? y, Tensor weight, Tensor bias, float epsilon) -> ()");
+  amd.impl("add_layer_norm", torch::kCUDA, &add_layer_norm);
   amd.def("skinny_linear_packed_argmax(Tensor x, Tensor w_packed, int N, int K) -> Tensor");
   amd.impl("skinny_linear_packed_argmax", torch::kCUDA, &skinny_linear_packed_argmax);
   amd.def("stream_linear_packed(Tensor x, Tensor w_packed, Tensor? bias, int N, int K) -> Tensor");

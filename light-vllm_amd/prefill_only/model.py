@@ -3,10 +3,11 @@ light_vllm/encode_only/modelzoo/xlm_roberta.py (bge-m3's backbone, BASELINE conf
 (word + position + token type, LayerNorm), then per layer fused QKV projection -> bidirectional
 attention -> output projection -> add & LayerNorm -> GELU MLP -> add & LayerNorm.
 
-Attention is this package's HIP varlen kernel (AttentionType.ENCODER); LayerNorm and GELU are torch
-ops, as SURVEY F5 / §8f-2 state (the reference's encoder path has no custom norm or activation
-kernel either); the projections are library GEMMs (prompt batches are hundreds to thousands of rows).
+Attention is this package's HIP varlen kernel (AttentionType.ENCODER); the residual add and the LayerNorm
+behind it are one launch (`_C_amd.add_layer_norm`; the reference leaves both to torch),
+GELU is the torch op; the projections are library GEMMs (prompt batches are hundreds to thousands of rows).
 Weights are random-initialised: no checkpoint is available offline."""
+import os
 from dataclasses import dataclass
 from typing import List
 
@@ -14,6 +15,8 @@ import torch
 import torch.nn.functional as F
 
 from ..attention.prefill_only import AttentionType, PrefillOnlyHIPVarlenBackend
+
+_FUSED_LN = os.environ.get("LVLLM_FUSED_LAYER_NORM", "1") != "0"  # A/B switch
 
 
 @dataclass
@@ -88,12 +91,21 @@ class EncoderModel:
         # xlm_roberta.py: position ids start after the padding index
         x = (F.embedding(input_ids, self.word_emb) + F.embedding(positions + cfg.pad_token_id + 1, self.pos_emb)
              + self.type_emb[0])
-        x = F.layer_norm(x, (hid,), self.emb_ln[0], self.emb_ln[1], eps)
+        fused = x.is_cuda and hid % 8 == 0 and x.dtype in (torch.bfloat16, torch.float16) and _FUSED_LN
+
+        def add_ln(a, b, ln):  # LayerNorm(a + b), b optional
+            if fused:
+                out = torch.empty_like(a)
+                torch.ops._C_amd.add_layer_norm(out, a, b, ln[0], ln[1], eps)
+                return out
+            return F.layer_norm(a if b is None else a + b, (hid,), ln[0], ln[1], eps)
+
+        x = add_ln(x, None, self.emb_ln)
         for lw in self.layers:
             qkv = F.linear(x, lw.qkv_w, lw.qkv_b)
             q, k, v = qkv.split([hid, hid, hid], dim=-1)  # strided views of the fused projection
             a = self.attn.forward(q, k, v, None, attn_metadata, attn_type=AttentionType.ENCODER)
-            x = F.layer_norm(x + F.linear(a, lw.out_w, lw.out_b), (hid,), lw.attn_ln[0], lw.attn_ln[1], eps)
+            x = add_ln(x, F.linear(a, lw.out_w, lw.out_b), lw.attn_ln)
             h = F.gelu(F.linear(x, lw.fc1_w, lw.fc1_b))
-            x = F.layer_norm(x + F.linear(h, lw.fc2_w, lw.fc2_b), (hid,), lw.out_ln[0], lw.out_ln[1], eps)
+            x = add_ln(x, F.linear(h, lw.fc2_w, lw.fc2_b), lw.out_ln)
         return x

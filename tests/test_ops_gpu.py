@@ -525,3 +525,26 @@ def test_blocksparse_attention(ops, dtype, version, vert, local, bsz, step):
     # and it differs from dense attention (the mask really bites)
     dense = dense_attention_fp64(inp)
     assert float((out.double().cpu() - dense).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,hidden", [(1, 8), (7, 128), (33, 1024), (4, 4096), (3, 16384), (2, 1000)])
+@pytest.mark.parametrize("with_y", [True, False])
+def test_add_layer_norm_matches_torch(ops, dtype, T, hidden, with_y):
+    """LayerNorm(x + y) in one launch against torch's add + layer_norm evaluated in fp32 on the
+    same rounded sum; tolerance: output rounding + reduction order."""
+    g = torch.Generator(device=DEV).manual_seed(T * 31 + hidden)
+    x = (torch.randn(T, hidden, generator=g, device=DEV) * 2).to(dtype)
+    y = (torch.randn(T, hidden, generator=g, device=DEV) + 0.5).to(dtype) if with_y else None
+    w = (1 + 0.1 * torch.randn(hidden, generator=g, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(hidden, generator=g, device=DEV)).to(dtype)
+    out = torch.empty_like(x)
+    torch.ops._C_amd.add_layer_norm(out, x, y, w, b, 1e-5)
+    z = (x + y) if with_y else x  # the rounded sum, as torch materialises it
+    ref = torch.nn.functional.layer_norm(z.float(), (hidden,), w.float(), b.float(), 1e-5)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * max(1.0, ref.abs().max().item()), err
+    # in place
+    x2 = x.clone()
+    torch.ops._C_amd.add_layer_norm(x2, x2, y, w, b, 1e-5)
+    assert torch.equal(x2.view(torch.int16), out.view(torch.int16))
