@@ -257,6 +257,68 @@ __global__ void add_layer_norm_kernel(typename T::store_t* out, const typename T
   }
 }
 
+// The same for rows of at most 8 * kMaxCached * 64 = 2048 elements: one WAVE per row, four rows per
+// workgroup, wave-level reductions only -- no barrier between the three passes.
+template <typename T>
+__global__ void add_layer_norm_wave_kernel(typename T::store_t* out, const typename T::store_t* x,  // may alias
+                                           const typename T::store_t* __restrict__ y,  // nullable
+                                           const typename T::store_t* __restrict__ weight,
+                                           const typename T::store_t* __restrict__ bias, const float epsilon,
+                                           const int hidden_size, const int num_tokens) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t token = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (token >= num_tokens) return;
+  const int nvec = hidden_size / N;
+  const V* x_v = reinterpret_cast<const V*>(x) + token * nvec;
+  const V* y_v = y ? reinterpret_cast<const V*>(y) + token * nvec : nullptr;
+  V* out_v = reinterpret_cast<V*>(out) + token * nvec;
+  const V* w_v = reinterpret_cast<const V*>(weight);
+  const V* b_v = reinterpret_cast<const V*>(bias);
+  V cache[kMaxCached];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxCached; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nvec) {
+      V z = x_v[i];
+      if (y_v != nullptr) {
+        const V r = y_v[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) z.v[j] = T::from_float(T::to_float(z.v[j]) + T::to_float(r.v[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) sum += T::to_float(z.v[j]);
+      cache[k] = z;
+    }
+  }
+  const float mean = wave_sum(sum) / hidden_size;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxCached; ++k)
+    if (lane + 64 * k < nvec) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float d = T::to_float(cache[k].v[j]) - mean;
+        var += d * d;
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(var) / hidden_size + epsilon);
+#pragma unroll
+  for (int k = 0; k < kMaxCached; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nvec) {
+      const V w = w_v[i], b = b_v[i];
+      V o;
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        o.v[j] = T::from_float((T::to_float(cache[k].v[j]) - mean) * rstd * T::to_float(w.v[j]) + T::to_float(b.v[j]));
+      out_v[i] = o;
+    }
+  }
+}
+
 template <typename T, bool FUSED_ADD>
 static int launch_rms(void* out, void* res, const void* in, const void* weight, float eps,
                       int num_tokens, int hidden_size, hipStream_t stream) {
@@ -343,6 +405,20 @@ extern "C" int lvllm_add_layer_norm(void* out, const void* x, const void* y, con
   LV_CHECK((((uintptr_t)out | (uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0,
            "pointers must be 16-byte aligned");
   const int nvec = hidden_size / 8;
+  if (nvec <= 64 * lvllm::kMaxCached) {  // a wave per row
+    const int rows = 4;
+    const dim3 grid((num_tokens + rows - 1) / rows), block(64 * rows);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((lvllm::add_layer_norm_wave_kernel<lvllm::BF16>), grid, block, 0, (hipStream_t)stream,
+                         (uint16_t*)out, (const uint16_t*)x, (const uint16_t*)y, (const uint16_t*)weight,
+                         (const uint16_t*)bias, epsilon, hidden_size, num_tokens);
+    else
+      hipLaunchKernelGGL((lvllm::add_layer_norm_wave_kernel<lvllm::F16>), grid, block, 0, (hipStream_t)stream,
+                         (uint16_t*)out, (const uint16_t*)x, (const uint16_t*)y, (const uint16_t*)weight,
+                         (const uint16_t*)bias, epsilon, hidden_size, num_tokens);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
   int threads = ((nvec + 63) / 64) * 64;
   threads = threads > 1024 ? 1024 : threads;
   LV_CHECK(nvec <= lvllm::kMaxCached * threads, "hidden_size beyond 32768 is not supported");
