@@ -634,7 +634,8 @@ __global__ void skinny_argmax_reduce_kernel(int64_t* __restrict__ tokens, const 
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) tokens[m] = si[0];
+  // a row of NaNs beats no candidate: answer token 0 rather than an index no embedding table has
+  if (threadIdx.x == 0) tokens[m] = si[0] == 0x7fffffff ? 0 : si[0];
 }
 
 // out[m, n] = silu_and_mul of T(sum_s partial[s, m, n] + bias[n]) and T(sum_s partial[s, m, N/2 + n] + bias[N/2 + n]):
