@@ -174,6 +174,10 @@ int lvllm_rotary_embedding(const int64_t* positions, void* query, void* key,
 int lvllm_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
                        int dtype, void* stream);
 
+/* Exact (erf) GELU, elementwise: out = T(0.5 x (1 + erf(x / sqrt 2))) in fp32 (torch.nn.functional.gelu of the
+ * encoder models' MLP, a torch op in the reference).  16-bit types, numel % 8 == 0, out may alias x. */
+int lvllm_gelu(void* out, const void* x, int64_t numel, int dtype, void* stream);
+
 /* ---- extension (no counterpart operator in the reference): weight-streaming GEMM --------
  * Y[M,N] = X[M,K] . W[N,K]^T (+ bias[N]) for decode batches (M <= 64), bf16/f16, fp32
  * accumulate: the dense projections of light_vllm/backends/linear.py:134-139 (F.linear) at

@@ -82,3 +82,42 @@ extern "C" int lvllm_silu_and_mul(void* out, const void* input, int64_t num_toke
   LV_LAUNCH_CHECK();
   return 0;
 }
+
+// Exact (erf) GELU of the encoder models' MLP (xlm_roberta.py `hidden_act = "gelu"`; torch.nn.functional.gelu in
+// the reference): out = T(0.5 x (1 + erf(x / sqrt(2)))) in fp32, elementwise, out may alias x.
+namespace lvllm {
+template <typename T>
+__global__ void gelu_vec_kernel(typename T::store_t* out, const typename T::store_t* x, const int64_t num_chunks) {
+  using V = Vec16<T>;
+  constexpr int N = V::N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < num_chunks;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const V a = reinterpret_cast<const V*>(x)[idx];
+    V o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float f = T::to_float(a.v[j]);
+      o.v[j] = T::from_float(f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f)));
+    }
+    reinterpret_cast<V*>(out)[idx] = o;
+  }
+}
+}  // namespace lvllm
+
+extern "C" int lvllm_gelu(void* out, const void* x, int64_t numel, int dtype, void* stream) {
+  if (numel == 0) return 0;
+  LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit element types only");
+  LV_CHECK(numel % 8 == 0 && (((uintptr_t)out | (uintptr_t)x) & 15) == 0, "numel % 8 == 0 and 16-byte aligned pointers");
+  const int64_t chunks = numel / 8;
+  const int threads = 256;
+  int64_t want = (chunks + threads - 1) / threads;
+  const int grid = (int)(want < 16384 ? want : 16384);
+  if (dtype == LVLLM_BF16)
+    hipLaunchKernelGGL((lvllm::gelu_vec_kernel<lvllm::BF16>), dim3(grid), dim3(threads), 0, (hipStream_t)stream,
+                       (uint16_t*)out, (const uint16_t*)x, chunks);
+  else
+    hipLaunchKernelGGL((lvllm::gelu_vec_kernel<lvllm::F16>), dim3(grid), dim3(threads), 0, (hipStream_t)stream,
+                       (uint16_t*)out, (const uint16_t*)x, chunks);
+  LV_LAUNCH_CHECK();
+  return 0;
+}

@@ -390,6 +390,14 @@ torch::Tensor skinny_linear_packed_partials(const torch::Tensor& gate_up, const 
   return partials;
 }
 
+void gelu(torch::Tensor& out, const torch::Tensor& x) {
+  LV_CHECK_DEVICE(x);
+  TORCH_CHECK(x.is_contiguous() && out.is_contiguous() && out.sizes() == x.sizes() && out.scalar_type() == x.scalar_type(),
+              "gelu: contiguous out and x of the same shape and type");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  check(lvllm_gelu(out.data_ptr(), x.data_ptr(), x.numel(), dtype_code(x, "gelu"), current_stream(x)));
+}
+
 void add_layer_norm(torch::Tensor& out, const torch::Tensor& x, const std::optional<torch::Tensor>& y,
                     const torch::Tensor& weight, const torch::Tensor& bias, double epsilon) {
   LV_CHECK_DEVICE(x);
@@ -792,6 +800,8 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_packed", torch::kCUDA, &skinny_linear_packed);
   amd.def("pack_weight(Tensor w) -> Tensor");
   amd.impl("pack_weight", torch::kCUDA, &pack_weight);
+  amd.def("gelu(Tensor! out, Tensor x) -> ()");
+  amd.impl("gelu", torch::kCUDA, &gelu);
   amd.def("add_layer_norm(Tensor! out, Tensor x, Tensor? y, Tensor weight, Tensor bias, float epsilon) -> ()");
   amd.impl("add_layer_norm", torch::kCUDA, &add_layer_norm);
   amd.def("skinny_linear_packed_argmax(Tensor x, Tensor w_packed, int N, int K) -> Tensor");

@@ -5,7 +5,7 @@ attention -> output projection -> add & LayerNorm -> GELU MLP -> add & LayerNorm
 
 Attention is this package's HIP varlen kernel (AttentionType.ENCODER); the residual add and the LayerNorm
 behind it are one launch (`_C_amd.add_layer_norm`; the reference leaves both to torch),
-GELU is the torch op; the projections are library GEMMs (prompt batches are hundreds to thousands of rows).
+exact GELU is an in-place kernel of this package too; the projections are library GEMMs (prompt batches are hundreds to thousands of rows).
 Weights are random-initialised: no checkpoint is available offline."""
 import os
 from dataclasses import dataclass
@@ -106,6 +106,10 @@ class EncoderModel:
             q, k, v = qkv.split([hid, hid, hid], dim=-1)  # strided views of the fused projection
             a = self.attn.forward(q, k, v, None, attn_metadata, attn_type=AttentionType.ENCODER)
             x = add_ln(x, F.linear(a, lw.out_w, lw.out_b), lw.attn_ln)
-            h = F.gelu(F.linear(x, lw.fc1_w, lw.fc1_b))
+            h = F.linear(x, lw.fc1_w, lw.fc1_b)
+            if fused and h.numel() % 8 == 0:
+                torch.ops._C_amd.gelu(h, h)  # exact GELU in place
+            else:
+                h = F.gelu(h)
             x = add_ln(x, F.linear(h, lw.fc2_w, lw.fc2_b), lw.out_ln)
         return x

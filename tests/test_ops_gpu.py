@@ -548,3 +548,20 @@ def test_add_layer_norm_matches_torch(ops, dtype, T, hidden, with_y):
     x2 = x.clone()
     torch.ops._C_amd.add_layer_norm(x2, x2, y, w, b, 1e-5)
     assert torch.equal(x2.view(torch.int16), out.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gelu_matches_torch(ops, dtype):
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn(37, 4096, generator=g, device=DEV) * 3).to(dtype)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 20.0, -20.0, 65000.0 if dtype == torch.float16 else 3e38, -10.0],
+                            device=DEV).to(dtype)
+    want = torch.nn.functional.gelu(x)
+    out = torch.empty_like(x)
+    torch.ops._C_amd.gelu(out, x)
+    d = (out.float() - want.float()).abs()
+    ulp = torch.finfo(dtype).eps * want.float().abs().clamp_min(torch.finfo(dtype).tiny)
+    assert bool((d <= ulp).all()), float(d.max())  # the same fp32 formula: at most one rounding step apart
+    x2 = x.clone()
+    torch.ops._C_amd.gelu(x2, x2)
+    assert torch.equal(x2.view(torch.int16), out.view(torch.int16))
