@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--library-gemm", action="store_true", help="dense projections through hipBLASLt (F.linear)")
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-iters", type=int, default=96)
+    ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
     return ap.parse_args()
 
@@ -112,7 +112,7 @@ def kernel_leg(engine, B, iters, seq_len=None):
                 vp(stream))
         assert rc == 0, lib.lvllm_last_error()
 
-    for i in range(8):
+    for i in range(32):  # one untimed train
         launch(i, 1)
     torch.cuda.synchronize(dev)
     # HIP events on the launch stream around TRAINS of back-to-back launches, one layer's cache per
