@@ -194,9 +194,11 @@ int lvllm_skinny_gemm(void* y, const void* x, const void* w, const void* bias, i
 int lvllm_pack_weight(void* dst, const void* src, int N, int K, int dtype, void* stream);
 /* Greedy sampling fused into a projection (the lm_head of a decode step): tokens[m] = argmax over n of
  * (X . W^T)[m, n], compared after rounding to the element type (what torch.argmax of the projection's
- * output sees; ties go to the smaller n), without writing the [M, N] result.  M <= 64, K <= 4096 at
- * M <= 32 (K within one workgroup), packed weights, no bias.  tokens: int64 [M] on the device. */
-int64_t lvllm_skinny_gemm_argmax_workspace_bytes(int M);
+ * output sees; ties go to the smaller n), without writing the [M, N] result.  M <= 64, packed weights, no
+ * bias; when K is split over workgroups (K > 4096 at M <= 32, > 2048 above) the fp32 partials pass through
+ * the workspace and the arg-max runs inside the reduce pass.  tokens: int64 [M] on the device. */
+int64_t lvllm_skinny_gemm_argmax_workspace_bytes(int M);                    /* K within one workgroup */
+int64_t lvllm_skinny_gemm_argmax_workspace_bytes_ex(int M, int N, int K);   /* any shape of the envelope */
 int lvllm_skinny_gemm_argmax(int64_t* tokens, const void* x, const void* w_packed, int M, int N, int K,
                              int64_t ldx, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same product for 1 <= M <= 256 rows (meant for 65..256: a large decode batch, a prefill chunk):

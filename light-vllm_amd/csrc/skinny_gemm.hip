@@ -679,6 +679,56 @@ __global__ void skinny_gemm_reduce_swiglu_kernel(typename T::store_t* __restrict
   *reinterpret_cast<uint2*>(y + i) = ov;
 }
 
+// The arg-max epilogue for shapes whose K is split over workgroups: block (b, m) sums the fp32 partials of
+// its slice of row m, rounds to T as the reduce kernel would, and leaves one candidate; the kernel above
+// picks the winner over the 64 slices.
+template <typename T>
+__global__ void skinny_gemm_reduce_argmax_kernel(float* __restrict__ cand, const float* __restrict__ partial,
+                                                 const int M, const int N, const int ksplit) {
+  const int m = blockIdx.y, nb = gridDim.x;
+  const int per = ((N / 4 + nb - 1) / nb) * 4;  // columns of a slice, a multiple of 4
+  const int n_begin = blockIdx.x * per, n_end = n_begin + per < N ? n_begin + per : N;
+  const int64_t MN = (int64_t)M * N;
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int n = n_begin + 4 * threadIdx.x; n < n_end; n += 4 * blockDim.x) {
+    g_f32x4_t sum = *reinterpret_cast<const g_f32x4_t*>(partial + (int64_t)m * N + n);
+    for (int sp = 1; sp < ksplit; ++sp) {
+      const g_f32x4_t v = *reinterpret_cast<const g_f32x4_t*>(partial + (int64_t)sp * MN + (int64_t)m * N + n);
+      sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = T::to_float(T::from_float(sum[r]));
+      if (v > bv || (v == bv && n + r < bi)) {
+        bv = v;
+        bi = n + r;
+      }
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s2 = blockDim.x / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) {
+      const float v = sv[threadIdx.x + s2];
+      const int ix = si[threadIdx.x + s2];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = ix;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* dst = cand + ((int64_t)blockIdx.x * M + m) * 2;
+    dst[0] = sv[0];
+    reinterpret_cast<int*>(dst)[1] = si[0];
+  }
+}
+
 template <typename T, int MT, int KSTEPS, bool W8 = false>
 static void launch_skinny(void* y, float* partial, const void* x, const void* w, const void* bias, int M,
                           int N, int K, int64_t ldx, int steps_per_wave, int ntiles, int groups, int ksplit,
@@ -931,6 +981,10 @@ extern "C" int lvllm_pack_weight(void* dst, const void* src, int N, int K, int d
 // to the element type (what torch.argmax of the projection's output sees; ties: the smaller n), without
 // writing the [M, N] result.  workspace: lvllm_skinny_gemm_argmax_workspace_bytes(M) bytes.
 extern "C" int64_t lvllm_skinny_gemm_argmax_workspace_bytes(int M) { return (int64_t)1024 * (M > 0 ? M : 1) * 8; }
+// for any shape of the envelope: adds the fp32 partials when K is split over workgroups at this M
+extern "C" int64_t lvllm_skinny_gemm_argmax_workspace_bytes_ex(int M, int N, int K) {
+  return lvllm_skinny_gemm_argmax_workspace_bytes(M) + lvllm_skinny_gemm_workspace_bytes(M, N, K);
+}
 
 extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const void* bias, int M, int N,
                                     int K, int64_t ldx, int dtype, int packed, int act, int partial_out,
@@ -991,11 +1045,20 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
     else if (groups > ntiles / 2) groups = ntiles / 2;
   }
   void* const tokens_out = y;
-  if (act == 3) {  // arg-max epilogue: y is int64 [M]; the workgroups' candidates go through `workspace`
-    LV_CHECK(ksplit == 1 && !partial_out && bias == nullptr, "the arg-max epilogue needs K within one workgroup and no bias");
-    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)groups * M * 8,
-             "workspace too small (see lvllm_skinny_gemm_argmax_workspace_bytes)");
-    y = workspace;
+  const bool amax_reduce = act == 3 && ksplit > 1;  // K split over workgroups: arg-max inside a reduce pass
+  float* amax_cand = nullptr;
+  if (act == 3) {  // arg-max: y is int64 [M]; candidates (and, with split K, the fp32 partials) go through `workspace`
+    LV_CHECK(!partial_out && bias == nullptr, "the arg-max epilogue takes no bias and writes the tokens itself");
+    if (amax_reduce) {
+      LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4 + (int64_t)64 * M * 8,
+               "workspace too small (see lvllm_skinny_gemm_argmax_workspace_bytes_ex)");
+      amax_cand = (float*)((char*)workspace + (int64_t)ksplit * M * N * 4);
+      act = 0;  // plain tiles into the fp32 partials
+    } else {
+      LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)groups * M * 8,
+               "workspace too small (see lvllm_skinny_gemm_argmax_workspace_bytes)");
+      y = workspace;
+    }
   }
   if (ksplit_out) *ksplit_out = ksplit;
   LV_CHECK(!(partial_out && bias != nullptr), "partial_out leaves the bias to the caller");
@@ -1029,6 +1092,18 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
 #undef LV_SG_MT
 #undef LV_SG
   LV_LAUNCH_CHECK();
+  if (amax_reduce) {
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_argmax_kernel<BF16>), dim3(64, M), dim3(256), 0, s, amax_cand, partial, M,
+                         N, ksplit);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_argmax_kernel<F16>), dim3(64, M), dim3(256), 0, s, amax_cand, partial, M,
+                         N, ksplit);
+    hipLaunchKernelGGL(skinny_argmax_reduce_kernel, dim3(M), dim3(256), 0, s, (int64_t*)tokens_out,
+                       (const float*)amax_cand, 64, M);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
   if (act == 3) {
     hipLaunchKernelGGL(skinny_argmax_reduce_kernel, dim3(M), dim3(256), 0, s, (int64_t*)tokens_out, (const float*)y,
                        groups, M);

@@ -304,20 +304,15 @@ torch::Tensor skinny_linear_packed(const torch::Tensor& x, const torch::Tensor& 
   return y;
 }
 
-// lm_head + greedy sampling in one launch: int64 [M] = argmax(x . w^T) over the rounded values, no logits
-// tensor.  Falls back to the two ops when K is split over workgroups at this M.
+// lm_head + greedy sampling: int64 [M] = argmax(x . w^T) over the rounded values, no logits tensor (in the
+// projection's epilogue, or inside its split-K reduce pass when K is split over workgroups at this M).
 torch::Tensor skinny_linear_packed_argmax(const torch::Tensor& x, const torch::Tensor& w_packed, int64_t N, int64_t K) {
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && w_packed.numel() == N * K, "skinny_linear_packed_argmax: bad shapes");
   TORCH_CHECK(skinny_ok(x, w_packed, std::nullopt), "skinny_linear_packed_argmax: M <= 64 rows of bf16/f16 on the GPU only");
   const int64_t M = x.size(0);
-  if (lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K) > 0) {
-    auto logits = skinny_linear_impl(x, w_packed, std::nullopt, true, N, K);
-    TORCH_CHECK(logits.defined(), lvllm_last_error());
-    return at::argmax(logits, -1);
-  }
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
   auto tokens = torch::empty({M}, x.options().dtype(torch::kLong));
-  const int64_t ws_bytes = lvllm_skinny_gemm_argmax_workspace_bytes((int)M);
+  const int64_t ws_bytes = lvllm_skinny_gemm_argmax_workspace_bytes_ex((int)M, (int)N, (int)K);
   auto ws = torch::empty({ws_bytes / 4}, x.options().dtype(torch::kFloat));
   check(lvllm_skinny_gemm_argmax(tokens.data_ptr<int64_t>(), x.data_ptr(), w_packed.data_ptr(), (int)M, (int)N, (int)K,
                                  x.stride(0), dtype_code(x, "skinny_linear_packed_argmax"), ws.data_ptr(), ws_bytes,

@@ -161,7 +161,7 @@ def test_stream_linear_matches_fp32_matmul(ops, dtype, M, N, K, use_bias):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(32, 128256, 4096), (1, 512, 256), (17, 32000, 1024), (64, 4096, 2048),
-                                   (33, 1040, 8192), (5, 48, 64), (32, 16, 32)])
+                                   (33, 1040, 8192), (5, 48, 64), (32, 16, 32), (64, 128256, 4096), (40, 48, 8192)])
 @pytest.mark.parametrize("wgs", [256, 128, 9])
 def test_argmax_epilogue_gives_torch_argmax_of_the_projection(ops, dtype, M, N, K, wgs):
     """tokens = argmax of the rounded logits, ties to the smaller index -- also with many exact ties
