@@ -98,11 +98,11 @@ class PagedAttnMetadata:
     context_lens_tensor: Optional[torch.Tensor]
     block_tables: Optional[torch.Tensor]
     use_cuda_graph: bool = False
-    # host copies the prefill path walks without synchronising the device
-    query_lens: Optional[List[int]] = None
-    context_lens: Optional[List[int]] = None
     _cached_prefill_metadata: Optional["PagedAttnMetadata"] = None
     _cached_decode_metadata: Optional["PagedAttnMetadata"] = None
+    # (not in the reference) host copies the prefill path walks without synchronising the device
+    query_lens: Optional[List[int]] = None
+    context_lens: Optional[List[int]] = None
 
     @property
     def prefill_metadata(self) -> Optional["PagedAttnMetadata"]:
@@ -137,6 +137,12 @@ class PagedAttnMetadata:
                 query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
                 block_tables=self.block_tables[n:], use_cuda_graph=self.use_cuda_graph)
         return self._cached_decode_metadata
+
+    def asdict_zerocopy(self, skip_fields=None) -> Dict[str, Any]:
+        """dataclasses.asdict without the deep copy (abstract.py:105-117)."""
+        import dataclasses
+        skip = skip_fields or set()
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self) if f.name not in skip}
 
     def to(self, device, non_blocking=True):
         for k, v in list(self.__dict__.items()):
@@ -237,6 +243,11 @@ class PagedAttnMetadataBuilder:
             query_start_loc=query_start_loc, seq_start_loc=seq_start_loc,
             context_lens_tensor=cpu(self.context_lens, torch.int32), block_tables=block_tables,
             use_cuda_graph=False, query_lens=list(query_lens), context_lens=list(self.context_lens))
+
+    def __call__(self, *args, **kwargs):
+        """AttentionMetadataBuilder's abstract call hook (backends/attention/abstract.py:90-92); the
+        decoding workflow never calls it (flash_attn.py:367-368 leaves it empty too)."""
+        pass
 
 
 class PagedAttnImpl:
@@ -426,7 +437,11 @@ class PagedAttnBackend:
     """`DecodeOnlyAttentionBackend` of the paged KV layout (abstract.py:15-72)."""
 
     def __init__(self, attn_type=None):
-        self.attn_type = attn_type
+        self._attn_type = attn_type
+
+    @property
+    def attn_type(self):
+        return self._attn_type
 
     @staticmethod
     def get_name() -> str:

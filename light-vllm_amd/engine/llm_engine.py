@@ -57,6 +57,11 @@ class Worker:
                                   model_config.head_dim ** -0.5, model_config.num_key_value_heads,
                                   None, cache_config.sliding_window, cache_config.cache_dtype,
                                   decode_version=decode_version)
+        if self.device.type == "cuda":  # free memory before the weights (gpu_worker.py:78-80)
+            torch.cuda.empty_cache()
+            self.init_gpu_memory = torch.cuda.mem_get_info(self.device)[0]
+        else:
+            self.init_gpu_memory = 0
         self.model = DecoderModel(model_config, self.attn_impl, device, seed)
         self.attn_backend = attn_backend
         self.cache_engine: Optional[CacheEngine] = None
@@ -72,18 +77,103 @@ class Worker:
         self.capture_logits = False
         self.last_logits: Optional[torch.Tensor] = None
 
-    def determine_num_available_blocks(self) -> Tuple[int, int]:
-        """Blocks that fit beside the weights (gpu_worker.py:95-143): a profile forward with no
-        KV cache measures the activation peak; the rest of `gpu_memory_utilization` x total
-        memory is KV cache."""
-        torch.cuda.empty_cache()
-        torch.cuda.reset_peak_memory_stats(self.device)
-        free, total = torch.cuda.mem_get_info(self.device)
-        peak = total - free
-        block_bytes = CacheEngine.get_cache_block_size(self.cache_config, self.model_config)
-        num_gpu = int((total * self.cache_config.gpu_memory_utilization - peak) // block_bytes)
-        num_cpu = int(self.cache_config.swap_space_bytes // block_bytes)
+    # ---- KV-cache sizing (decoding/worker/gpu_worker.py:95-144, runner/model_runner.py:111-145) ----
+    @staticmethod
+    def profile_seq_lens(max_num_batched_tokens: int, max_num_seqs: int) -> List[int]:
+        """Prompt lengths of the profile run: the token budget dealt over `max_num_seqs` dummy prompts,
+        the remainder one token each to the first ones (model_runner.py:117-123)."""
+        return [max_num_batched_tokens // max_num_seqs + (i < max_num_batched_tokens % max_num_seqs)
+                for i in range(max_num_seqs)]
+
+    @staticmethod
+    def kv_blocks_from_profile(total: int, init_free: int, free_after_load: int, free_after_profile: int,
+                               gpu_memory_utilization: float, scheduling: str, block_bytes: int,
+                               swap_space_bytes: int, reserve_bytes: int = 0) -> Tuple[int, int]:
+        """The arithmetic of gpu_worker.py:100-141 on four memory readings: weights = init_free -
+        free_after_load; peak = init_free - free_after_profile; runtime = peak - weights; steps in flight on
+        their own streams ("async", "double_buffer") hold two sets of activations, so the runtime part counts
+        twice (:116-118).  `reserve_bytes` (not in the reference: HIP-graph pools and GEMM workspaces of the
+        captured steps) comes off the top."""
+        model_memory_usage = init_free - free_after_load
+        peak_memory = init_free - free_after_profile
+        runtime_memory = peak_memory - model_memory_usage
+        if scheduling in ("async", "double_buffer"):
+            peak_memory += runtime_memory
+        assert peak_memory > 0, ("Error in memory profiling. "
+                                 f"Initial free memory {init_free}, current free memory {free_after_profile}.")
+        num_gpu = int((total * gpu_memory_utilization - peak_memory - reserve_bytes) // block_bytes)
+        num_cpu = int(swap_space_bytes // block_bytes)
         return max(num_gpu, 0), max(num_cpu, 0)
+
+    @torch.inference_mode()
+    def profile_run(self, scheduler_config: SchedulerConfig) -> None:
+        """One forward of the largest prompt batch the scheduler can emit with no KV cache
+        (`kv_caches = [None] * L`, block tables None -> slot -1 everywhere, model_runner.py:111-145), then the
+        logits of one row per sequence through top-k / top-p filtering as the reference's profile sampling
+        parameters do (top_p 0.99, top_k vocab - 1: a full sort of [max_num_seqs, vocab])."""
+        from ..sampling import apply_top_k_top_p
+        from .scheduler import SequenceGroupMetadata
+        from .sequence import SequenceData
+        lens = self.profile_seq_lens(scheduler_config.max_num_batched_tokens, scheduler_config.max_num_seqs)
+        metas = []
+        for gid, n in enumerate(lens):
+            if n == 0:
+                continue
+            metas.append(SequenceGroupMetadata(request_id=str(gid), is_prompt=True,
+                                               seq_data={gid: SequenceData([0] * n)}, block_tables=None,
+                                               do_sample=True, token_chunk_size=n, computed_block_nums=[]))
+        builder = ModelInputBuilder(scheduler_config, self.cache_config, self.attn_backend,
+                                    self.cache_config.sliding_window)
+        mi = builder.prepare_model_input(metas).to(self.device)
+        hidden = self.model.forward(mi.input_tokens, mi.input_positions, None, mi.attn_metadata)
+        rows = torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)
+        logits = self.model.compute_logits(hidden[rows]).float()
+        n = logits.shape[0]
+        p = torch.full((n,), 0.99, device=self.device)
+        k = torch.full((n,), self.model_config.vocab_size - 1, device=self.device, dtype=torch.long)
+        torch.argmax(torch.softmax(apply_top_k_top_p(logits, p, k), dim=-1), dim=-1)
+        torch.cuda.synchronize(self.device)
+
+    def graph_reserve_bytes(self, scheduler_config: SchedulerConfig) -> int:
+        """Device memory the captured decode steps will take after the cache is sized (not in the
+        reference, which runs eager): per slot and captured batch size the activations of one step stay
+        allocated in the graph's private pool -- hidden / residual / normed rows, qkv, attention output,
+        SwiGLU output, the fp32 split-K partials of the o / down projections (<= 8 slabs) and the lm_head's
+        per-workgroup arg-max candidates.  An upper bound, counted for the largest batch (max_num_seqs rows,
+        capped at the 64 rows the decode path takes) twice over (a second captured size)."""
+        if not self.use_hip_graph:
+            return 0
+        cfg = self.model_config
+        rows = min(scheduler_config.max_num_seqs, 64)
+        e = 2
+        per_layer = rows * (4 * cfg.hidden_size + (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
+                            + cfg.num_attention_heads * cfg.head_dim + cfg.intermediate_size) * e
+        per_layer += 2 * 8 * rows * cfg.hidden_size * 4
+        step = per_layer * cfg.num_hidden_layers + rows * 4096 * 16 + (8 << 20)
+        return 2 * self.num_slots * step
+
+    def determine_num_available_blocks(self, scheduler_config: Optional[SchedulerConfig] = None) -> Tuple[int, int]:
+        """(num_gpu_blocks, num_cpu_blocks) as gpu_worker.py:95-144 computes them: weights = free memory
+        before the model minus free memory after; a profile forward with no KV cache; peak = everything the
+        caching allocator holds afterwards; the activation part doubled when two steps run on their own
+        streams; the rest of `gpu_memory_utilization` x total memory, less the graph reserve, is KV cache."""
+        scheduler_config = scheduler_config or SchedulerConfig()
+        torch.cuda.empty_cache()
+        free_after_load = torch.cuda.mem_get_info(self.device)[0]
+        self.profile_run(scheduler_config)
+        torch.cuda.synchronize(self.device)
+        free_after_profile, total = torch.cuda.mem_get_info(self.device)
+        block_bytes = CacheEngine.get_cache_block_size(self.cache_config, self.model_config)
+        out = self.kv_blocks_from_profile(total, self.init_gpu_memory, free_after_load, free_after_profile,
+                                          self.cache_config.gpu_memory_utilization, scheduler_config.scheduling,
+                                          block_bytes, self.cache_config.swap_space_bytes,
+                                          self.graph_reserve_bytes(scheduler_config))
+        self.profile = dict(total=total, init_free=self.init_gpu_memory, free_after_load=free_after_load,
+                            free_after_profile=free_after_profile, block_bytes=block_bytes)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
 
     def initialize_cache(self, num_gpu_blocks: int, num_cpu_blocks: int) -> None:
         self.cache_config.num_gpu_blocks = num_gpu_blocks
@@ -212,7 +302,7 @@ class LLMEngine:
         torch.ops._C_amd.set_tuning("gemm_workgroups", gemm_wgs)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
         if num_gpu is None:
-            num_gpu, auto_cpu = self.worker.determine_num_available_blocks()
+            num_gpu, auto_cpu = self.worker.determine_num_available_blocks(scheduler_config)
             num_cpu = auto_cpu if num_cpu is None else num_cpu
         self.worker.initialize_cache(num_gpu, num_cpu or 0)
         chunked = scheduler_config.chunked_prefill_enabled

@@ -9,7 +9,16 @@ oracle/_ref).  The fixtures are data: inputs and the reference's outputs.
                               (paged_attention_v1/v2, reshape_and_cache, copy_blocks, rms_norm,
                               fused_add_rms_norm, rotary_embedding, silu_and_mul)
 
-usage: python oracle/make_golden.py [block_manager] [ops]
+  input_builder.json          per-step input arrays (token ids, positions, slot mapping, block tables,
+                              sequence lengths, start offsets) the reference's ModelInputForGPUBuilder +
+                              flash-attn metadata builder produce for the seeded scenarios of
+                              tests/ib_driver.py
+
+  kv_sizing.json              num_gpu_blocks / num_cpu_blocks of the reference's
+                              Worker.determine_num_available_blocks on scripted memory readings, block
+                              bytes of CacheEngine.get_cache_block_size, prompt lengths of profile_run
+
+usage: python oracle/make_golden.py [block_manager] [ops] [prefill_only] [sampler] [input_builder] [kv_sizing]
 """
 import json
 import os
@@ -237,9 +246,106 @@ def make_sampler_vectors():
     print("sampler_front_half.npz")
 
 
+def make_input_builder_vectors():
+    """what the reference's own input builder (model_input_builder.py:105-378) and the metadata
+    builder of its wired attention backend (flash_attn.py:208-365, slot mapping backends/utils.py:31-75)
+    produce for every scenario of tests/ib_driver.py."""
+    import ib_driver
+    from oracle import ref_block_manager
+    ns = ref_block_manager.load_input_builder()
+    scenarios = ib_driver.make_scenarios()
+    n_tok = 0
+    for sc in scenarios:
+        mi = ref_block_manager.ref_build_model_input(ns, sc)
+        sc["expect"] = ib_driver.record(mi)
+        n_tok += len(sc["expect"]["input_tokens"])
+    path = os.path.join(GOLDEN, "input_builder.json")
+    with open(path, "w") as f:
+        json.dump({"seed": 1234, "scenarios": scenarios}, f, separators=(",", ":"))
+    print(f"{path}: {len(scenarios)} steps, {n_tok} tokens ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def make_kv_sizing_vectors():
+    """KV-cache sizing of the reference, run here on made-up memory readings.
+    `Worker.determine_num_available_blocks` (decoding/worker/gpu_worker.py:95-144) is arithmetic around
+    torch.cuda.mem_get_info(); it is called UNMODIFIED on a stand-in `self` while torch.cuda.mem_get_info /
+    empty_cache / synchronize are replaced by a scripted sequence of readings (no GPU in this container).
+    Also recorded: CacheEngine.get_cache_block_size (cache_engine.py:85-103) and the prompt lengths of
+    GPUModelRunner.profile_run (decoding/runner/model_runner.py:111-145)."""
+    import random
+    import types
+    import torch
+    from oracle import ref_block_manager
+    ref_block_manager.load_input_builder()
+    from light_vllm.decoding.runner import model_runner
+    from light_vllm.decoding.worker import cache_engine, gpu_worker
+    rng = random.Random(99)
+    GiB = 1 << 30
+    cases = []
+    real = (torch.cuda.mem_get_info, torch.cuda.empty_cache, torch.cuda.synchronize)
+    try:
+        torch.cuda.empty_cache = lambda: None
+        torch.cuda.synchronize = lambda *a, **k: None
+        for i in range(40):
+            total = rng.choice([288, 192, 80, 24]) * GiB - rng.randrange(0, GiB)
+            init_free = total - rng.randrange(0, 2 * GiB)
+            weights = rng.randrange(GiB // 4, 40 * GiB)
+            runtime = rng.randrange(GiB // 64, 6 * GiB)
+            util = rng.choice([0.9, 0.95, 0.5, 0.3])
+            scheduling = rng.choice(["sync", "simple_async", "async", "double_buffer"])
+            swap = rng.choice([4 * GiB, 0, GiB + 12345])
+            L, bs, kvh, d = rng.choice([(32, 16, 8, 128), (28, 16, 4, 128), (2, 32, 2, 64), (80, 16, 8, 128)])
+            cache_dtype, model_dtype = rng.choice([("auto", torch.bfloat16), ("auto", torch.float32),
+                                                   ("fp8", torch.bfloat16), ("fp8_e4m3", torch.float16)])
+            mc = types.SimpleNamespace(get_head_size=lambda d=d: d, get_num_kv_heads=lambda k=kvh: k,
+                                       get_num_attention_layers=lambda L=L: L, dtype=model_dtype)
+            cc = types.SimpleNamespace(block_size=bs, cache_dtype=cache_dtype, gpu_memory_utilization=util,
+                                       swap_space_bytes=swap)
+            block_bytes = cache_engine.CacheEngine.get_cache_block_size(cc, mc)
+            readings = iter([(init_free - weights, total), (init_free - weights - runtime, total)])
+            torch.cuda.mem_get_info = lambda *a, **k: next(readings)
+            me = types.SimpleNamespace(
+                init_gpu_memory=init_free, cache_config=cc, model_config=mc,
+                scheduler_config=types.SimpleNamespace(scheduling=scheduling),
+                model_runner=types.SimpleNamespace(profile_run=lambda: None),
+                get_cache_block_size_bytes=lambda b=block_bytes: b)
+            fn = gpu_worker.Worker.determine_num_available_blocks
+            num_gpu, num_cpu = fn(me)
+            cases.append(dict(total=total, init_free=init_free, free_after_load=init_free - weights,
+                              free_after_profile=init_free - weights - runtime, gpu_memory_utilization=util,
+                              scheduling=scheduling, swap_space_bytes=swap, num_layers=L, block_size=bs,
+                              num_kv_heads=kvh, head_size=d, cache_dtype=cache_dtype,
+                              model_dtype=str(model_dtype).split(".")[-1], block_bytes=block_bytes,
+                              num_gpu_blocks=num_gpu, num_cpu_blocks=num_cpu))
+    finally:
+        torch.cuda.mem_get_info, torch.cuda.empty_cache, torch.cuda.synchronize = real
+    # prompt lengths of the profile run
+    profiles = []
+    for tokens, seqs in [(8192, 256), (64, 64), (2048, 7), (100, 33), (512, 512), (4097, 256)]:
+        seen = {}
+        me = types.SimpleNamespace(
+            scheduler_config=types.SimpleNamespace(max_num_batched_tokens=tokens, max_num_seqs=seqs),
+            model_config=types.SimpleNamespace(get_num_layers=lambda: 3), vocab_size=1000,
+            prepare_model_input=lambda s, seen=seen: seen.setdefault("seqs", s) and types.SimpleNamespace(to=lambda d: None),
+            execute_model=lambda mi, kv, seen=seen: seen.setdefault("kv", kv))
+        real_sync = torch.cuda.synchronize
+        torch.cuda.synchronize = lambda *a, **k: None
+        try:
+            model_runner.GPUModelRunner.profile_run(me)
+        finally:
+            torch.cuda.synchronize = real_sync
+        lens = [list(m.seq_data.values())[0].get_len() for m in seen["seqs"]]
+        assert all(m.is_prompt and m.block_tables is None for m in seen["seqs"]) and seen["kv"] == [None] * 3
+        profiles.append(dict(max_num_batched_tokens=tokens, max_num_seqs=seqs, seq_lens=lens))
+    path = os.path.join(GOLDEN, "kv_sizing.json")
+    with open(path, "w") as f:
+        json.dump({"cases": cases, "profile_runs": profiles}, f, separators=(",", ":"))
+    print(f"{path}: {len(cases)} sizing cases, {len(profiles)} profile shapes")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only", "sampler"]
+    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only", "sampler", "input_builder", "kv_sizing"]
     if "block_manager" in what:
         make_block_manager_traces()
     if "ops" in what:
@@ -248,3 +354,7 @@ if __name__ == "__main__":
         make_prefill_only_vectors()
     if "sampler" in what:
         make_sampler_vectors()
+    if "input_builder" in what:
+        make_input_builder_vectors()
+    if "kv_sizing" in what:
+        make_kv_sizing_vectors()

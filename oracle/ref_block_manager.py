@@ -65,3 +65,54 @@ def load():
         BlockSpaceManagerV1=BlockSpaceManagerV1, BlockSpaceManagerV2=BlockSpaceManagerV2,
         Sequence=Sequence, SequenceGroup=SequenceGroup, SequenceStatus=SequenceStatus,
         Logprob=Logprob, TextOnlyInputs=TextOnlyInputs, AllocStatus=AllocStatus)
+
+
+def load_input_builder():
+    """The reference's per-step input builder and attention-plugin classes (SURVEY a13 / boundary B):
+    ModelInputForGPUBuilder (decoding/processor/model_input_builder.py:105-378), the flash backend's
+    metadata builder (decoding/backends/attention/backends/flash_attn.py:208-365), the slot-mapping
+    helpers (backends/utils.py:31-75), the abstract plugin classes (backends/abstract.py:15-166) and the
+    sequence metadata they consume.  flash_attn.py imports two callables from the third-party package
+    `vllm_flash_attn` (requirements.txt:32, absent here) at module level; neither is reached by the
+    metadata builder, so the harness registers an empty module of that name carrying the two names.
+    The module-level `pin_memory` flags (a GPU probe) are set to False: pinning needs a GPU."""
+    ns = load()
+    if "vllm_flash_attn" not in sys.modules:
+        m = types.ModuleType("vllm_flash_attn")
+        m.flash_attn_varlen_func = m.flash_attn_with_kvcache = None
+        sys.modules["vllm_flash_attn"] = m
+    from light_vllm.decoding.backends.attention.backends import abstract, flash_attn, utils
+    from light_vllm.decoding.processor import model_input_builder
+    from light_vllm.decoding.schema.sequence import SequenceData, SequenceGroupMetadata
+    flash_attn.pin_memory = False
+    model_input_builder.pin_memory = False
+    ns.abstract, ns.flash_attn, ns.attn_utils = abstract, flash_attn, utils
+    ns.model_input_builder = model_input_builder
+    ns.SequenceData, ns.SequenceGroupMetadata = SequenceData, SequenceGroupMetadata
+    return ns
+
+
+def ref_build_model_input(ns, scenario, attn_backend=None):
+    """Runs one tests/ib_driver.py scenario through the reference's ModelInputForGPUBuilder with the
+    given attention backend class (default: the reference's own flash backend) and returns its
+    DecodingModelInputForGPU."""
+    backend = attn_backend or ns.flash_attn.DecodeOnlyFlashAttentionBackend
+    window = scenario["sliding_window"]
+    model_config = types.SimpleNamespace(get_sliding_window=lambda: window)
+    scheduler_config = types.SimpleNamespace(use_v2_block_manager=scenario["use_v2_block_manager"],
+                                             chunked_prefill_enabled=scenario["chunked_prefill_enabled"])
+    cache_config = types.SimpleNamespace(block_size=scenario["block_size"])
+    builder = ns.model_input_builder.ModelInputForGPUBuilder(
+        model_config=model_config, scheduler_config=scheduler_config, cache_config=cache_config,
+        attn_backend=backend, device="cpu")
+    for g in scenario["groups"]:
+        seq_data = {}
+        for sid, prompt, out, comp in zip(g["seq_ids"], g["prompts"], g["outputs"], g["num_computed"]):
+            d = ns.SequenceData(prompt, out)
+            d.update_num_computed_tokens(comp)
+            seq_data[sid] = d
+        builder.add_seq_group(ns.SequenceGroupMetadata(
+            request_id=g["request_id"], is_prompt=g["is_prompt"], seq_data=seq_data, sampling_params=None,
+            block_tables=dict(zip(g["seq_ids"], g["block_tables"])), do_sample=g["do_sample"],
+            token_chunk_size=g["token_chunk_size"], computed_block_nums=g["computed_block_nums"] or None))
+    return builder.build()
