@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--scheduling", default="async", choices=["sync", "simple_async", "async"])
@@ -47,11 +47,16 @@ def parse():
                     help="non-default runs only: W8A8 projections (BASELINE config 5; the headline is bf16)")
     ap.add_argument("--on-the-fly", type=int, default=2,
                     help="steps in flight with async scheduling (reference default: 2)")
+    ap.add_argument("--num-scheduler-steps", type=int, default=8,
+                    help="model steps per engine step (multi-step decode: advance_step on the device between them); "
+                         "1 = one host round trip per model step.  The timed region holds exactly --steps MODEL steps: "
+                         "bursts use the largest divisor of --steps (and of --warmup) that is <= this")
     ap.add_argument("--attn-version", default="v2", choices=["v1", "v2", "auto"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--library-gemm", action="store_true", help="dense projections through hipBLASLt (F.linear)")
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-ops-baseline", action="store_true", help="no per-op GPU / CPU timings of the small operators")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
     return ap.parse_args()
@@ -108,8 +113,8 @@ def kernel_leg(engine, B, iters, seq_len=None):
                 ctypes.c_int64(q.stride(0)), ctypes.c_int64(kc.stride(0)), ctypes.c_int64(kc.stride(1)),
                 ctypes.c_int(dt), ctypes.c_int(1 if kv_fp8 else 0), ctypes.c_float(1.0), ctypes.c_float(1.0),
                 ctypes.c_int(0),
-                ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(64), ctypes.c_int(0), ctypes.c_int(phases),
-                vp(stream))
+                ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(64), ctypes.c_int(0),
+                ctypes.c_int64(kc.numel() * kc.element_size()), ctypes.c_int(phases), vp(stream))
         assert rc == 0, lib.lvllm_last_error()
 
     for i in range(32):  # one untimed train
@@ -135,7 +140,11 @@ def kernel_leg(engine, B, iters, seq_len=None):
     esz = 2
     algo_bytes = (2 * sum(lens) * KVH * D * (1 if kv_fp8 else esz) + 2 * len(seqs) * H * D * esz +
                   len(seqs) * ((max_len + BS - 1) // BS) * 4 + len(seqs) * 4)
-    return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P)
+    # shares per context the library picks for this launch (attention.hip: want = ceil(2048 / (8 * pairs)),
+    # pairs = seqs * kv heads * ceil(G / 16)), for the label of the roofline object
+    pairs = len(seqs) * KVH * ((H // KVH + 15) // 16)
+    nsplit = max(1, min(P, (2048 + 8 * pairs - 1) // (8 * pairs), ((max_len + 15) // 16) // 4))
+    return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P, nsplit=nsplit)
 
 
 def gemm_leg(engine, B):
@@ -223,8 +232,141 @@ def cpu_baseline_leg(engine, B, budget_s=20.0):
                        f"in {el:.1f} s; {per_call * 1e3:.2f} ms/call")
 
 
+def ops_baseline_leg(engine, B, iters=200, cpu_budget_s=1.5):
+    """The small operators of the path at the decode shapes (T = B tokens):
+    reshape_and_cache, rms_norm, fused_add_rms_norm, rotary_embedding, silu_and_mul -- GPU microseconds per launch
+    (HIP events around trains of back-to-back launches) and GB/s of the algorithmic bytes, next to the reference's
+    own csrc/cpu operator (oracle/_ref, kind "reference") or our C restatement (kind "port") on the host cores.
+    At T = 32 these kernels are launch-latency bound on the GPU (about 1 MiB of traffic each): the GB/s column
+    says how far from a bandwidth regime they are, not how good the kernel is."""
+    from oracle import oracle as port
+    from oracle import ref
+    from light_vllm_amd import _custom_ops as ops
+    cfg = engine.model_config
+    dev = engine.device
+    T, hid, inter = B, cfg.hidden_size, cfg.intermediate_size
+    H, KVH, D, BS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, engine.cache_config.block_size
+    dt = cfg.dtype
+    es = 2
+    use_ref = ref.load() and BS == 16 and dt == torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(T, hid, generator=g).to(dt)
+    res = torch.randn(T, hid, generator=g).to(dt)
+    w = (1 + 0.1 * torch.randn(hid, generator=g)).to(dt)
+    qkv = torch.randn(T, (H + 2 * KVH) * D, generator=g).to(dt)
+    pos = torch.randint(0, 1024, (T,), generator=g, dtype=torch.int64)
+    cache = engine.worker.model.cos_sin_cache.cpu()
+    gu = torch.randn(T, 2 * inter, generator=g).to(dt)
+    NB = 64
+    kc = torch.zeros(NB, KVH, D // 8, BS, 8, dtype=dt)
+    vc = torch.zeros(NB, KVH, D, BS, dtype=dt)
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+
+    def on(device):
+        d = {}
+        d["x"], d["res"], d["w"], d["qkv"], d["pos"], d["cache"], d["gu"], d["kc"], d["vc"], d["slots"] = (
+            t.to(device) for t in (x, res, w, qkv, pos, cache, gu, kc, vc, slots))
+        d["out"] = torch.empty_like(d["x"])
+        d["act"] = torch.empty(T, inter, dtype=dt, device=device)
+        d["q"] = d["qkv"][:, :H * D]
+        d["k"] = d["qkv"][:, H * D:(H + KVH) * D]
+        d["v"] = d["qkv"][:, (H + KVH) * D:]
+        return d
+
+    def calls(o, cache_ops, d):
+        return {
+            "reshape_and_cache": (lambda: cache_ops.reshape_and_cache(d["k"].view(T, KVH, D), d["v"].view(T, KVH, D), d["kc"],
+                                                                      d["vc"], d["slots"], "auto", 1.0, 1.0),
+                                  4 * T * KVH * D * es + 8 * T),
+            "rms_norm": (lambda: o.rms_norm(d["out"], d["x"], d["w"], 1e-5), (2 * T * hid + hid) * es),
+            "fused_add_rms_norm": (lambda: o.fused_add_rms_norm(d["x"], d["res"], d["w"], 1e-5), (4 * T * hid + hid) * es),
+            "rotary_embedding": (lambda: o.rotary_embedding(d["pos"], d["q"], d["k"], D, d["cache"], True),
+                                 2 * T * (H + KVH) * D * es + T * (8 + D * es)),
+            "silu_and_mul": (lambda: o.silu_and_mul(d["act"], d["gu"]), 3 * T * inter * es),
+        }
+
+    gd = on(dev)
+    gpu_calls = calls(ops, ops, gd)
+    cd = on("cpu")
+    if use_ref:
+        cpu_calls = calls(torch.ops._ref_C, torch.ops._ref_C_cache_ops, cd)
+        kind, cores = "reference", torch.get_num_threads()
+    else:
+        class _P:  # the port takes the same arguments
+            rms_norm = staticmethod(port.rms_norm)
+            fused_add_rms_norm = staticmethod(port.fused_add_rms_norm)
+            rotary_embedding = staticmethod(port.rotary_embedding)
+            silu_and_mul = staticmethod(port.silu_and_mul)
+            reshape_and_cache = staticmethod(lambda k_, v_, kc_, vc_, s_, *_: port.reshape_and_cache(k_, v_, kc_, vc_, s_))
+        cpu_calls = calls(_P, _P, cd)
+        kind, cores = "port", port.num_threads()
+    out = {}
+    for name, (fn, nbytes) in gpu_calls.items():
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        us = a.elapsed_time(b) * 1e3 / iters
+        cfn = cpu_calls[name][0]
+        cfn()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            cfn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > cpu_budget_s or n >= 2000:
+                break
+        cpu_us = el / n * 1e6
+        out[name] = {"algorithmic_bytes": nbytes, "gpu_us": round(us, 2), "gpu_GB/s": round(nbytes / us / 1e3, 1),
+                     "cpu_us": round(cpu_us, 1), "cpu_GB/s": round(nbytes / cpu_us / 1e3, 2), "cpu_calls": n}
+    return {"tokens": T, "dtype": "bf16", "cpu_kind": kind, "cpu_cores": int(cores),
+            "note": "eager launches back to back, launch gap included; T = batch rows of one decode step", "ops": out}
+
+
+def largest_divisor_at_most(n, k):
+    """Largest d <= k with n % d == 0 (>= 1)."""
+    for d in range(max(1, min(k, n)), 0, -1):
+        if n % d == 0:
+            return d
+    return 1
+
+
+def spawn_replicas(a):
+    """`python bench.py --gpus N` started as ONE plain process: start the N ranks itself, before anything in this
+    process touches a GPU -- a child `python -m torch.distributed.run` (the launcher the driver uses), whose exit
+    code becomes ours.  (Never an exec: this process stays the parent.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plan_steps(a):
+    """(burst for the timed region, burst for the warm-up, steps in flight): bursts divide the step counts so that
+    the timed region holds exactly --steps model steps; the pipeline cannot hold more engine steps than there are."""
+    k_req = max(1, a.num_scheduler_steps)
+    k = largest_divisor_at_most(a.steps, k_req)
+    kw = largest_divisor_at_most(a.warmup, k_req) if a.warmup > 0 else 1
+    on_the_fly = max(1, a.on_the_fly) if a.scheduling != "sync" else 1
+    on_the_fly = max(1, min(on_the_fly, a.steps // k))
+    return k, kw, on_the_fly
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_replicas(a))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
@@ -237,27 +379,26 @@ def main():
     # one process per GPU; RCCL is used for the barrier and the max-over-ranks clock only
     group = ReplicaGroup(device=torch.device(dev))
     rank, world = group.rank, group.world_size
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU"
 
     B, ctx = a.batch_size, a.context
-    on_the_fly = max(1, a.on_the_fly) if a.scheduling != "sync" else 1
-    # the timed region holds exactly K steps with an empty pipeline on both sides: it cannot keep more
-    # steps in flight than it has steps
-    on_the_fly = max(1, min(on_the_fly, a.steps))
+    k, kw, on_the_fly = plan_steps(a)
+    k_max = max(k, kw)
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
     cfg.fuse_decode_ops = not a.no_fusion
     cfg.quantization = a.quantization
     total_steps = a.steps + a.warmup
-    max_len = ctx + total_steps // on_the_fly + 8
+    max_len = ctx + total_steps // on_the_fly + 2 * k_max + 8
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
     blocks = n_req * ((max_len + bs - 1) // bs + 1) + 64
     engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype),
                        SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
                                        max_model_len=max_model_len, scheduling=a.scheduling,
-                                       max_num_on_the_fly=on_the_fly),
+                                       max_num_on_the_fly=on_the_fly, use_v2_block_manager=k_max > 1,
+                                       num_scheduler_steps=k_max),
                        device=dev, use_hip_graph=not a.no_graph,
                        decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
     engine.step_returns_outputs = False
@@ -269,26 +410,30 @@ def main():
     # set-up, not a step: every stream's HIP graph of the step is captured now, so that the timed region
     # replays graphs whatever W is (capture otherwise happens at a slot's first step)
     engine.capture_decode_graphs(B)
-    if a.scheduling != "sync":
-        def step(i, n):
-            # the last (on_the_fly - 1) calls only collect: the pipeline is empty on both sides
-            # of the timed region, which therefore holds exactly K steps
-            return engine.async_step(schedule_more=i < n - (on_the_fly - 1))
-    else:
-        def step(i, n):
-            return engine.step()
 
-    for i in range(a.warmup):
-        step(i, a.warmup)
-    assert engine.num_on_the_fly == 0
+    def run(n_model_steps, burst):
+        """n_model_steps model steps as n / burst engine steps (each `burst` model steps chained on the device);
+        the last (on_the_fly - 1) calls only collect, so the pipeline is empty on both sides of the region.
+        Returns the tokens produced."""
+        engine.scheduler_config.num_scheduler_steps = burst  # lookahead slots stay at k_max - 1
+        n = n_model_steps // burst
+        produced = 0
+        for i in range(n):
+            if a.scheduling != "sync":
+                outs = engine.async_step(schedule_more=i < n - (on_the_fly - 1))
+            else:
+                outs = engine.step()
+            produced += len(outs) * burst
+        assert engine.num_on_the_fly == 0
+        return produced
+
+    if a.warmup > 0:
+        run(a.warmup, kw)
     torch.cuda.synchronize(dev)
     group.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    tokens = 0
-    for i in range(a.steps):
-        tokens += len(step(i, a.steps))
-    assert engine.num_on_the_fly == 0
+    tokens = run(a.steps, k)
     torch.cuda.synchronize(dev)
     group.barrier()
     torch.cuda.synchronize(dev)
@@ -297,24 +442,26 @@ def main():
     elapsed = group.max(elapsed)            # slowest replica's clock
     value = group.sum(tokens) / elapsed      # whole-job tokens/s
 
-    k = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
+    kl = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
     gm = gemm_leg(engine, B) if B <= 64 else None
-    cpu = None
+    cpu = ops_base = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
         cpu = cpu_baseline_leg(engine, B)
-    ctx_now = sum(k["lens"]) / len(k["lens"])
+    if rank == 0 and world == 1 and not a.skip_ops_baseline:
+        ops_base = ops_baseline_leg(engine, B)
+    ctx_end = sum(s.get_len() for grp in engine.scheduler.running for s in grp.seqs) / max(1, len(engine.scheduler.running))
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the microarch guide prescribes for gfx950),
     # measured on the same kernel at seq=1024 and scaled by this launch's algorithmic bytes.
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_attn.json")) as f:
-            traffic = int(json.load(f)["traffic_over_algorithmic"] * k["algo_bytes"])
+            traffic = int(json.load(f)["traffic_over_algorithmic"] * kl["algo_bytes"])
     except (OSError, KeyError, ValueError):
         pass
     engine.shutdown()
     if rank == 0:
-        achieved = k["algo_bytes"] / k["avg_s"] / 1e9
+        achieved = kl["algo_bytes"] / kl["avg_s"] / 1e9
         line = {
             "metric": "decode tokens/sec Llama-3-8B bs=32 seq=1k; paged-attn HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -325,20 +472,28 @@ def main():
                      (" + fp8 (e4m3) KV cache" if a.kv_cache_dtype != "auto" else ""),
             "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
-                                   f"decode bs={B} per step, context {ctx}..{int(ctx_now)}, block_size 16, "
-                                   f"{a.scheduling} scheduling ({on_the_fly} batches in flight, one stream each), "
-                                   f"attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "
+                                   f"decode bs={B} per step, context {ctx} at the first step growing to {int(ctx_end)}, "
+                                   f"block_size 16, {a.scheduling} scheduling ({on_the_fly} batches in flight, one stream "
+                                   f"each), {k} model steps per engine step"
+                                   + (" (advance_step on the device between them)" if k > 1 else "") +
+                                   f", attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "
                                    "random-init weights, synthetic KV",
-                       "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)"},
-            "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 partition pass (paged_attn_mfma_kernel), "
-                                                      f"seq_lens = {ctx} for all {B} sequences",
+                       "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)",
+                       "num_scheduler_steps": k, "max_num_on_the_fly": on_the_fly},
+            "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 (paged_attn_mfma_kernel): "
+                                                      + ("single pass, nsplit = 1 -- the batch alone fills the GPU, no "
+                                                         "reduce launch, scratch untouched" if kl["nsplit"] == 1 else
+                                                         f"partition pass, {kl['nsplit']} shares per context") +
+                                                      f"; seq_lens = {ctx} for all {B} sequences",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_attn.json (2*FETCH_SIZE + WRITE_SIZE per launch, scaled)",
-                         "algorithmic_bytes_per_launch": k["algo_bytes"],
-                         "avg_launch_us": round(k["avg_s"] * 1e6, 2), "min_launch_us": round(k["min_s"] * 1e6, 2)},
+                         "algorithmic_bytes_per_launch": kl["algo_bytes"],
+                         "avg_launch_us": round(kl["avg_s"] * 1e6, 2), "min_launch_us": round(kl["min_s"] * 1e6, 2)},
             "cpu_baseline": cpu,
         }
+        if ops_base is not None:
+            line["ops_baseline"] = ops_base
         if gm is not None:  # the second HBM stream of the step: one layer's four projections
             g_ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
             gm_traffic = None

@@ -14,6 +14,13 @@
  *   - `stream` is a hipStream_t (void* here so that C callers need no HIP
  *     headers); kernels are launched asynchronously on it and never
  *     synchronise (graph-capture safe);
+ *   - kv_cache_bytes (attention, reshape_and_cache, the fused rope + cache write, prefill): the bytes the
+ *     caller owns behind key_cache (== behind value_cache).  The library cannot see allocations: with
+ *     kv_cache_bytes = 0 EXTENTS ARE UNCHECKED -- a block table entry, a slot or an element size that does
+ *     not belong to the caches makes the kernel read or write outside them (a GPU memory fault, not an
+ *     error code).  With the extent stated, block numbers are clamped to the blocks that fit
+ *     (kv_cache_bytes / (kv_block_stride * element bytes)) and slots beyond the last one are skipped like
+ *     padding slots: a mismatch then gives wrong numbers, never a fault.  The torch bindings always state it.
  *   - return value: 0 on success, non-zero on a rejected argument or HIP
  *     error; lvllm_last_error() returns the message (thread-local).  The torch
  *     binding turns non-zero into RuntimeError, which is what TORCH_CHECK does
@@ -50,7 +57,9 @@ const char* lvllm_last_error(void);
 /* build identification: "lvllm_hip gfx950 <abi version>" */
 const char* lvllm_version(void);
 /* Launch-shape knobs for the host's concurrency level (process-wide): "gemm_workgroups" (default
- * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4). */
+ * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4), "attn_splits" (paged_attention_v2:
+ * 0 = shares chosen per call, n >= 1 = n shares, -1 = the reference's 512-token partitions),
+ * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used). */
 int lvllm_set_tuning(const char* key, int value);
 
 /* ---- attention (replaces csrc/ops.h:8-27, attention_kernels.cu:808-997) --- */
@@ -70,18 +79,24 @@ int lvllm_paged_attention_v1(
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int dtype, int kv_dtype, float k_scale, float v_scale, int tp_rank,
     int blocksparse_local_blocks, int blocksparse_vert_stride,
-    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream);
+    int blocksparse_block_size, int blocksparse_head_sliding_step, int64_t kv_cache_bytes, void* stream);
 
 /* paged_attention_v2: as v1, split in partitions of 512 tokens
  * (attention_kernels.cu:850) and merged by a reduce pass.  Scratch, caller
  * allocated exactly as light_vllm/decoding/backends/attention/ops/paged_attn.py:156-166:
  *   tmp_out   [num_seqs,num_heads,max_num_partitions,head_size] (dtype)
  *   exp_sums, max_logits float32 [num_seqs,num_heads,max_num_partitions]
- * They are SCRATCH: the reference cuts every context at 512 tokens; this library cuts it
- * into n equal shares, n chosen per call to fill the GPU (n = 1 when the batch alone does:
- * then the scratch is not touched), n <= max_num_partitions.  Slot j of a (seq, head) row
- * holds share j's (max logit, exp sum, normalised partial output), the same quantities the
- * reference stores per partition (attention_kernels.cu:349-357,483-495). */
+ * They are SCRATCH, and what they hold after the call DIFFERS from the reference by default:
+ *   - the reference cuts every context at 512 tokens: slot j of a (seq, head) row holds partition j's
+ *     (max logit, exp sum, normalised partial output) (attention_kernels.cu:349-357,483-495);
+ *   - this library cuts a context into n EQUAL SHARES of whole 16-token tiles, n chosen per call to fill the
+ *     GPU and n <= max_num_partitions: slot j holds share j's quantities (same kind, other token ranges).
+ *     n = 1 when the batch alone fills the GPU (e.g. 32 sequences x 8 kv heads): ONE PASS writes `out`
+ *     directly, no reduce launch, and the scratch is NOT TOUCHED.
+ * `out` is the same attention result either way.  A caller that reads the scratch (none in the reference:
+ * paged_attn.py allocates and drops it) selects the reference's partitioning with
+ * lvllm_set_tuning("attn_splits", -1): 512-token partitions whatever the batch, every non-empty slot
+ * written, then the reduce pass -- tests/test_ops_gpu.py compares the three tensors with the oracle's. */
 int lvllm_paged_attention_v2(
     void* out, float* exp_sums, float* max_logits, void* tmp_out,
     const void* query, const void* key_cache, const void* value_cache,
@@ -92,7 +107,7 @@ int lvllm_paged_attention_v2(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, void* stream);
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, void* stream);
 
 /* The two passes of paged_attention_v2 individually, for profiling and for the benchmark's
  * per-kernel timing: phases = 1 runs only the partition pass (writes tmp_out / exp_sums /
@@ -107,7 +122,7 @@ int lvllm_paged_attention_v2_phases(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, int phases, void* stream);
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream);
 
 /* ---- cache ops (replaces csrc/cache.h:9-33, cache_kernels.cu) ------------- */
 
@@ -118,7 +133,7 @@ int lvllm_reshape_and_cache(
     const void* key, const void* value, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
     int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
-    int kv_dtype, float k_scale, float v_scale, void* stream);
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream);
 
 /* reshape_and_cache_flash: cache layout [num_blocks, block_size, num_heads,
  * head_size], block_stride = key_cache.stride(0) (cache_kernels.cu:206-247). */
@@ -243,7 +258,7 @@ int lvllm_rotary_embedding_and_cache_ex(
     int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
-    void* stream);
+    int64_t kv_cache_bytes, void* stream);
 
 /* Causal varlen attention of prompt chunks over the paged cache: prefill, chunked prefill and
  * prefix-cache hits.  Replaces the reference's third-party call
@@ -276,7 +291,7 @@ int lvllm_paged_prefill_attention_ex(
     int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
     int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
-    void* stream);
+    int64_t kv_cache_bytes, void* stream);
 
 /* Dense varlen attention without a KV cache: the encode-only / prefill-only path
  * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
@@ -303,6 +318,16 @@ int lvllm_advance_step(int num_seqs, int num_queries, int block_size, int64_t* i
                        const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
                        int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
                        void* stream);
+
+/* The same inside a multi-step decode (num_scheduler_steps > 1: k model steps replayed back to back, this
+ * call between them): token_log (nullable) also receives the sampled ids, row for row -- step j's tokens
+ * are kept for the host in row j of a [k, num_seqs] buffer -- and with skip_empty_rows != 0 a row whose
+ * seq_lens[i] <= 0 (padding of a captured batch) is left untouched. */
+int lvllm_advance_step_ex(int num_seqs, int num_queries, int block_size, int64_t* input_tokens,
+                          const int64_t* sampled_token_ids, int64_t* input_positions,
+                          int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables,
+                          int64_t block_tables_stride, int64_t* token_log, int skip_empty_rows,
+                          void* stream);
 
 /* convert_fp8: csrc/cache_kernels.cu:334-410, torch_bindings.cpp:261-264 ("only for testing" there).
  * to_fp8 != 0: dst (bytes) = fp8(float(src) / scale); else dst = T(float(fp8 src) * scale).  `dtype` is the

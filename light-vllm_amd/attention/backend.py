@@ -103,6 +103,9 @@ class PagedAttnMetadata:
     # (not in the reference) host copies the prefill path walks without synchronising the device
     query_lens: Optional[List[int]] = None
     context_lens: Optional[List[int]] = None
+    # (not in the reference) paged_attention_v2 scratch (exp_sums, max_logits, tmp_out) owned by the caller: a
+    # captured step brings its own, so that two graphs replaying on two streams never share one
+    decode_scratch: Optional[tuple] = None
 
     @property
     def prefill_metadata(self) -> Optional["PagedAttnMetadata"]:
@@ -135,7 +138,8 @@ class PagedAttnMetadata:
                 seq_lens_tensor=self.seq_lens_tensor[n:], max_query_len=None,
                 max_prefill_seq_len=0, max_decode_seq_len=self.max_decode_seq_len,
                 query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
-                block_tables=self.block_tables[n:], use_cuda_graph=self.use_cuda_graph)
+                block_tables=self.block_tables[n:], use_cuda_graph=self.use_cuda_graph,
+                decode_scratch=self.decode_scratch)
         return self._cached_decode_metadata
 
     def asdict_zerocopy(self, skip_fields=None) -> Dict[str, Any]:
@@ -280,6 +284,13 @@ class PagedAttnImpl:
         self.use_hip_prefill = True  # False: torch SDPA per sequence (kept for A/B tests)
         self._scratch: Dict[Tuple[int, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
+    def make_v2_scratch(self, num_seqs: int, max_seq_len: int, dtype, device):
+        """(exp_sums, max_logits, tmp_out) of paged_attn.py:156-166 for a caller that owns them."""
+        parts = (max_seq_len + 511) // 512
+        tmp = torch.empty(num_seqs, self.num_heads, parts, self.head_size, dtype=dtype, device=device)
+        es = torch.empty(num_seqs, self.num_heads, parts, dtype=torch.float32, device=device)
+        return es, torch.empty_like(es), tmp
+
     def _v2_scratch(self, num_seqs: int, max_seq_len: int, like: torch.Tensor):
         parts = (max_seq_len + 511) // 512
         # per stream: steps in flight on different streams (and the graphs captured on them)
@@ -321,7 +332,7 @@ class PagedAttnImpl:
             force = self.decode_version
             use_v1 = (force == "v1") if force else PagedAttention.use_v1(
                 dq.shape[0], self.num_kv_heads, self.num_heads, max_len)
-            scratch = None if use_v1 else self._v2_scratch(dq.shape[0], max_len, dq)
+            scratch = None if use_v1 else (decode_meta.decode_scratch or self._v2_scratch(dq.shape[0], max_len, dq))
             alibi = self.alibi_slopes
             if alibi is not None and alibi.device != dq.device:
                 alibi = self.alibi_slopes = alibi.to(dq.device)
@@ -345,7 +356,7 @@ class PagedAttnImpl:
         force = self.decode_version
         use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads,
                                                                       self.num_heads, max_len)
-        scratch = None if use_v1 else self._v2_scratch(dq.shape[0], max_len, dq)
+        scratch = None if use_v1 else (md.decode_scratch or self._v2_scratch(dq.shape[0], max_len, dq))
         alibi = self.alibi_slopes
         if alibi is not None and alibi.device != dq.device:
             alibi = self.alibi_slopes = alibi.to(dq.device)

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
   const int kvh = head / G;
   const int seq_len = p.seq_lens[seq];
   int t0 = 0, t1 = seq_len;
-  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1)) return;
+  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1, p.split_tiles)) return;
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const S* kc = (const S*)p.k_cache + (int64_t)kvh * p.kv_head_stride;
   const S* vc = (const S*)p.v_cache + (int64_t)kvh * p.kv_head_stride;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
     const int ce = min(t1, cs + chunk_tokens);
     float m_loc = -FLT_MAX;
     for (int tok = cs + threadIdx.x; tok < ce; tok += blockDim.x) {
-      const int64_t bn = block_table[tok / block_size];
+      const int64_t bn = min((uint32_t)block_table[tok / block_size], (uint32_t)p.max_block);
       const int off = tok % block_size;
       const S* kb = kc + bn * p.kv_block_stride + off * X;
       float dot = 0.f;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
     o1 *= alpha;
     __syncthreads();
     for (int tok = cs; tok < ce; ++tok) {
-      const int64_t bn = block_table[tok / block_size];
+      const int64_t bn = min((uint32_t)block_table[tok / block_size], (uint32_t)p.max_block);
       const int off = tok % block_size;
       const S* vb = vc + bn * p.kv_block_stride + off;
       const float pr = logits[tok - cs];
@@ -121,14 +121,14 @@ __global__ void paged_attn_v2_reduce_generic_kernel(typename T::store_t* __restr
                                                     const typename T::store_t* __restrict__ tmp_out,
                                                     const int32_t* __restrict__ seq_lens,
                                                     const int max_num_partitions,
-                                                    const int num_splits,
+                                                    const int num_splits, const int split_tiles,
                                                     const int num_rows, const int num_heads,
                                                     const int D) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= num_rows) return;
   const int lane = threadIdx.x & 63;
   const int seq_len = seq_lens[row / num_heads];
-  const int np = num_nonempty_splits(seq_len, num_splits);
+  const int np = num_nonempty_splits(seq_len, num_splits, split_tiles);
   typename T::store_t* o = out + (int64_t)row * D;
   const typename T::store_t* tmp = tmp_out + (int64_t)row * max_num_partitions * D;
   if (np <= 1) {  // one share: copy through (attention_kernels.cu:582-594); empty context: zeros
@@ -189,6 +189,22 @@ static int check_common(int num_seqs, int num_heads, int head_size, int num_kv_h
   return 0;
 }
 
+// Largest block number the caches can hold, from the extent the caller states (kv_cache_bytes = bytes
+// of the key cache == bytes of the value cache; 0: not stated, numbers are taken as they come).  Also
+// rejects strides that put a kv head outside its block.
+static int cache_extent(int64_t kv_cache_bytes, int64_t kv_block_stride, int64_t kv_head_stride,
+                        int num_kv_heads, int head_size, int block_size, int elem_bytes, int* max_block) {
+  LV_CHECK(kv_block_stride > 0 && kv_head_stride > 0, "kv cache strides must be positive");
+  LV_CHECK((int64_t)(num_kv_heads - 1) * kv_head_stride + (int64_t)head_size * block_size <= kv_block_stride,
+           "kv_head_stride / kv_block_stride do not describe [num_blocks, num_kv_heads, head_size * block_size]");
+  *max_block = 0x7fffffff;
+  if (kv_cache_bytes <= 0) return 0;
+  const int64_t nb = kv_cache_bytes / (kv_block_stride * elem_bytes);
+  LV_CHECK(nb >= 1, "kv_cache_bytes is smaller than one block of the stated strides and element size");
+  *max_block = (int)(nb - 1 < 0x7fffffff ? nb - 1 : 0x7fffffff);
+  return 0;
+}
+
 }  // namespace lvllm
 
 using namespace lvllm;
@@ -201,9 +217,13 @@ extern "C" int lvllm_paged_attention_v1(
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int dtype, int kv_dtype, float k_scale, float v_scale, int tp_rank,
     int blocksparse_local_blocks, int blocksparse_vert_stride,
-    int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream) {
+    int blocksparse_block_size, int blocksparse_head_sliding_step, int64_t kv_cache_bytes, void* stream) {
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
+    return rc;
+  int max_block = 0;
+  if (int rc = cache_extent(kv_cache_bytes, kv_block_stride, kv_head_stride, num_kv_heads, head_size, block_size,
+                            kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : (dtype == LVLLM_F32 ? 4 : 2), &max_block))
     return rc;
   const bool bsparse = blocksparse_vert_stride > 1;
   LV_CHECK(!bsparse || (blocksparse_block_size > 0 && blocksparse_block_size % block_size == 0),
@@ -224,7 +244,7 @@ extern "C" int lvllm_paged_attention_v1(
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = 1;
-  p.partitioned = 0; p.scale = scale;
+  p.partitioned = 0; p.scale = scale; p.max_block = max_block;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
   p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   hipStream_t s = (hipStream_t)stream;
@@ -257,9 +277,13 @@ extern "C" int lvllm_paged_attention_v2_phases(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, int phases, void* stream) {
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream) {
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
+    return rc;
+  int max_block = 0;
+  if (int rc = cache_extent(kv_cache_bytes, kv_block_stride, kv_head_stride, num_kv_heads, head_size, block_size,
+                            kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : (dtype == LVLLM_F32 ? 4 : 2), &max_block))
     return rc;
   const bool bsparse = blocksparse_vert_stride > 1;
   LV_CHECK(!bsparse || (blocksparse_block_size > 0 && blocksparse_block_size % block_size == 0),
@@ -284,7 +308,7 @@ extern "C" int lvllm_paged_attention_v2_phases(
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi_slopes = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.max_num_blocks_per_seq = max_num_blocks_per_seq; p.max_num_partitions = max_num_partitions;
-  p.partitioned = 1; p.scale = scale;
+  p.partitioned = 1; p.scale = scale; p.max_block = max_block;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
   p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   hipStream_t s = (hipStream_t)stream;
@@ -307,12 +331,18 @@ extern "C" int lvllm_paged_attention_v2_phases(
   int nsplit = (int)(want < max_num_partitions ? want : max_num_partitions);
   if (nsplit > max_tiles / 4) nsplit = max_tiles / 4;
   if (nsplit < 1) nsplit = 1;
-  if (const char* e = getenv("LVLLM_ATTN_SPLITS")) {  // experiments / tests
-    const int forced = atoi(e);
-    if (forced >= 1) nsplit = forced < max_num_partitions ? forced : max_num_partitions;
+  // lvllm_set_tuning("attn_splits", n): n >= 1 forces n shares (tests, experiments); -1 = the reference's
+  // partitioning, 512 tokens per share whatever the batch, so that the scratch slots hold exactly what
+  // attention_kernels.cu:349-357,483-495 stores in them
+  const int forced = tuning().attn_splits;
+  if (forced >= 1) nsplit = forced < max_num_partitions ? forced : max_num_partitions;
+  if (forced == -1) {
+    nsplit = (max_seq_len + kPartitionSize - 1) / kPartitionSize;
+    if (nsplit < 1) nsplit = 1;
+    p.split_tiles = kPartitionSize / 16;
   }
   p.num_splits = nsplit;
-  if (nsplit == 1) {  // single share: write `out` directly, nothing to reduce
+  if (nsplit == 1 && forced != -1) {  // single share: write `out` directly, nothing to reduce
     p.out = out;
     p.partitioned = 0;
     p.max_num_partitions = 1;
@@ -330,7 +360,7 @@ extern "C" int lvllm_paged_attention_v2_phases(
     if (rc) return rc;
     LV_LAUNCH_CHECK();
   }
-  if (nsplit == 1) return 0;
+  if (nsplit == 1 && forced != -1) return 0;
   if (!(phases & 2)) return 0;
 
   const int num_rows = num_seqs * num_heads;
@@ -340,7 +370,7 @@ extern "C" int lvllm_paged_attention_v2_phases(
   hipLaunchKernelGGL((paged_attn_v2_reduce_generic_kernel<T_>), dim3(grid), dim3(waves_per_block * 64), \
                      0, s, (typename T_::store_t*)out, exp_sums, max_logits,                        \
                      (const typename T_::store_t*)tmp_out, seq_lens, max_num_partitions, nsplit,    \
-                     num_rows, num_heads, head_size)
+                     p.split_tiles, num_rows, num_heads, head_size)
   if (dtype == LVLLM_BF16) LV_REDUCE(BF16);
   else if (dtype == LVLLM_F16) LV_REDUCE(F16);
   else LV_REDUCE(F32);
@@ -359,11 +389,11 @@ extern "C" int lvllm_paged_attention_v2(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, void* stream) {
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, void* stream) {
   return lvllm_paged_attention_v2_phases(
       out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
       head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
       max_num_blocks_per_seq, max_num_partitions, alibi_slopes, q_stride, kv_block_stride,
       kv_head_stride, dtype, kv_dtype, k_scale, v_scale, tp_rank, blocksparse_local_blocks,
-      blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step, 3, stream);
+      blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step, kv_cache_bytes, 3, stream);
 }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 
   int t0 = 0, t1 = seq_len;
   // empty share: nothing to do (the reference's early exit, attention_kernels.cu:116-119)
-  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1)) return;
+  if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1, p.split_tiles)) return;
   const int ntiles = (t1 - t0 + 15) >> 4;
   const int tile0 = t0 >> 4;
   // tiles of this wave: lt = wave + j * NWAVES, j = 0 .. nmy-1
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   const int last_block = p.max_num_blocks_per_seq - 1;
   auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
     const int blk = ((tile0 + wave + j * NWAVES) << 4) / BS;
-    return block_table[min(blk, last_block)];
+    return (int)min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
   };
 
   // running softmax state of this wave: column c of lanes (g, c) is head head0 + c

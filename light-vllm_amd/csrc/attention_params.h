@@ -20,6 +20,11 @@ struct AttnParams {
   int num_heads, num_kv_heads, max_num_blocks_per_seq, max_num_partitions;
   int partitioned;  // 0: whole sequence per workgroup (v1)
   int num_splits;   // partitioned: every sequence is cut into at most this many equal shares
+  int split_tiles;  // > 0: shares are exactly this many 16-token tiles (32 = the reference's 512-token
+                    // partitions, attention_kernels.cu:850), not equal parts of the context
+  int max_block;    // block numbers read from the table are clamped to [0, max_block] (unsigned min):
+                    // a wrong table or a cache handed over with the wrong element size then reads
+                    // wrong blocks of the allocation instead of faulting (kv_cache_bytes of the C-ABI)
   float scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;  // kv strides in cache elements
   // kv_cache_dtype "fp8": the caches hold OCP e4m3fn bytes, layouts with x = 16; a dequantised
@@ -48,9 +53,10 @@ __host__ __device__ inline bool blocksparse_attended(const AttnParams& p, int to
 // whole 16-token tiles: tokens [t0, t1).  Returns false for an empty share.  Both passes of
 // paged_attention_v2 (and every kernel variant) use this one function, so the partition
 // pass and the reduce pass always agree on which scratch slots hold data.
-__host__ __device__ inline bool split_range(int seq_len, int num_splits, int s, int* t0, int* t1) {
+__host__ __device__ inline bool split_range(int seq_len, int num_splits, int s, int* t0, int* t1,
+                                            int split_tiles = 0) {
   const int ntiles = (seq_len + 15) >> 4;
-  const int chunk = (ntiles + num_splits - 1) / num_splits;  // tiles per share
+  const int chunk = split_tiles > 0 ? split_tiles : (ntiles + num_splits - 1) / num_splits;  // tiles per share
   const int first = s * chunk;
   if (first >= ntiles) return false;
   *t0 = first << 4;
@@ -58,10 +64,10 @@ __host__ __device__ inline bool split_range(int seq_len, int num_splits, int s, 
   *t1 = end < seq_len ? end : seq_len;
   return true;
 }
-__host__ __device__ inline int num_nonempty_splits(int seq_len, int num_splits) {
+__host__ __device__ inline int num_nonempty_splits(int seq_len, int num_splits, int split_tiles = 0) {
   const int ntiles = (seq_len + 15) >> 4;
   if (ntiles == 0) return 0;
-  const int chunk = (ntiles + num_splits - 1) / num_splits;
+  const int chunk = split_tiles > 0 ? split_tiles : (ntiles + num_splits - 1) / num_splits;
   return (ntiles + chunk - 1) / chunk;
 }
 

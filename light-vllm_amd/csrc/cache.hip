@@ -23,7 +23,7 @@ __global__ void reshape_and_cache_kernel(
     const int64_t* __restrict__ slot_mapping, const int64_t num_chunks,
     const int chunks_per_head, const int num_heads, const int head_size,
     const int block_size, const int64_t key_stride, const int64_t value_stride,
-    const bool vec_ok) {
+    const bool vec_ok, const int64_t num_slots) {
   using vec_t = uint4;
   static_assert(sizeof(store_t) * X == 16, "chunk must be 16 bytes");
   const int chunks_per_token = chunks_per_head * num_heads;
@@ -32,7 +32,7 @@ __global__ void reshape_and_cache_kernel(
     const int64_t token = idx / chunks_per_token;
     const int rem = (int)(idx - token * chunks_per_token);
     const int64_t slot = slot_mapping[token];
-    if (slot < 0) continue;  // padding token
+    if (slot < 0 || slot >= num_slots) continue;  // padding token / a slot outside the stated extent
     const int head = rem / chunks_per_head;
     const int x_idx = rem - head * chunks_per_head;
     const int64_t block_idx = slot / block_size;
@@ -76,7 +76,7 @@ __global__ void reshape_and_cache_fp8_kernel(
     uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
     const int64_t* __restrict__ slot_mapping, const int64_t num_chunks, const int chunks_per_head,
     const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
-    const int64_t value_stride, const float k_scale, const float v_scale) {
+    const int64_t value_stride, const float k_scale, const float v_scale, const int64_t num_slots) {
   const int chunks_per_token = chunks_per_head * num_heads;
   auto quant4 = [](float a, float b, float c, float d, float scale) { return fp8_kv_quant4(a, b, c, d, scale); };
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < num_chunks;
@@ -84,7 +84,7 @@ __global__ void reshape_and_cache_fp8_kernel(
     const int64_t token = idx / chunks_per_token;
     const int rem = (int)(idx - token * chunks_per_token);
     const int64_t slot = slot_mapping[token];
-    if (slot < 0) continue;  // padding token
+    if (slot < 0 || slot >= num_slots) continue;  // padding token / outside the stated extent
     const int head = rem / chunks_per_head;
     const int x_idx = rem - head * chunks_per_head;
     const int64_t block_idx = slot / block_size;
@@ -192,6 +192,95 @@ __global__ void copy_blocks_kernel(const void* const* __restrict__ key_cache_ptr
   }
 }
 
+// 16-bit caches, many tokens (prompt chunks): one workgroup per (tile of 64 consecutive tokens, kv head).
+// The per-chunk kernel above writes a V chunk as 8 two-byte stores to 8 rows of [.., D, BS] and a K chunk as
+// a 16-byte piece of a 256-byte-strided row: at 8 192 tokens it moved 1.2 TB/s (profiles/r01_bench_kernel_
+// stats_v6.csv).  Here both tiles go through LDS and leave in DESTINATION order:
+//   K  [tok][d8] -> [d8][tok]: lane (d8, tok) stores 16 bytes; consecutive tokens of a sequence sit in
+//      consecutive slots, so 16 lanes cover one 256-byte row of the block;
+//   V  [tok][d] -> [d][tok]: the tile's tokens are cut into groups of consecutive slots inside one aligned
+//      8-slot window (group = at most 8 tokens, found with two ballots); a thread owns (d, group) and stores
+//      its 8 elements as ONE 16-byte piece when the group is full, element by element at sequence edges.
+// slot_mapping is arbitrary (slot < 0 or >= num_slots: skipped): every address comes from the token's own
+// slot, only the speed depends on the slots being consecutive.  Pure byte movement: bit-exact.
+constexpr int kTileTokens = 64;
+__global__ __launch_bounds__(256) void reshape_and_cache_tile_kernel(
+    const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, uint16_t* __restrict__ key_cache,
+    uint16_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, const int num_tokens,
+    const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
+    const int64_t value_stride, const int64_t num_slots) {
+  constexpr int TT = kTileTokens;
+  constexpr int KROW = TT + 1;  // 16-byte units per d8 row of the K tile (odd: conflict-free transposed writes)
+  constexpr int VROW = TT + 2;  // elements per d row of the V tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cph = head_size >> 3;
+  int64_t* slots = reinterpret_cast<int64_t*>(smem);                 // [TT]
+  int* grp = reinterpret_cast<int*>(slots + TT);                     // [TT] start | len << 8
+  int* ngrp = grp + TT;                                              // [4]
+  uint4* kt = reinterpret_cast<uint4*>(ngrp + 4);                    // [cph][KROW]
+  uint16_t* vt = reinterpret_cast<uint16_t*>(kt + cph * KROW);       // [head_size][VROW]
+  const int tok0 = blockIdx.x * TT, head = blockIdx.y;
+  const int nt = min(TT, num_tokens - tok0);
+  const int tid = threadIdx.x;
+
+  if (tid < TT) {  // wave 0: slots of the tile and the groups of its V stores
+    int64_t s = tid < nt ? slot_mapping[tok0 + tid] : -1;
+    if (s >= num_slots) s = -1;
+    slots[tid] = s;
+    const int64_t prev = (int64_t)__shfl_up((long long)s, 1);
+    const bool valid = s >= 0;
+    const bool first = valid && (tid == 0 || prev < 0 || s != prev + 1 || (s & 7) == 0);
+    const uint64_t F = __ballot(first), V = __ballot(valid);
+    if (first) {
+      const uint64_t above = tid == 63 ? 0 : (F | ~V) >> (tid + 1);  // next group start or gap
+      const int len = above ? __builtin_ctzll(above) + 1 : 64 - tid;
+      grp[__builtin_popcountll(F & ((1ull << tid) - 1))] = tid | (len << 8);
+    }
+    if (tid == 0) ngrp[0] = __builtin_popcountll(F);
+  }
+  // source rows -> LDS, read in source order (whole 2*head_size-byte rows)
+  for (int i = tid; i < nt * cph; i += 256) {
+    const int tok = i / cph, j = i - tok * cph;
+    const uint4 kv = *reinterpret_cast<const uint4*>(key + (int64_t)(tok0 + tok) * key_stride + head * head_size + j * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(value + (int64_t)(tok0 + tok) * value_stride + head * head_size + j * 8);
+    kt[j * KROW + tok] = kv;
+    const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[(j * 8 + e) * VROW + tok] = ve[e];
+  }
+  __syncthreads();
+  // K out: lane (d8, tok), tok fastest
+  for (int i = tid; i < nt * cph; i += 256) {
+    const int j = i / nt, tok = i - j * nt;
+    const int64_t s = slots[tok];
+    if (s < 0) continue;
+    const int64_t b = s / block_size;
+    const int o = (int)(s - b * block_size);
+    uint16_t* dst = key_cache + (((b * num_heads + head) * cph + j) * (int64_t)block_size + o) * 8;
+    *reinterpret_cast<uint4*>(dst) = kt[j * KROW + tok];
+  }
+  // V out: thread (d, group), group fastest
+  const int ng = ngrp[0];
+  for (int i = tid; i < head_size * ng; i += 256) {
+    const int d = i / ng, gi = i - d * ng;
+    const int g = grp[gi];
+    const int ts = g & 0xff, len = g >> 8;
+    const int64_t s = slots[ts];
+    const int64_t b = s / block_size;
+    const int o = (int)(s - b * block_size);
+    uint16_t* dst = value_cache + ((b * num_heads + head) * (int64_t)head_size + d) * block_size + o;
+    const uint16_t* src = vt + d * VROW + ts;
+    if (len == 8) {
+      alignas(16) uint16_t e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = src[k];
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(e);
+    } else {
+      for (int k = 0; k < len; ++k) dst[k] = src[k];
+    }
+  }
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace lvllm
@@ -202,10 +291,16 @@ extern "C" int lvllm_reshape_and_cache(
     const void* key, const void* value, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
     int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
-    int kv_dtype, float k_scale, float v_scale, void* stream) {
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
   LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
   if (num_tokens == 0) return 0;
   const int esize = dtype == LVLLM_F32 ? 4 : 2;
+  LV_CHECK(num_heads > 0 && head_size > 0 && block_size > 0, "num_heads, head_size, block_size must be positive");
+  // slots the caches hold, from the extent the caller states (0: not stated): a slot beyond it is skipped
+  // like a padding slot instead of being written outside the allocation
+  const int64_t cache_esize = kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : esize;
+  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_heads * head_size * cache_esize)
+                                               : INT64_MAX;
   LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
   if (kv_dtype == LVLLM_KV_FP8_E4M3) {
     LV_CHECK(x == 16, "fp8 key_cache.size(4) must be 16");
@@ -220,7 +315,7 @@ extern "C" int lvllm_reshape_and_cache(
         (reshape_and_cache_fp8_kernel<scalar_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
         (const typename scalar_t::store_t*)key, (const typename scalar_t::store_t*)value, (uint8_t*)key_cache,
         (uint8_t*)value_cache, slot_mapping, num_chunks, chunks_per_head, num_heads, head_size, block_size,
-        key_stride, value_stride, k_scale, v_scale));
+        key_stride, value_stride, k_scale, v_scale, num_slots));
     LV_LAUNCH_CHECK();
     return 0;
   }
@@ -235,16 +330,28 @@ extern "C" int lvllm_reshape_and_cache(
   const int64_t want = (num_chunks + threads - 1) / threads;
   const int grid = (int)(want < 4096 ? want : 4096);
   hipStream_t s = (hipStream_t)stream;
+  if (esize == 2 && vec_ok && aligned16(value_cache) && num_tokens >= tuning().cache_tile_min_tokens &&
+      head_size <= 256 && block_size % 8 == 0 && num_heads <= 65535) {
+    const int cph = head_size / 8;
+    const size_t smem = kTileTokens * 8 + kTileTokens * 4 + 16 + (size_t)cph * (kTileTokens + 1) * 16 +
+                        (size_t)head_size * (kTileTokens + 2) * 2;
+    hipLaunchKernelGGL(reshape_and_cache_tile_kernel, dim3((num_tokens + kTileTokens - 1) / kTileTokens, num_heads),
+                       dim3(256), smem, s, (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
+                       (uint16_t*)value_cache, slot_mapping, num_tokens, num_heads, head_size, block_size,
+                       key_stride, value_stride, num_slots);
+    LV_LAUNCH_CHECK();
+    return 0;
+  }
   if (esize == 2) {
     hipLaunchKernelGGL((reshape_and_cache_kernel<uint16_t, 8>), dim3(grid), dim3(threads), 0, s,
                        (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
                        (uint16_t*)value_cache, slot_mapping, num_chunks, chunks_per_head,
-                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok);
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots);
   } else {
     hipLaunchKernelGGL((reshape_and_cache_kernel<float, 4>), dim3(grid), dim3(threads), 0, s,
                        (const float*)key, (const float*)value, (float*)key_cache,
                        (float*)value_cache, slot_mapping, num_chunks, chunks_per_head,
-                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok);
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots);
   }
   LV_LAUNCH_CHECK();
   return 0;

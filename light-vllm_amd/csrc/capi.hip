@@ -13,6 +13,7 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_GEMM_CUS_WIDE")) v.gemm_workgroups_wide = atoi(e);
     if (const char* e = getenv("LVLLM_GEMM_WIDE_MIN_TILES")) v.gemm_wide_min_tiles = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
+    if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     return v;
   }();
@@ -36,6 +37,12 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
+  } else if (k == "attn_splits") {
+    LV_CHECK(value >= -1, "attn_splits must be -1 (512-token partitions), 0 (automatic) or a share count");
+    lvllm::tuning().attn_splits = value;
+  } else if (k == "cache_tile_min_tokens") {
+    LV_CHECK(value >= 1, "cache_tile_min_tokens must be positive");
+    lvllm::tuning().cache_tile_min_tokens = value;
   } else if (k == "prefill_lds") {
     lvllm::tuning().prefill_lds = value != 0;
   } else {
@@ -44,7 +51,7 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   return 0;
 }
 
-extern "C" const char* lvllm_version(void) { return "lvllm_hip gfx950 abi1"; }
+extern "C" const char* lvllm_version(void) { return "lvllm_hip gfx950 abi2"; }
 
 // csrc/cuda_utils_kernels.cu:1-35 of the reference: thin wrappers over the
 // runtime's attribute query, kept so that torch.ops._C_cuda_utils.* exists.

@@ -21,12 +21,16 @@ void set_error(const std::string& msg);
 //                    that keeps two steps in flight on two streams sets 128: each GEMM then
 //                    leaves half the CUs to the other stream's kernel, +10 % tokens/s measured)
 //   attn_waves       waves per workgroup of the long-context decode attention (8 or 4)
+//   attn_splits      how paged_attention_v2 cuts contexts: 0 automatic, n >= 1 forced, -1 the reference's
+//                    512-token partitions (scratch contents then equal the reference's)
 //   prefill_lds      1 | 0, see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
   int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
   int gemm_wide_min_tiles = 1024;  // 1024: gate_up and lm_head of an 8B model; 4096: lm_head only
   int attn_waves = 8;
+  int attn_splits = 0;  // paged_attention_v2: 0 = shares chosen per call; n >= 1 = n shares; -1 = 512-token partitions
+  int cache_tile_min_tokens = 64;  // reshape_and_cache: >= this many tokens take the LDS-tiled kernel
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
 };
 Tuning& tuning();

@@ -108,7 +108,8 @@ __global__ void rotary_embedding_and_cache_kernel(
     const typename T::store_t* __restrict__ cos_sin_cache, void* __restrict__ key_cache_v,
     void* __restrict__ value_cache_v, const int64_t* __restrict__ slot_mapping,
     const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
-    const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale) {
+    const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale,
+    const int64_t num_slots) {
   LVLLM_TRACE_BEGIN();
   using S = typename T::store_t;
   using V = Vec16<T>;
@@ -117,23 +118,24 @@ __global__ void rotary_embedding_and_cache_kernel(
   S* value_cache = reinterpret_cast<S*>(value_cache_v);
   uint8_t* key_cache8 = reinterpret_cast<uint8_t*>(key_cache_v);
   uint8_t* value_cache8 = reinterpret_cast<uint8_t*>(value_cache_v);
-  // 8 elements of head `head` starting at d (a multiple of 8) -> their 8 bytes inside the x = 16 chunk
-  auto store_k8 = [&](const V& x, const int head, const int d) {
-    uint8_t* dst = key_cache8 + (((slot_mapping[blockIdx.x] / block_size) * num_kv_heads + head) * (head_size / 16) + d / 16) *
-                                    (int64_t)block_size * 16 + (slot_mapping[blockIdx.x] % block_size) * 16 + (d % 16);
-    uint2 q;
-    q.x = fp8_kv_quant4(T::to_float(x.v[0]), T::to_float(x.v[1]), T::to_float(x.v[2]), T::to_float(x.v[3]), k_scale);
-    q.y = fp8_kv_quant4(T::to_float(x.v[4]), T::to_float(x.v[5]), T::to_float(x.v[6]), T::to_float(x.v[7]), k_scale);
-    *reinterpret_cast<uint2*>(dst) = q;
-  };
   const int64_t token = blockIdx.x;
   const int64_t pos = positions[token];
   const int embed_dim = head_size / 2;
   const S* cos_ptr = cos_sin_cache + pos * head_size;
   const S* sin_ptr = cos_ptr + embed_dim;
-  const int64_t slot = slot_mapping[token];
+  int64_t slot = slot_mapping[token];
+  if (slot >= num_slots) slot = -1;  // outside the extent the caller stated: skipped like a padding slot
   const int64_t block_idx = slot >= 0 ? slot / block_size : 0;
   const int64_t block_off = slot >= 0 ? slot % block_size : 0;
+  // 8 elements of head `head` starting at d (a multiple of 8) -> their 8 bytes inside the x = 16 chunk
+  auto store_k8 = [&](const V& x, const int head, const int d) {
+    uint8_t* dst = key_cache8 + ((block_idx * num_kv_heads + head) * (head_size / 16) + d / 16) *
+                                    (int64_t)block_size * 16 + block_off * 16 + (d % 16);
+    uint2 q;
+    q.x = fp8_kv_quant4(T::to_float(x.v[0]), T::to_float(x.v[1]), T::to_float(x.v[2]), T::to_float(x.v[3]), k_scale);
+    q.y = fp8_kv_quant4(T::to_float(x.v[4]), T::to_float(x.v[5]), T::to_float(x.v[6]), T::to_float(x.v[7]), k_scale);
+    *reinterpret_cast<uint2*>(dst) = q;
+  };
   const int cph = head_size / N;  // 16-byte chunks per head
   // work items: rotation units of q heads, then of k heads, then v chunks
   const int rot_units = IS_NEOX ? embed_dim / N : cph;  // per head
@@ -261,7 +263,7 @@ extern "C" int lvllm_rotary_embedding_and_cache(
   return lvllm_rotary_embedding_and_cache_ex(positions, query, key, value, num_tokens, num_heads, num_kv_heads,
                                              head_size, rot_dim, query_stride, key_stride, value_stride,
                                              cos_sin_cache, is_neox, key_cache, value_cache, slot_mapping,
-                                             block_size, dtype, LVLLM_KV_AUTO, 1.f, 1.f, stream);
+                                             block_size, dtype, LVLLM_KV_AUTO, 1.f, 1.f, 0, stream);
 }
 
 extern "C" int lvllm_rotary_embedding_and_cache_ex(
@@ -269,7 +271,7 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
     int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
-    void* stream) {
+    int64_t kv_cache_bytes, void* stream) {
   if (num_tokens == 0) return 0;
   LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
   const bool kv8 = kv_dtype == LVLLM_KV_FP8_E4M3;
@@ -283,6 +285,8 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
     set_error("lvllm_rotary_embedding_and_cache: arguments outside the fused kernel's envelope");
     return 3;
   }
+  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_kv_heads * head_size * (kv8 ? 1 : 2))
+                                               : INT64_MAX;
   const int units = (num_heads + num_kv_heads) * (is_neox ? head_size / 16 : head_size / 8) + num_kv_heads * head_size / 8;
   int threads = ((units + 63) / 64) * 64;
   threads = threads > 512 ? 512 : threads;
@@ -290,7 +294,8 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
   hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_, KV8_>), dim3(num_tokens), dim3(threads), 0, \
                      (hipStream_t)stream, positions, (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value, \
                      (const uint16_t*)cos_sin_cache, key_cache, value_cache, slot_mapping, query_stride,      \
-                     key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size, k_scale, v_scale)
+                     key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size, k_scale, v_scale, \
+                     num_slots)
 #define LV_RC_N(T_)                                   \
   do {                                                \
     if (is_neox) {                                    \

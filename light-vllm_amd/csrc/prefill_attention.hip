@@ -17,7 +17,7 @@ extern "C" int lvllm_paged_prefill_attention(
                                           num_kv_heads, scale, block_tables, seq_lens, query_start_loc,
                                           max_query_len, block_size, max_num_blocks_per_seq, alibi_slopes, causal,
                                           sliding_window, softcap, q_stride, out_stride, kv_block_stride,
-                                          kv_head_stride, dtype, kv_dtype, 1.f, 1.f, stream);
+                                          kv_head_stride, dtype, kv_dtype, 1.f, 1.f, 0, stream);
 }
 
 extern "C" int lvllm_paged_prefill_attention_ex(
@@ -27,7 +27,7 @@ extern "C" int lvllm_paged_prefill_attention_ex(
     int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
     int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
-    void* stream) {
+    int64_t kv_cache_bytes, void* stream) {
   LV_CHECK(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
            "num_heads must be a positive multiple of num_kv_heads");
   LV_CHECK(dtype == LVLLM_F16 || dtype == LVLLM_BF16, "dtype must be float16 or bfloat16");
@@ -51,6 +51,13 @@ extern "C" int lvllm_paged_prefill_attention_ex(
   p.alibi_slopes = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.max_num_blocks_per_seq = max_num_blocks_per_seq;
+  p.max_block = 0x7fffffff;
+  if (kv_cache_bytes > 0) {  // the extent the caller states: block numbers beyond it are clamped, not followed
+    LV_CHECK(kv_block_stride > 0, "kv_block_stride must be positive");
+    const int64_t nb = kv_cache_bytes / (kv_block_stride * (kv_dtype == LVLLM_KV_AUTO ? 2 : 1));
+    LV_CHECK(nb >= 1, "kv_cache_bytes is smaller than one block of the stated strides and element size");
+    p.max_block = (int)(nb - 1 < 0x7fffffff ? nb - 1 : 0x7fffffff);
+  }
   p.causal = causal ? 1 : 0;
   p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
   p.sliding_window = sliding_window; p.scale = scale; p.softcap = softcap;

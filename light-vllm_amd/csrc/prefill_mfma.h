@@ -55,6 +55,7 @@ struct PrefillParams {
   const int32_t* query_start_loc;  // [num_seqs + 1]
   const float* alibi_slopes;       // [num_heads] or null
   int num_heads, num_kv_heads, max_num_blocks_per_seq;
+  int max_block;       // block numbers from the table are clamped to [0, max_block] (attention_params.h)
   int gp_shift;        // log2 of the GQA group size rounded up to a power of two (<= 16)
   int causal;          // 1: bottom-right aligned causal mask; 0: every query sees the whole context
   int sliding_window;  // <= 0: none; else a query at position p sees keys p-w+1 .. p (causal only)
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
   const const_i32_ptr block_table_c = (const_i32_ptr)(uintptr_t)block_table;
   auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
     const int blk = min(((tile0 + j) << 4) / BS, last_block);
-    return arithmetic_blocks ? first_block + blk : block_table_c[blk];
+    return arithmetic_blocks ? first_block + blk : (int)min((uint32_t)block_table_c[blk], (uint32_t)p.max_block);
   };
 
   float m_run[NB], l_run[NB];

@@ -17,9 +17,13 @@ __global__ void advance_step_kernel(const int num_queries, const int block_size,
                                     int64_t* __restrict__ input_positions, int32_t* __restrict__ seq_lens,
                                     int64_t* __restrict__ slot_mapping,
                                     const int32_t* __restrict__ block_tables,
-                                    const int64_t block_tables_stride) {
+                                    const int64_t block_tables_stride, int64_t* __restrict__ token_log,
+                                    const int skip_empty_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num_queries) return;
+  if (token_log != nullptr) token_log[i] = sampled_token_ids[i];
+  // a captured step runs at its padded batch size: rows without a sequence (length 0, slot -1) stay that way
+  if (skip_empty_rows && seq_lens[i] <= 0) return;
   input_tokens[i] = sampled_token_ids[i];
   const int next_len = seq_lens[i] + 1;
   const int pos = next_len - 1;
@@ -35,12 +39,22 @@ extern "C" int lvllm_advance_step(int num_seqs, int num_queries, int block_size,
                                   const int64_t* sampled_token_ids, int64_t* input_positions,
                                   int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables,
                                   int64_t block_tables_stride, void* stream) {
+  return lvllm_advance_step_ex(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids, input_positions,
+                               seq_lens, slot_mapping, block_tables, block_tables_stride, nullptr, 0, stream);
+}
+
+extern "C" int lvllm_advance_step_ex(int num_seqs, int num_queries, int block_size, int64_t* input_tokens,
+                                     const int64_t* sampled_token_ids, int64_t* input_positions,
+                                     int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables,
+                                     int64_t block_tables_stride, int64_t* token_log, int skip_empty_rows,
+                                     void* stream) {
   LV_CHECK(num_seqs >= 0 && num_queries >= 0 && num_queries <= num_seqs, "need 0 <= num_queries <= num_seqs");
   LV_CHECK(block_size > 0, "block_size must be positive");
   if (num_queries == 0) return 0;
   hipLaunchKernelGGL(lvllm::advance_step_kernel, dim3((num_queries + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, num_queries, block_size, input_tokens, sampled_token_ids,
-                     input_positions, seq_lens, slot_mapping, block_tables, block_tables_stride);
+                     input_positions, seq_lens, slot_mapping, block_tables, block_tables_stride, token_log,
+                     skip_empty_rows);
   LV_LAUNCH_CHECK();
   return 0;
 }

@@ -46,6 +46,16 @@ void check_cache_dtype(const torch::Tensor& cache, const torch::Tensor& like, in
   }
 }
 
+// Bytes the kernels may touch behind key_cache.data_ptr() / value_cache.data_ptr() (the smaller of the two):
+// the C-ABI clamps block numbers / skips slots beyond it instead of following them out of the allocation.
+int64_t cache_extent_bytes(const torch::Tensor& key_cache, const torch::Tensor& value_cache) {
+  auto bytes = [](const torch::Tensor& t) {
+    return t.dim() == 0 ? (int64_t)0 : t.size(0) * t.stride(0) * (int64_t)t.element_size();
+  };
+  const int64_t k = bytes(key_cache), v = bytes(value_cache);
+  return k < v ? k : v;
+}
+
 void* current_stream(const torch::Tensor& t) {
   return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
@@ -77,7 +87,8 @@ void paged_attention_v1(torch::Tensor& out, torch::Tensor& query, torch::Tensor&
       (int)block_tables.size(1), alibi, query.stride(0), key_cache.stride(0), key_cache.stride(1),
       dtype_code(query, "paged_attention_v1"), kv_dtype_code(kv_cache_dtype), (float)k_scale,
       (float)v_scale, (int)tp_rank, (int)blocksparse_local_blocks, (int)blocksparse_vert_stride,
-      (int)blocksparse_block_size, (int)blocksparse_head_sliding_step, current_stream(query)));
+      (int)blocksparse_block_size, (int)blocksparse_head_sliding_step, cache_extent_bytes(key_cache, value_cache),
+      current_stream(query)));
 }
 
 void paged_attention_v2(torch::Tensor& out, torch::Tensor& exp_sums, torch::Tensor& max_logits,
@@ -110,7 +121,7 @@ void paged_attention_v2(torch::Tensor& out, torch::Tensor& exp_sums, torch::Tens
       key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_attention_v2"),
       kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale, (int)tp_rank,
       (int)blocksparse_local_blocks, (int)blocksparse_vert_stride, (int)blocksparse_block_size,
-      (int)blocksparse_head_sliding_step, current_stream(query)));
+      (int)blocksparse_head_sliding_step, cache_extent_bytes(key_cache, value_cache), current_stream(query)));
 }
 
 void silu_and_mul(torch::Tensor& out, torch::Tensor& input) {
@@ -240,7 +251,7 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value, torch::Tensor& 
                                 (int)key_cache.size(3), (int)key_cache.size(4), key.stride(0),
                                 value.stride(0), dtype_code(key, "reshape_and_cache"),
                                 kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale,
-                                current_stream(key)));
+                                cache_extent_bytes(key_cache, value_cache), current_stream(key)));
 }
 
 void reshape_and_cache_flash(torch::Tensor& key, torch::Tensor& value, torch::Tensor& key_cache,
@@ -442,7 +453,7 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
       (int)cos_sin_cache.size(1), query.stride(-2), key.stride(-2), value.stride(-2), cos_sin_cache.data_ptr(),
       is_neox ? 1 : 0, key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
       (int)value_cache.size(3), dtype_code(query, "rotary_embedding_and_cache"), kv_code, (float)k_scale,
-      (float)v_scale, current_stream(query));
+      (float)v_scale, cache_extent_bytes(key_cache, value_cache), current_stream(query));
   if (rc == 3) return false;
   check(rc);
   return true;
@@ -479,7 +490,8 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
       (int)block_tables.size(1), alibi, causal ? 1 : 0, (int)sliding_window, (float)softcap, query.stride(0),
       out.stride(0),
       key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_prefill_attention"),
-      kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale, current_stream(query)));
+      kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale, cache_extent_bytes(key_cache, value_cache),
+      current_stream(query)));
 }
 
 int64_t varlen_attention_workspace_bytes(int64_t num_tokens, int64_t num_seqs, int64_t max_seq_len,
@@ -537,6 +549,29 @@ void advance_step(int64_t num_seqs, int64_t num_queries, int64_t block_size, tor
                            seq_lens.data_ptr<int32_t>(), slot_mapping.data_ptr<int64_t>(),
                            block_tables.data_ptr<int32_t>(), block_tables.stride(0),
                            current_stream(sampled_token_ids)));
+}
+
+// Extension: advance_step between the model steps of a multi-step decode.  Same arithmetic; the sampled
+// ids are also logged into `token_log` and rows of the padded batch without a sequence are skipped.
+void advance_step_logged(int64_t block_size, torch::Tensor& input_tokens, const torch::Tensor& sampled_token_ids,
+                         torch::Tensor& input_positions, torch::Tensor& seq_lens, torch::Tensor& slot_mapping,
+                         const torch::Tensor& block_tables, torch::Tensor& token_log) {
+  const int64_t n = input_tokens.size(0);
+  TORCH_CHECK(input_tokens.is_cuda() && input_tokens.scalar_type() == at::kLong && input_tokens.is_contiguous());
+  TORCH_CHECK(sampled_token_ids.scalar_type() == at::kLong && sampled_token_ids.is_contiguous() &&
+              sampled_token_ids.numel() >= n);
+  TORCH_CHECK(input_positions.scalar_type() == at::kLong && input_positions.is_contiguous() && input_positions.size(0) == n);
+  TORCH_CHECK(seq_lens.scalar_type() == at::kInt && seq_lens.is_contiguous() && seq_lens.size(0) == n);
+  TORCH_CHECK(slot_mapping.scalar_type() == at::kLong && slot_mapping.is_contiguous() && slot_mapping.size(0) == n);
+  TORCH_CHECK(block_tables.scalar_type() == at::kInt && block_tables.dim() == 2 && block_tables.size(0) == n &&
+              block_tables.stride(1) == 1);
+  TORCH_CHECK(token_log.scalar_type() == at::kLong && token_log.is_contiguous() && token_log.numel() >= n);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input_tokens));
+  check(lvllm_advance_step_ex((int)n, (int)n, (int)block_size, input_tokens.data_ptr<int64_t>(),
+                              sampled_token_ids.data_ptr<int64_t>(), input_positions.data_ptr<int64_t>(),
+                              seq_lens.data_ptr<int32_t>(), slot_mapping.data_ptr<int64_t>(),
+                              block_tables.data_ptr<int32_t>(), block_tables.stride(0),
+                              token_log.data_ptr<int64_t>(), 1, current_stream(input_tokens)));
 }
 
 // csrc/cache_kernels.cu:352-410
@@ -827,6 +862,10 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_w8a8_swiglu", torch::kCUDA, &skinny_linear_w8a8_swiglu);
   amd.def("skinny_linear_w8a8_argmax(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K) -> Tensor");
   amd.impl("skinny_linear_w8a8_argmax", torch::kCUDA, &skinny_linear_w8a8_argmax);
+  amd.def("advance_step_logged(int block_size, Tensor! input_tokens, Tensor sampled_token_ids, "
+          "Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables, "
+          "Tensor! token_log) -> ()");
+  amd.impl("advance_step_logged", torch::kCUDA, &advance_step_logged);
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });

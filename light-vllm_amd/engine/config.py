@@ -64,8 +64,24 @@ class SchedulerConfig:
     max_num_on_the_fly: Optional[int] = None  # None: 3 for "double_buffer", else 2 (decoding/config.py:149-155)
     preemption_mode: Optional[str] = None  # None | "swap" | "recompute"
     chunked_prefill_enabled: bool = False  # decoding/config.py: prompts are cut to the token budget
+    # slots reserved per decoding sequence beyond its known tokens (decoding/config.py:127,160; the
+    # reference plumbs them through its scheduler for lookahead / speculative decoding, scheduler.py:1095-1106)
+    num_lookahead_slots: int = 0
+    # > 1: a decode step runs this many model steps back to back on the device (advance_step between
+    # them, csrc/prepare_inputs/advance_step.cu) and returns to the host once; needs the lookahead slots
+    # for the tokens in between, hence the v2 block manager (v1 refuses lookahead, block_manager_v1.py:353-355)
+    num_scheduler_steps: int = 1
 
     def __post_init__(self) -> None:
+        if self.num_scheduler_steps < 1:
+            raise ValueError(f"num_scheduler_steps {self.num_scheduler_steps} must be positive")
+        if self.num_scheduler_steps > 1:
+            self.num_lookahead_slots = max(self.num_lookahead_slots, self.num_scheduler_steps - 1)
+        if self.num_lookahead_slots < 0:
+            raise ValueError(f"num_lookahead_slots ({self.num_lookahead_slots}) must be greater than or equal to 0.")
+        if self.num_lookahead_slots > 0 and not self.use_v2_block_manager:
+            raise ValueError("lookahead slots (multi-step decode) need use_v2_block_manager=True: "
+                             "BlockSpaceManagerV1 does not support lookahead allocation")
         if self.max_num_on_the_fly is None:
             self.max_num_on_the_fly = 3 if self.scheduling == "double_buffer" else 2
         if self.max_num_on_the_fly < 1:  # the reference insists on >= 2 (:190-193); one step in flight is

@@ -48,15 +48,49 @@ class DecodeGraph:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.hidden: Optional[torch.Tensor] = None
         self.next_tokens: Optional[torch.Tensor] = None
+        # multi-step decode: the tokens of model step j of a burst land in row j, on the device and (one copy
+        # per burst) in a pinned twin
+        self._scratch = None  # this graph's own paged_attention_v2 scratch (see PagedAttnMetadata.decode_scratch)
+        self.token_log: Optional[torch.Tensor] = None
+        self._host_logs: List[torch.Tensor] = []
+        self._host_logs_next = 0
+
+    def replay_steps(self, k: int) -> torch.Tensor:
+        """k model steps back to back on the current stream with no host round trip: replay, then
+        advance_step on the device (tokens <- sampled ids, positions and lengths + 1, slots through the block
+        table: csrc/prepare_inputs/advance_step.cu:14-57), k times; returns the [k, B] tokens.  The block
+        tables must already cover the k - 1 positions ahead (lookahead slots of the block manager)."""
+        B = self.batch_size
+        if self.token_log is None or self.token_log.shape[0] < k:
+            self.token_log = torch.zeros(k, B, dtype=torch.int64, device=self.packed.device)
+            pin = self.packed.device.type == "cuda"
+            self._host_logs = [torch.empty(k, B, dtype=torch.int64, pin_memory=pin) for _ in range(4)]
+        for j in range(k):
+            self.graph.replay()
+            if j + 1 < k:
+                torch.ops._C_amd.advance_step_logged(self.block_size, self.input_ids, self.next_tokens, self.positions,
+                                                     self.seq_lens, self.slot_mapping, self.block_tables,
+                                                     self.token_log[j])
+            else:
+                self.token_log[j].copy_(self.next_tokens)
+        return self.token_log[:k]
+
+    def next_host_log(self, k: int) -> torch.Tensor:
+        t = self._host_logs[self._host_logs_next]
+        self._host_logs_next = (self._host_logs_next + 1) % len(self._host_logs)
+        return t[:k]
 
     def _metadata(self) -> PagedAttnMetadata:
+        if self._scratch is None and hasattr(self.model.attn, "make_v2_scratch"):
+            self._scratch = self.model.attn.make_v2_scratch(self.batch_size, self.max_blocks_per_seq * self.block_size,
+                                                           self.model.cfg.dtype, self.packed.device)
         return PagedAttnMetadata(
             num_prefills=0, num_prefill_tokens=0, num_decode_tokens=self.batch_size,
             slot_mapping=self.slot_mapping, seq_lens=None, seq_lens_tensor=self.seq_lens,
             max_query_len=1, max_prefill_seq_len=0,
             max_decode_seq_len=self.max_blocks_per_seq * self.block_size,
             query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
-            block_tables=self.block_tables, use_cuda_graph=True)
+            block_tables=self.block_tables, use_cuda_graph=True, decode_scratch=self._scratch)
 
     def _step(self):
         hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, self._metadata())

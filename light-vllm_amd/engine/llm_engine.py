@@ -35,10 +35,11 @@ class RequestOutput:
 
 @dataclass
 class ExecuteOutput:
-    sampled: Optional[torch.Tensor]  # [num sampled rows] int64 on the CPU (pinned)
+    sampled: Optional[torch.Tensor]  # [num sampled rows] int64 on the CPU (pinned); [num_steps, rows] of a burst
     sample_seq_ids: List[int]
     execute_begin_ts: float = 0.0
     execute_end_ts: float = 0.0
+    num_steps: int = 1  # model steps this result covers (multi-step decode)
 
 
 class Worker:
@@ -229,10 +230,12 @@ class Worker:
 
 
     @torch.inference_mode()
-    def execute_decode(self, metas, slot: int = 0) -> Optional[ExecuteOutput]:
+    def execute_decode(self, metas, slot: int = 0, num_steps: int = 1) -> Optional[ExecuteOutput]:
         """A step of decode tokens only, taken straight from the scheduler's metadata to the captured
         graph's staging buffer (DecodeStepArrays): same inputs as `execute(input_builder(...))`, a
-        fraction of the host time.  None when the step does not fit the captured shapes."""
+        fraction of the host time.  None when the step does not fit the captured shapes.
+        num_steps > 1: that many model steps back to back on the device (DecodeGraph.replay_steps); the
+        result then holds [num_steps, n] tokens."""
         graphs = self.graph_pools[slot] if self.graph_pools is not None else None
         if graphs is None or self.capture_logits:
             return None
@@ -242,6 +245,11 @@ class Worker:
         if seq_ids is None:  # a block table wider than the captured step
             return None
         g.load_staged()
+        if num_steps > 1:
+            tokens = g.replay_steps(num_steps)[:, :n]
+            out = g.next_host_log(num_steps)[:, :n]
+            out.copy_(tokens, non_blocking=True)
+            return ExecuteOutput(out, seq_ids, num_steps=num_steps)
         tokens = g.replay()[:n]
         out = g.next_host_tokens()[:n]
         out.copy_(tokens, non_blocking=True)
@@ -336,6 +344,9 @@ class LLMEngine:
         # LVLLM_POLL_COMPLETION=0 brings the per-slot waiter threads back)
         self.poll_completion = os.environ.get("LVLLM_POLL_COMPLETION", "1") != "0"
         self._pending: List[Tuple[int, torch.cuda.Event, SchedulerOutput, ExecuteOutput]] = []
+        self._last_event: Dict[int, Optional[torch.cuda.Event]] = {}  # latest step of each slot
+        self._fence: Optional[torch.cuda.Event] = None                # latest block-moving step (see _launch)
+        self.step_timeout_s = 300.0
         self.step_returns_outputs = True
 
     def capture_decode_graphs(self, batch_size: int) -> None:
@@ -362,7 +373,53 @@ class LLMEngine:
         return self.scheduler.has_unfinished_requests()
 
     # ---- output processing (decoding/processor/output_processor.py, greedy subset) ----
+    def _process_burst(self, sched: SchedulerOutput, out: ExecuteOutput) -> List[RequestOutput]:
+        """Output processing of a multi-step decode: sequence i sampled out.sampled[0..k-1, i]; the tokens are
+        appended one by one under the stop checks of the single-step path, and what a sequence sampled after it
+        finished is dropped (its KV went into lookahead slots that are freed with the sequence)."""
+        rows = out.sampled.t().tolist()  # [n][k]
+        tok_of = dict(zip(out.sample_seq_ids, rows))
+        results: List[RequestOutput] = []
+        max_model_len = self.scheduler_config.max_model_len
+        eos = self.eos_token_id
+        for s in sched.scheduled_seq_groups:
+            g = s.seq_group
+            seq = g.seqs[0]
+            for tok in tok_of[seq.seq_id]:
+                seq.data.update_num_computed_tokens(1)
+                seq.append_token_id(tok, 0.0)
+                if eos is not None and tok == eos:
+                    seq.status = SequenceStatus.FINISHED_STOPPED
+                elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                elif seq.get_len() >= max_model_len:
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                if seq.status > 2:
+                    break
+            finished = seq.status > 2
+            if finished:
+                self.scheduler.free_seq(seq)
+            if self.step_returns_outputs:
+                results.append(RequestOutput(g.request_id, list(seq.get_output_token_ids()), finished,
+                                             SequenceStatus.get_finished_reason(seq.status)))
+            else:
+                results.append(RequestOutput(g.request_id, [], finished))
+        if any(r.finished for r in results):
+            self.scheduler.free_finished_request([s.seq_group.request_id for s in sched.scheduled_seq_groups])
+            for r in results:
+                if r.finished:
+                    g = self.groups.pop(r.request_id, None)
+                    if g is not None:
+                        for seq in g.seqs:
+                            self.seq_to_group.pop(seq.seq_id, None)
+        else:
+            for s in sched.scheduled_seq_groups:
+                s.seq_group.busy = False
+        return results
+
     def _process(self, sched: SchedulerOutput, out: ExecuteOutput) -> List[RequestOutput]:
+        if out.num_steps > 1:
+            return self._process_burst(sched, out)
         sampled = out.sampled.tolist() if out.sampled is not None else []
         tok_of = dict(zip(out.sample_seq_ids, sampled))
         results: List[RequestOutput] = []
@@ -447,7 +504,7 @@ class LLMEngine:
             plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
             metas = sched.seq_group_metadata_list
             if DecodeStepArrays.eligible(metas, plain, self.cache_config.sliding_window):
-                out = self.worker.execute_decode(metas, slot)
+                out = self.worker.execute_decode(metas, slot, self._burst_steps(sched))
                 if out is not None:
                     return out
             elif self.worker.mixed_graph_tokens > 0 and MixedStepArrays.eligible(metas, plain,
@@ -456,6 +513,20 @@ class LLMEngine:
                 if out is not None:
                     return out
         return self.worker.execute(self.input_builder(sched), slot)
+
+    def _burst_steps(self, sched: SchedulerOutput) -> int:
+        """Model steps a decode-only step runs on the device before it returns to the host: the configured
+        `num_scheduler_steps` when the block manager reserved the slots for it and no sequence would run past
+        the model length (positions of a burst: len - 1 .. len + k - 2), else 1."""
+        k = self.scheduler_config.num_scheduler_steps
+        if k <= 1 or sched.num_lookahead_slots < k - 1:
+            return 1
+        limit = self.scheduler_config.max_model_len
+        for m in sched.seq_group_metadata_list:
+            for data in m.seq_data.values():
+                if data.get_len() + k - 1 > limit:
+                    return 1
+        return k
 
     def _launch(self, sched: SchedulerOutput) -> None:
         """What the reference's async_execute_loop does per task (core/executor.py:62-93): take a
@@ -470,10 +541,29 @@ class LLMEngine:
         try:
             t0 = time.perf_counter()
             stream = self.streams[slot]
+            # Steps in flight run on their own streams with no ordering between them, which is only safe while
+            # they touch disjoint blocks.  A step that MOVES blocks (swap in / out, copy-on-write) or an engine
+            # with prefix caching (a later prompt reads blocks an earlier step is still filling; blocks are
+            # marked computed at schedule time, scheduler.py:924-926) is ordered on the device instead: it waits
+            # for every step in flight, and every later step waits for it.  No host wait.
+            moves = bool(sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
+            fence = moves or self.cache_config.enable_prefix_caching
             with torch.cuda.stream(stream):
+                if self._fence is not None:
+                    if self._fence.query():
+                        self._fence = None
+                    else:
+                        stream.wait_event(self._fence)
+                if fence:
+                    for other, last in self._last_event.items():
+                        if other != slot and last is not None and not last.query():
+                            stream.wait_event(last)
                 out = self._execute(sched, slot)
                 ev = torch.cuda.Event()
                 ev.record(stream)
+            self._last_event[slot] = ev
+            if fence:
+                self._fence = ev
             out.execute_begin_ts = t0
             if self.poll_completion:
                 self._pending.append((slot, ev, sched, out))
@@ -522,6 +612,8 @@ class LLMEngine:
         if self.poll_completion:
             # the engine thread watches the steps' events itself: no waiter thread to wake, no queue hop
             # between a step finishing and its group's next step being prepared
+            spins = 0
+            t_wait = None
             while True:
                 for i, (slot, ev, sched, out) in enumerate(self._pending):
                     if ev.query():
@@ -530,6 +622,13 @@ class LLMEngine:
                         out.execute_end_ts = time.perf_counter()
                         self.num_on_the_fly -= 1
                         return self._process(sched, out)
+                spins += 1
+                if spins & 0xfff == 0:  # a hung step must not spin the engine thread for ever
+                    now = time.perf_counter()
+                    t_wait = t_wait or now
+                    if now - t_wait > self.step_timeout_s:
+                        raise RuntimeError(f"no step completed within {self.step_timeout_s:.0f} s "
+                                           f"({len(self._pending)} in flight)")
         item = self.executor_out.get()
         if isinstance(item, Exception):
             raise item

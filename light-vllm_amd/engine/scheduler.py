@@ -172,6 +172,7 @@ class DecodingScheduler:
         q = self.running
         num_scheduled_seqs = 0
         deferred: List[SequenceGroup] = []
+        lookahead = self._get_num_lookahead_slots(is_prefill=False)
         while q:
             seq_group = q[0]
             if seq_group.busy:  # a step holding this group is still in flight
@@ -185,9 +186,9 @@ class DecodingScheduler:
                     and seqs[0].status == SequenceStatus.RUNNING and not seqs[0].is_prefill()
                     and num_scheduled_seqs + 1 <= budget.max_num_seqs
                     and (not enable_chunking or budget.remaining_token_budget() >= 1)
-                    and self.block_manager.can_append_slots(seq_group, 0)):
+                    and self.block_manager.can_append_slots(seq_group, lookahead)):
                 q.popleft()
-                blocks_to_copy.extend(self.block_manager.append_slots(seqs[0], 0))
+                blocks_to_copy.extend(self.block_manager.append_slots(seqs[0], lookahead))
                 num_scheduled_seqs += 1
                 decodes.append(ScheduledSequenceGroup(seq_group, 1))
                 budget.add_num_batched_tokens(seq_group.request_id, 1)
@@ -207,7 +208,7 @@ class DecodingScheduler:
             if num_running_tokens == 0:
                 break
             q.popleft()
-            while not self.block_manager.can_append_slots(seq_group, 0):
+            while not self.block_manager.can_append_slots(seq_group, lookahead):
                 budget.subtract_num_batched_tokens(seq_group.request_id, num_running_tokens)
                 budget.subtract_num_seqs(seq_group.request_id, seq_group.get_max_num_running_seqs())
                 # evict the most recently arrived group first -- but never one that a step still in
@@ -250,7 +251,7 @@ class DecodingScheduler:
         q = self.swapped
         while q:
             seq_group = q[0]
-            status = self.block_manager.can_swap_in(seq_group, 0)
+            status = self.block_manager.can_swap_in(seq_group, self._get_num_lookahead_slots(seq_group.is_prefill()))
             if status == AllocStatus.LATER:
                 break
             if status == AllocStatus.NEVER:
@@ -355,7 +356,8 @@ class DecodingScheduler:
             scheduled_seq_groups=prefills + decodes + sw_decodes, num_prefill_groups=len(prefills),
             num_batched_tokens=budget.num_batched_tokens, blocks_to_swap_in=swap_in_blocks,
             blocks_to_swap_out=swap_out_blocks, blocks_to_copy=copy_blocks + sw_copy,
-            ignored_seq_groups=ignored + infeasible, num_lookahead_slots=0,
+            ignored_seq_groups=ignored + infeasible,
+            num_lookahead_slots=self._get_num_lookahead_slots(is_prefill=bool(prefills)),
             running_queue_size=len(self.running), preempted=len(preempted) + len(swapped_out))
 
     def _schedule_chunked_prefill(self) -> SchedulerOutput:
@@ -379,7 +381,8 @@ class DecodingScheduler:
             num_prefill_groups=len(prefills) + len(sw_prefills) + len(run_prefills),
             num_batched_tokens=budget.num_batched_tokens, blocks_to_swap_in=swap_in_blocks,
             blocks_to_swap_out=swap_out_blocks, blocks_to_copy=copy_blocks + sw_copy,
-            ignored_seq_groups=ignored + infeasible, num_lookahead_slots=0,
+            ignored_seq_groups=ignored + infeasible,
+            num_lookahead_slots=self._get_num_lookahead_slots(is_prefill=False),
             running_queue_size=len(self.running), preempted=len(preempted) + len(swapped_out))
 
     def need_scheduling(self) -> bool:
@@ -454,9 +457,17 @@ class DecodingScheduler:
                 g.busy = False
         self.running = remaining
 
+    def _get_num_lookahead_slots(self, is_prefill: bool) -> int:
+        """Slots to allocate per sequence per step beyond the known token ids: none for prompts, the
+        configured number for decoding sequences (scheduler.py:1095-1106)."""
+        if is_prefill:
+            return 0
+        return self.scheduler_config.num_lookahead_slots
+
     def _append_slots(self, seq_group: SequenceGroup, blocks_to_copy: List[Tuple[int, int]]) -> None:
+        num_lookahead_slots = self._get_num_lookahead_slots(is_prefill=False)  # scheduler.py:978-982
         for seq in seq_group.get_seqs(status=SequenceStatus.RUNNING):
-            blocks_to_copy.extend(self.block_manager.append_slots(seq, 0))
+            blocks_to_copy.extend(self.block_manager.append_slots(seq, num_lookahead_slots))
 
     def _preempt(self, seq_group: SequenceGroup, blocks_to_swap_out: List[Tuple[int, int]]) -> PreemptionMode:
         if self.user_specified_preemption_mode is None:

@@ -152,6 +152,7 @@ class PrefillOnlyEngine:
                 self._done_q.put((slot, ev, sched, host, mi.seq_lens))
             except Exception as e:
                 self.free_slots.put(slot)
+                e.failed_request_ids = [r.request_id for r in sched.scheduled_requests]
                 self.executor_out.put(e)
 
     def _done_loop(self) -> None:
@@ -183,9 +184,10 @@ class PrefillOnlyEngine:
         if self.num_on_the_fly == 0:
             return outs
         item = self.executor_out.get()
-        if isinstance(item, Exception):
+        self.num_on_the_fly -= 1  # the failed step is no longer in flight either: encode()'s loop must end
+        if isinstance(item, Exception):  # its requests will never produce an output: they leave the books
+            self.scheduler.requests.difference_update(getattr(item, "failed_request_ids", ()))
             raise item
-        self.num_on_the_fly -= 1
         sched, host, lens = item
         return outs + self._process(PrefillOnlySchedulerOutput(sched.scheduled_requests, []), host, lens)
 

@@ -67,7 +67,10 @@ def make_block_manager_traces():
                    num_cpu_blocks=cfg["num_cpu_blocks"], watermark=cfg["watermark"],
                    sliding_window=cfg["sliding_window"], enable_caching=cfg["enable_caching"])
 
+    only = os.environ.get("GOLDEN_ONLY")  # e.g. GOLDEN_ONLY=lookahead: regenerate just the matching traces
     for name, cfg, seed, num_ops in bm_driver.DEFAULT_CONFIGS + getattr(bm_driver, "V2_CONFIGS", []):
+        if only and only not in name:
+            continue
         hook = _recording_free_hook if cfg["version"] == "v1" else None
         trace = bm_driver.run_program(make_manager, adapter, cfg, seed, num_ops, free_hook=hook)
         for op in trace:  # only table frees are order-sensitive; drop the rest of the logs

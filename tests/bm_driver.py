@@ -152,17 +152,24 @@ def run_program(make_manager, adapter, config: Dict[str, Any], seed: int, num_op
         elif r < 0.62 and running_groups:
             # ---- decode step of one running group ----
             g = rng.choice(running_groups)
-            ok = bm.can_append_slots(g, 0)
+            # "lookahead" programs (multi-step decode): the manager reserves `la` slots beyond the known
+            # tokens (block_manager_v2.py:183-239) and the step then appends 1 .. la + 1 tokens at once
+            la = config.get("lookahead", 0)
+            ok = bm.can_append_slots(g, la)
             op.update(op="decode", group=g.request_id, can_append=bool(ok))
+            if la:
+                op["lookahead"] = la
             if ok:
                 cows = []
                 for s in g.get_seqs(status=S("RUNNING")):
-                    cows.extend([list(p) for p in bm.append_slots(s, 0)])
+                    cows.extend([list(p) for p in bm.append_slots(s, la)])
                 op["cows"] = cows
                 schedule_side_effects(g, op)
+                n_new = rng.randint(1, la + 1) if la else 1
                 for s in g.get_seqs(status=S("RUNNING")):
-                    s.data.update_num_computed_tokens(1)
-                    adapter.append(s, rng.randrange(vocab))
+                    for _ in range(n_new):
+                        s.data.update_num_computed_tokens(1)
+                        adapter.append(s, rng.randrange(vocab))
         elif r < 0.70 and running_groups and not config.get("no_fork"):
             # ---- fork (parallel sampling / beam): child shares the parent's blocks ----
             g = rng.choice(running_groups)
@@ -183,7 +190,7 @@ def run_program(make_manager, adapter, config: Dict[str, Any], seed: int, num_op
                     s.status = S("SWAPPED")
         elif r < 0.88 and swapped_groups:
             g = rng.choice(swapped_groups)
-            verdict = bm.can_swap_in(g, 0).name
+            verdict = bm.can_swap_in(g, config.get("lookahead", 0)).name
             op.update(op="swap_in", group=g.request_id, verdict=verdict)
             if verdict == "OK":
                 op["mapping"] = [list(p) for p in bm.swap_in(g)]
@@ -245,4 +252,11 @@ V2_CONFIGS = [
                             sliding_window=None, enable_caching=True, free_running_only=True, no_fork=True), 14, 700),
     ("v2_sliding_window", dict(version="v2", block_size=8, num_gpu_blocks=64, num_cpu_blocks=0, watermark=0.01,
                                sliding_window=20, enable_caching=False, no_fork=True), 15, 400),
+    # multi-step decode: lookahead slots reserved at every decode, several tokens appended per step
+    # (no swap space: the reference's own swap_out raises IndexError on a table that ends in reserved,
+    # still empty lookahead blocks -- block/common.py:207 via naive_block.py:335)
+    ("v2_naive_lookahead3", dict(version="v2", block_size=8, num_gpu_blocks=56, num_cpu_blocks=0, watermark=0.05,
+                                 sliding_window=None, enable_caching=False, no_fork=True, lookahead=3), 16, 500),
+    ("v2_naive_lookahead7_fork", dict(version="v2", block_size=16, num_gpu_blocks=96, num_cpu_blocks=0, watermark=0.01,
+                                      sliding_window=None, enable_caching=False, lookahead=7), 17, 400),
 ]

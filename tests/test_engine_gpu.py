@@ -52,7 +52,8 @@ def dense_reference_logits(model, token_ids):
 
 
 def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048,
-                cache_dtype="auto", quantization=None, v2=False, prefix_caching=False, preemption_mode=None):
+                cache_dtype="auto", quantization=None, v2=False, prefix_caching=False, preemption_mode=None,
+                num_scheduler_steps=1, max_model_len=512):
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
@@ -60,10 +61,10 @@ def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=Fa
     cfg.quantization = quantization
     return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32,
                                       cache_dtype=cache_dtype, enable_prefix_caching=prefix_caching),
-                     SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=512,
+                     SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=max_model_len,
                                      scheduling=scheduling, max_num_on_the_fly=2,
                                      chunked_prefill_enabled=chunked, use_v2_block_manager=v2,
-                                     preemption_mode=preemption_mode),
+                                     preemption_mode=preemption_mode, num_scheduler_steps=num_scheduler_steps),
                      device=DEV, use_hip_graph=graph, seed=0)
 
 
@@ -438,3 +439,82 @@ def test_decode_batches_of_65_to_128_rows_take_the_stream_gemm(monkeypatch):
     same_first = sum(got[k][0] == want[k][0] for k in want)
     same_all = sum(got[k] == want[k] for k in want)
     assert same_first >= len(reqs) - 3 and same_all >= int(0.8 * len(reqs)), (same_first, same_all)
+
+
+# ------------------------------------------------------------------ multi-step decode (advance_step on the device)
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_multi_step_decode_gives_the_tokens_of_single_steps(k):
+    """num_scheduler_steps = k: k model steps per engine step, chained on the device by advance_step
+    (csrc/prepare_inputs/advance_step.cu:14-57) over lookahead slots of the v2 block manager.  Greedy
+    tokens must be those of k single steps: sync and with two bursts in flight, at token budgets that are and
+    are not multiples of k (a sequence that finishes mid-burst drops the rest), on a pool small enough to
+    preempt, and up against the model length (bursts that would cross it fall back to single steps)."""
+    ref = run_to_completion(make_engine(graph=True, v2=True), max_tokens=21)
+    assert all(len(t) == 21 for t in ref)
+    for kw, use_async in ((dict(), False), (dict(scheduling="async", max_seqs=3), True),
+                          (dict(num_blocks=24), False)):
+        e = make_engine(graph=True, v2=True, num_scheduler_steps=k, **kw)
+        got = run_to_completion(e, max_tokens=21, use_async=use_async)
+        assert got == ref, (k, kw)
+        assert e.scheduler.block_manager.get_num_free_gpu_blocks() == kw.get("num_blocks", 256)
+    # model length 120: the 90-token prompt may only reach 120 tokens, the others stop at their budget
+    short_ref = run_to_completion(make_engine(graph=True, v2=True, max_model_len=120), max_tokens=40)
+    short = run_to_completion(make_engine(graph=True, v2=True, max_model_len=120, num_scheduler_steps=k), max_tokens=40)
+    assert short == short_ref and len(short[3]) == 30
+
+
+def test_multi_step_decode_stops_at_eos_inside_a_burst():
+    """A sequence that samples EOS in the middle of a burst ends there: what the device generated for it
+    afterwards is dropped, every other sequence is unaffected."""
+    ref = run_to_completion(make_engine(graph=True, v2=True), max_tokens=24)
+    eos = ref[1][9]  # request 1 emits it as its 10th token
+
+    def run(k):
+        e = make_engine(graph=True, v2=True, num_scheduler_steps=k)
+        e.eos_token_id = eos  # set before the requests are added: the engine checks it in its output processing
+        return run_to_completion(e, max_tokens=24)
+
+    single, burst = run(1), run(4)
+    assert single == burst
+    assert len(single[1]) <= 10 and single[1][-1] == eos and single[1] == ref[1][:len(single[1])]
+
+
+def test_multi_step_needs_the_v2_block_manager():
+    from light_vllm_amd.engine.config import SchedulerConfig
+    with pytest.raises(ValueError):
+        SchedulerConfig(num_scheduler_steps=4)
+    assert SchedulerConfig(num_scheduler_steps=4, use_v2_block_manager=True).num_lookahead_slots == 3
+
+
+@pytest.mark.parametrize("prefix_caching", [False, True])
+def test_async_steps_with_swaps_and_prefix_caching_are_ordered_on_the_device(prefix_caching):
+    """Two steps in flight on two streams while the scheduler swaps groups out and in (and, with prefix caching,
+    later prompts read blocks an earlier step fills): every block-moving step waits for the steps in flight and
+    fences the later ones (LLMEngine._launch), so the tokens are those of the sync run."""
+    if prefix_caching:
+        kw = dict(num_blocks=72, max_seqs=6, prefix_caching=True)
+    else:
+        kw = dict(num_blocks=26, max_seqs=6, preemption_mode="swap")
+    g = torch.Generator().manual_seed(5)
+    shared = torch.randint(0, 512, (40,), generator=g).tolist()
+    reqs = [shared + torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (3, 50, 17, 80, 33, 64, 9, 70)]
+
+    def run(engine, use_async):
+        for i, p in enumerate(reqs):
+            engine.add_request(str(i), p, max_tokens=30)
+        final = {}
+        step = engine.async_step if use_async else engine.step
+        for _ in range(4000):
+            for out in step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not engine.has_unfinished_requests() and engine.num_on_the_fly == 0:
+                break
+        engine.shutdown()
+        return [final[str(i)] for i in range(len(reqs))], engine.scheduler.num_cumulative_preemption
+
+    want, _ = run(make_engine(graph=True, **kw), False)
+    got, preempted = run(make_engine(graph=True, scheduling="async", **kw), True)
+    assert got == want
+    if not prefix_caching:
+        assert preempted > 0, "the pool was meant to be too small: nothing was swapped"

@@ -293,14 +293,13 @@ def split_ranges(seq_len, num_splits):
 
 
 @pytest.fixture
-def force_splits(monkeypatch):
+def force_splits(ops):
+    """lvllm_set_tuning("attn_splits", n): n shares; None / 0 = the library's choice; -1 = the
+    reference's 512-token partitions."""
     def _set(n):
-        if n is None:
-            monkeypatch.delenv("LVLLM_ATTN_SPLITS", raising=False)
-        else:
-            monkeypatch.setenv("LVLLM_ATTN_SPLITS", str(n))
+        torch.ops._C_amd.set_tuning("attn_splits", 0 if n is None else int(n))
     yield _set
-    monkeypatch.delenv("LVLLM_ATTN_SPLITS", raising=False)
+    torch.ops._C_amd.set_tuning("attn_splits", 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
@@ -565,3 +564,166 @@ def test_gelu_matches_torch(ops, dtype):
     x2 = x.clone()
     torch.ops._C_amd.gelu(x2, x2)
     assert torch.equal(x2.view(torch.int16), out.view(torch.int16))
+
+
+# ------------------------------------------------ v2 scratch under the reference's partitioning
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [
+    (4, 8, 2, 128, 16, [1024, 1500, 512, 17]),
+    (3, 4, 4, 64, 32, [513, 2048, 1]),
+    (2, 14, 2, 128, 16, [700, 0]),
+    (5, 32, 8, 128, 16, [1024] * 5),
+], ids=["gqa4", "mha_bs32", "gqa7_empty", "metric_shape"])
+def test_v2_scratch_equals_the_reference_partitions(ops, dtype, case, force_splits):
+    """With lvllm_set_tuning("attn_splits", -1) paged_attention_v2 cuts contexts at 512 tokens as
+    attention_kernels.cu:850 does, and exp_sums / max_logits / tmp_out hold, slot for slot, what the
+    reference's partition kernel stores (attention_kernels.cu:349-357,483-495; oracle_paged_attention_v2
+    restates it).  Slots of partitions past a sequence's end are never written by either."""
+    S, H, KVH, D, BS, lens = case
+    inp = make_paged_inputs(S, H, KVH, D, BS, lens, dtype=dtype, seed=S * 7 + D, q_in_qkv=True)
+    exp_out, exp_es, exp_ml, exp_tmp = oracle_v2(inp)
+    force_splits(-1)
+    out, es, ml, tmp = run_v2(ops, to_dev(inp))
+    tol = 2e-2 if dtype != torch.float32 else 1e-4
+    check_attention(out, exp_out, dense_attention_fp64(inp), tol)
+    es, ml, tmp = es.cpu(), ml.cpu(), tmp.cpu()
+    scale = float(exp_out.float().abs().max().clamp_min(1e-6))
+    for s_i, L in enumerate(lens):
+        for j in range((L + 511) // 512):
+            assert torch.allclose(ml[s_i, :, j], exp_ml[s_i, :, j], atol=2e-3, rtol=1e-3), (s_i, j)
+            assert torch.allclose(es[s_i, :, j], exp_es[s_i, :, j], rtol=5e-3, atol=1e-4), (s_i, j)
+            assert ((tmp[s_i, :, j].float() - exp_tmp[s_i, :, j].float()).abs().max() <= tol * max(
+                scale, float(exp_tmp[s_i, :, j].float().abs().max()))), (s_i, j)
+
+
+def test_v2_forced_shares_on_512_multiples_are_the_reference_partitions(ops, force_splits):
+    """Contexts that are multiples of 512 cut into max_seq/512 equal shares: share j IS partition j, so the
+    default kernel's scratch equals the oracle's without the reference-partition switch."""
+    lens = [2048, 2048, 2048]
+    inp = make_paged_inputs(3, 8, 2, 128, 16, lens, dtype=torch.bfloat16, seed=11)
+    exp_out, exp_es, exp_ml, exp_tmp = oracle_v2(inp)
+    force_splits(4)
+    out, es, ml, tmp = run_v2(ops, to_dev(inp))
+    check_attention(out, exp_out)
+    assert torch.allclose(ml.cpu(), exp_ml, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(es.cpu(), exp_es, rtol=5e-3, atol=1e-4)
+    assert (tmp.cpu().float() - exp_tmp.float()).abs().max() <= 2e-2 * float(exp_tmp.float().abs().max())
+
+
+# ------------------------------------------------ stated cache extents (kv_cache_bytes of the C-ABI)
+def test_block_numbers_beyond_the_stated_extent_are_clamped_not_followed(ops):
+    """The caches are the FRONT of one larger allocation whose tail holds NaN: a block table that points
+    past the caches' last block must read inside the stated extent (the torch binding states it), so the
+    result stays finite and equals the run with the numbers clamped by hand."""
+    inp = make_paged_inputs(2, 8, 2, 128, 16, [300, 77], dtype=torch.bfloat16, seed=2)
+    NB = inp["key_cache"].shape[0]
+    d = to_dev(inp)
+    big_k = torch.full((3 * NB,) + tuple(inp["key_cache"].shape[1:]), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_v = torch.full((3 * NB,) + tuple(inp["value_cache"].shape[1:]), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_k[:NB], big_v[:NB] = d["key_cache"], d["value_cache"]
+    bad = d["block_tables"].clone()
+    bad[0, 3] = NB + 5       # inside the big allocation, outside the stated caches
+    bad[1, 1] = 3 * NB - 1
+    clamped = bad.clamp(max=NB - 1)
+    outs = []
+    for bt in (bad, clamped):
+        dd = dict(d, key_cache=big_k[:NB], value_cache=big_v[:NB], block_tables=bt)
+        outs.append(run_v1(ops, dd))
+        outs.append(run_v2(ops, dd)[0])
+    assert all(torch.isfinite(o.float()).all() for o in outs)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
+def test_slots_beyond_the_stated_extent_are_skipped(ops):
+    g = torch.Generator().manual_seed(3)
+    T, H, D, BS, NB = 70, 2, 128, 16, 6
+    key = torch.randn(T, H, D, generator=g).to(torch.bfloat16).to(DEV)
+    value = torch.randn(T, H, D, generator=g).to(torch.bfloat16).to(DEV)
+    big_k = torch.zeros(2 * NB, H, D // 8, BS, 8, dtype=torch.bfloat16, device=DEV)
+    big_v = torch.zeros(2 * NB, H, D, BS, dtype=torch.bfloat16, device=DEV)
+    slots = torch.randperm(NB * BS, generator=g)[:T].to(torch.int64)
+    slots[5] = NB * BS + 3       # first slot past the stated caches
+    slots[40] = 2 * NB * BS - 1
+    for min_tok in (64, 1 << 20):  # the tiled kernel and the per-chunk kernel
+        torch.ops._C_amd.set_tuning("cache_tile_min_tokens", min_tok)
+        big_k.zero_(), big_v.zero_()
+        ops.reshape_and_cache(key, value, big_k[:NB], big_v[:NB], slots.to(DEV), "auto", 1.0, 1.0)
+        assert not big_k[NB:].any() and not big_v[NB:].any()
+        ok = slots.clone()
+        ok[5] = ok[40] = -1
+        kc_o, vc_o = torch.zeros_like(big_k[:NB]).cpu(), torch.zeros_like(big_v[:NB]).cpu()
+        oracle.reshape_and_cache(key.cpu(), value.cpu(), kc_o, vc_o, ok)
+        assert torch.equal(big_k[:NB].cpu(), kc_o) and torch.equal(big_v[:NB].cpu(), vc_o)
+    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 64)
+
+
+# ------------------------------------------------ reshape_and_cache at prompt sizes (LDS-tiled kernel)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+@pytest.mark.parametrize("num_heads,head_size", [(8, 128), (2, 64), (3, 80), (1, 256), (4, 120)])
+def test_reshape_and_cache_tiled_bit_exact(ops, dtype, block_size, num_heads, head_size):
+    """Prompt-sized batches take reshape_and_cache_tile_kernel: ragged sequences laid out back to back (token
+    tiles straddle sequences and blocks, contexts start mid-block as after a prefix hit or a chunk), padding
+    slots, a reversed run and fully random slots -- against the oracle, bit for bit, untouched bytes included."""
+    g = torch.Generator().manual_seed(block_size * 1000 + head_size + num_heads)
+    seqs = [(0, 37), (5, 130), (block_size - 1, 3), (17, 64), (0, 1), (block_size, 200), (3, 77)]
+    blocks_needed = sum((c + n + block_size - 1) // block_size for c, n in seqs)
+    NB = blocks_needed + 9
+    perm = torch.randperm(NB, generator=g).tolist()
+    slots = []
+    for ctx, n in seqs:
+        nb = (ctx + n + block_size - 1) // block_size
+        table, perm = perm[:nb], perm[nb:]
+        slots += [table[p // block_size] * block_size + p % block_size for p in range(ctx, ctx + n)]
+    T0 = len(slots)
+    free = [b for b in perm]
+    slots += [-1] * 5
+    slots += [free[0] * block_size + o for o in reversed(range(block_size))]          # descending run
+    rnd = torch.randperm(len(free[1:]) * block_size, generator=g)[:70] + 0
+    slots += [free[1 + int(r) // block_size] * block_size + int(r) % block_size for r in rnd]
+    slots[10] = -1
+    T = len(slots)
+    assert T > 64 and T0 > 400
+    x = 8
+    qkv = torch.randn(T, 3 * num_heads * head_size, generator=g).to(dtype)
+    key = qkv[:, num_heads * head_size: 2 * num_heads * head_size].view(T, num_heads, head_size)
+    value = qkv[:, 2 * num_heads * head_size:].view(T, num_heads, head_size)
+    kc = torch.randn(NB, num_heads, head_size // x, block_size, x, generator=g).to(dtype)
+    vc = torch.randn(NB, num_heads, head_size, block_size, generator=g).to(dtype)
+    slots_t = torch.tensor(slots, dtype=torch.int64)
+    kc_o, vc_o = kc.clone(), vc.clone()
+    oracle.reshape_and_cache(key, value, kc_o, vc_o, slots_t)
+    qkv_d = qkv.to(DEV)
+    key_d = qkv_d[:, num_heads * head_size: 2 * num_heads * head_size].view(T, num_heads, head_size)
+    value_d = qkv_d[:, 2 * num_heads * head_size:].view(T, num_heads, head_size)
+    kc_d, vc_d = kc.to(DEV), vc.to(DEV)
+    ops.reshape_and_cache(key_d, value_d, kc_d, vc_d, slots_t.to(DEV), "auto", 1.0, 1.0)
+    assert torch.equal(kc_d.cpu().view(torch.int16), kc_o.view(torch.int16))
+    assert torch.equal(vc_d.cpu().view(torch.int16), vc_o.view(torch.int16))
+
+
+def test_reshape_and_cache_full_size_round_trip(ops):
+    """BASELINE prefill size (8192 tokens x 8 kv heads x 128): the tiled kernel and the per-chunk kernel fill
+    two caches identically, and gathering the cache back through the slots returns the inputs."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    T, H, D, BS = 8192, 8, 128, 16
+    NB = T // BS + 50
+    key = torch.randn(T, H, D, generator=g, device=DEV).to(torch.bfloat16)
+    value = torch.randn(T, H, D, generator=g, device=DEV).to(torch.bfloat16)
+    table = torch.randperm(NB, generator=g, device=DEV)[: T // BS]
+    pos = torch.arange(T, device=DEV)
+    slots = table[pos // BS] * BS + pos % BS
+    caches = []
+    for min_tok in (64, 1 << 20):
+        torch.ops._C_amd.set_tuning("cache_tile_min_tokens", min_tok)
+        kc = torch.zeros(NB, H, D // 8, BS, 8, dtype=torch.bfloat16, device=DEV)
+        vc = torch.zeros(NB, H, D, BS, dtype=torch.bfloat16, device=DEV)
+        ops.reshape_and_cache(key, value, kc, vc, slots, "auto", 1.0, 1.0)
+        caches.append((kc, vc))
+    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 64)
+    assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1], caches[1][1])
+    kc, vc = caches[0]
+    blk, off = slots // BS, slots % BS
+    k_back = kc[blk, :, :, off, :].reshape(T, H, D)
+    v_back = vc[blk, :, :, off]
+    assert torch.equal(k_back, key) and torch.equal(v_back, value)

@@ -323,3 +323,40 @@ def test_mixed_step_arrays_equal_the_general_input_builder():
                             s.free_seq(seq)
             s.free_finished_request([sg.seq_group.request_id for sg in out.scheduled_seq_groups])
         assert checked > 150 and with_prompts > 30, (checked, with_prompts)
+
+
+def test_lookahead_slots_reach_the_block_manager_and_the_output():
+    """num_scheduler_steps = k reserves k - 1 slots beyond the known tokens of every decoding sequence at each
+    decode schedule (scheduler.py:978-982,1095-1106 with num_lookahead_slots), none for prompts."""
+    cc = CacheConfig(block_size=4, num_gpu_blocks=64, num_cpu_blocks=0)
+    sc = SchedulerConfig(max_num_batched_tokens=64, max_num_seqs=4, max_model_len=256, use_v2_block_manager=True,
+                         num_scheduler_steps=4)
+    assert sc.num_lookahead_slots == 3
+    s = DecodingScheduler(sc, cc)
+    g = add(s, 0, 6)          # 6 prompt tokens: 2 blocks
+    out = s.schedule()
+    assert out.num_prefill_groups == 1 and out.num_lookahead_slots == 0
+    assert len(out.seq_group_metadata_list[0].block_tables[0]) == 2
+    finish_step(s, out)       # +1 sampled token: 7 known tokens
+    out = s.schedule()
+    assert out.num_prefill_groups == 0 and out.num_lookahead_slots == 3
+    # 7 tokens + 3 lookahead = 10 slots -> 3 blocks
+    assert len(out.seq_group_metadata_list[0].block_tables[0]) == 3
+    # the burst appends 4 tokens: 11 known; the next schedule reserves up to 14 slots -> 4 blocks
+    for sg in out.scheduled_seq_groups:
+        for _ in range(4):
+            sg.seq_group.seqs[0].data.update_num_computed_tokens(1)
+            sg.seq_group.seqs[0].append_token_id(9)
+    s.free_finished_request([g.request_id])
+    out = s.schedule()
+    assert len(out.seq_group_metadata_list[0].block_tables[0]) == 4
+    free_before = s.block_manager.get_num_free_gpu_blocks()
+    g.seqs[0].status = SequenceStatus.FINISHED_STOPPED
+    s.free_seq(g.seqs[0])
+    assert s.block_manager.get_num_free_gpu_blocks() == free_before + 4 == 64
+
+
+def test_lookahead_needs_v2():
+    import pytest
+    with pytest.raises(ValueError):
+        SchedulerConfig(num_lookahead_slots=2)
