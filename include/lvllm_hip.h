@@ -124,6 +124,27 @@ int lvllm_paged_attention_v2_phases(
     int blocksparse_vert_stride, int blocksparse_block_size,
     int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream);
 
+/* Extension (not a reference operator): the three launches a decode step makes per layer --
+ *   rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)      csrc/ops.h:35-37
+ *   reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, "auto")     csrc/cache.h:18-22
+ *   paged_attention_v2(out, ..., query, key_cache, value_cache, ...)                csrc/ops.h:18-27
+ * -- as ONE (qwen2.py:151-154 -> layer.py:83-105 of the reference run them back to back).  One token per
+ * sequence: query [num_seqs, num_heads, D], key / value [num_seqs, num_kv_heads, D] (row strides in elements),
+ * positions / slot_mapping int64 [num_seqs].  The attention workgroup of a (sequence, kv head) rotates its query
+ * heads and the new key in registers (arithmetic and roundings of lvllm_rotary_embedding), writes the rotated key
+ * and the value into the paged caches at the slot, and attends to them from registers.  `out`, the caches and the
+ * scratch hold bit for bit what the three calls leave; query and key are NOT rotated in place (nothing downstream
+ * of attention reads them).  NeoX pairing, rot_dim == head_size in {64, 128, 256}, 16-bit types, kv_dtype AUTO,
+ * block_size 16 | 32, GQA group <= 16.  Returns 3 -- and does nothing -- outside that envelope. */
+int lvllm_rope_cache_paged_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key,
+    const void* value, void* key_cache, void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
+    int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, int64_t kv_cache_bytes, void* stream);
+
 /* ---- cache ops (replaces csrc/cache.h:9-33, cache_kernels.cu) ------------- */
 
 /* reshape_and_cache: scatter key/value [num_tokens,num_heads,head_size]

@@ -366,6 +366,25 @@ class PagedAttnImpl:
                                       force_version="v1" if use_v1 else "v2", scratch=scratch, output=out)
         return out.view(num_tokens, hidden_size)
 
+    def rope_cache_decode_attention(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                                    value: torch.Tensor, cos_sin_cache: torch.Tensor, key_cache: torch.Tensor,
+                                    value_cache: torch.Tensor, attn_metadata: PagedAttnMetadata) -> Optional[torch.Tensor]:
+        """rotary_embedding + reshape_and_cache + paged_attention_v2 of a decode-only step in ONE launch
+        (lvllm_rope_cache_paged_attention; bit-identical to the three).  None when the shapes are outside the
+        fused kernel's envelope -- nothing was done, the caller runs the separate launches."""
+        if self.alibi_slopes is not None or self.kv_cache_dtype != "auto" or self.decode_version == "v1":
+            return None
+        num_tokens, hidden_size = query.shape
+        md = attn_metadata.decode_metadata
+        max_len = md.max_decode_seq_len
+        scratch = md.decode_scratch or self._v2_scratch(num_tokens, max_len, query)
+        out = torch.empty(num_tokens, self.num_heads, self.head_size, dtype=query.dtype, device=query.device)
+        ok = torch.ops._C_amd.rope_cache_paged_attention(
+            out, scratch[0], scratch[1], scratch[2], positions, query, key, value, self.head_size, cos_sin_cache, True,
+            key_cache, value_cache, attn_metadata.slot_mapping, self.num_kv_heads, self.scale, md.block_tables,
+            md.seq_lens_tensor, value_cache.shape[3], max_len, self.kv_cache_dtype)
+        return out.view(num_tokens, hidden_size) if ok else None
+
     def unified_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                           block_tables: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
                           max_query_len: int) -> torch.Tensor:

@@ -267,7 +267,16 @@ extern "C" int lvllm_paged_attention_v1(
   return 0;
 }
 
-extern "C" int lvllm_paged_attention_v2_phases(
+struct RopeArgs {
+  const int64_t* positions;
+  const void* cos_sin_cache;
+  const void* k_new;
+  const void* v_new;
+  const int64_t* slot_mapping;
+  int64_t k_new_stride, v_new_stride;
+};
+
+static int paged_attention_v2_impl(
     void* out, float* exp_sums, float* max_logits, void* tmp_out,
     const void* query, const void* key_cache, const void* value_cache,
     int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
@@ -277,7 +286,8 @@ extern "C" int lvllm_paged_attention_v2_phases(
     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
-    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream) {
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream,
+    const RopeArgs* rope) {
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
@@ -311,6 +321,12 @@ extern "C" int lvllm_paged_attention_v2_phases(
   p.partitioned = 1; p.scale = scale; p.max_block = max_block;
   p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
   p.kv_fp8 = kv_dtype == LVLLM_KV_FP8_E4M3; p.k_scale = k_scale; p.v_scale = v_scale;
+  if (rope != nullptr) {
+    p.positions = rope->positions; p.cos_sin_cache = rope->cos_sin_cache;
+    p.k_new = rope->k_new; p.v_new = rope->v_new; p.slot_mapping = rope->slot_mapping;
+    p.k_new_stride = rope->k_new_stride; p.v_new_stride = rope->v_new_stride;
+    p.num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_kv_heads * head_size * 2) : INT64_MAX;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int kvb = p.kv_fp8 ? 1 : 2;
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
@@ -377,6 +393,57 @@ extern "C" int lvllm_paged_attention_v2_phases(
 #undef LV_REDUCE
   LV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int lvllm_paged_attention_v2_phases(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions,
+    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int tp_rank, int blocksparse_local_blocks,
+    int blocksparse_vert_stride, int blocksparse_block_size,
+    int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream) {
+  return paged_attention_v2_impl(
+      out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+      head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+      max_num_blocks_per_seq, max_num_partitions, alibi_slopes, q_stride, kv_block_stride,
+      kv_head_stride, dtype, kv_dtype, k_scale, v_scale, tp_rank, blocksparse_local_blocks,
+      blocksparse_vert_stride, blocksparse_block_size, blocksparse_head_sliding_step, kv_cache_bytes, phases,
+      stream, nullptr);
+}
+
+// Extension: one decode step's rotary_embedding (NeoX, rot_dim == head_size) + reshape_and_cache +
+// paged_attention_v2 in ONE launch (plus the reduce pass when contexts are cut into shares).  Returns 3 when
+// the arguments are outside the fused kernel's envelope (nothing was launched: run the three operators).
+extern "C" int lvllm_rope_cache_paged_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key,
+    const void* value, void* key_cache, void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
+    int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, int64_t kv_cache_bytes, void* stream) {
+  const bool ok =
+      (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && kv_dtype == LVLLM_KV_AUTO && is_neox && rot_dim == head_size &&
+      (head_size == 64 || head_size == 128 || head_size == 256) && (block_size == 16 || block_size == 32) &&
+      num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_heads / num_kv_heads <= 16 &&
+      (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache | (uintptr_t)value_cache |
+        (uintptr_t)cos_sin_cache) & 15) == 0 &&
+      q_stride % 8 == 0 && key_stride % 8 == 0 && value_stride % 8 == 0 && kv_block_stride % 8 == 0 &&
+      kv_head_stride % 8 == 0 && max_num_blocks_per_seq > 0 && tuning().attn_splits != -1;
+  if (!ok) {
+    set_error("lvllm_rope_cache_paged_attention: arguments outside the fused kernel's envelope");
+    return 3;
+  }
+  RopeArgs r{positions, cos_sin_cache, key, value, slot_mapping, key_stride, value_stride};
+  return paged_attention_v2_impl(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+                                 num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens, block_size,
+                                 max_seq_len, max_num_blocks_per_seq, max_num_partitions, nullptr, q_stride,
+                                 kv_block_stride, kv_head_stride, dtype, kv_dtype, 1.f, 1.f, 0, 0, 0, 64, 0,
+                                 kv_cache_bytes, 3, stream, &r);
 }
 
 extern "C" int lvllm_paged_attention_v2(

@@ -154,7 +154,8 @@ __device__ __forceinline__ u32x2_t dequant4(uint32_t w, float scale, bool scaled
 // d = 64i + 16g + 8h + e.  A V piece is 4 bytes per lane.  Conversion is v_cvt_pk_f32_fp8 (+ scale)
 // + v_cvt_pk_{bf16,f16}_f32: ~100 vector instructions per tile against ~7 us of HBM time per tile
 // and wave at full bandwidth -- free.
-template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8>
+// ROPE: see AttnParams (rotation of q and the new k, cache write of the new k and v, inside this launch).
+template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8, bool ROPE = false>
 __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
     const AttnParams p) {
   using S = typename T::store_t;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   constexpr int NKL = KV8 ? (D + 63) / 64 : NS;  // K wave loads (16 bytes per lane) per tile
   constexpr int NSQ = KV8 ? 2 * NKL : NS;        // k-slices actually multiplied (fp8: two per load)
   static_assert(!KV8 || D % 16 == 0, "fp8 cache: head size must be a multiple of x = 16");
+  static_assert(!ROPE || (!KV8 && D % 64 == 0), "fused rotation: 16-bit cache, NeoX halves on k-slice boundaries");
   using vraw_t = typename std::conditional<KV8, uint32_t, u32x2_t>::type;  // V piece as loaded
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -218,6 +220,82 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       if (c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
     }
   }
+  // ---- ROPE: rotate Q in registers; one wave rotates the new K, stores K and V to the caches and to LDS ----
+  // NeoX pairs d with d + D/2: chunk j (d = 32j + 8g ..) pairs with chunk j + NS/2 of the SAME lane, and the
+  // cos / sin of both are the 8 values at d mod D/2: the rotation never leaves the lane.
+  S* sm_knew = nullptr;
+  S* sm_vnew = nullptr;
+  bool owns_new_token = false;  // this workgroup's share ends with the step's new token
+  if constexpr (ROPE) {
+    constexpr int DPAD_ = ((D + 15) / 16) * 16;
+    const int nh_l = min(16, G);
+    // stash behind the merge area (the merge starts while other waves may still read the stash)
+    sm_knew = reinterpret_cast<S*>(smem_raw + (size_t)NWAVES * 16 * 2 * sizeof(float) +
+                                   (size_t)NWAVES * nh_l * DPAD_ * sizeof(float));
+    sm_vnew = sm_knew + D;
+    if (seq_len > 0) {
+      const int64_t pos = p.positions[seq];
+      const S* cosp = (const S*)p.cos_sin_cache + pos * D;
+      const S* sinp = cosp + D / 2;
+      auto rot8 = [&](u32x4_t& xv, u32x4_t& yv, const int d0) __attribute__((always_inline)) {
+        const u32x4_t cv = *reinterpret_cast<const u32x4_t*>(cosp + d0);
+        const u32x4_t sv = *reinterpret_cast<const u32x4_t*>(sinp + d0);
+        S* x = reinterpret_cast<S*>(&xv);
+        S* y = reinterpret_cast<S*>(&yv);
+        const S* cc = reinterpret_cast<const S*>(&cv);
+        const S* ss = reinterpret_cast<const S*>(&sv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {  // the arithmetic of pos_encoding.hip rotate<T>, operation for operation
+          const float xf = T::to_float(x[e]), yf = T::to_float(y[e]);
+          const float cf = T::to_float(cc[e]), sf = T::to_float(ss[e]);
+          const float xc = T::to_float(T::from_float(xf * cf));
+          const float ys = T::to_float(T::from_float(yf * sf));
+          const float yc = T::to_float(T::from_float(yf * cf));
+          const float xs = T::to_float(T::from_float(xf * sf));
+          x[e] = T::from_float(__fsub_rn(xc, ys));
+          y[e] = T::from_float(__fadd_rn(yc, xs));
+        }
+      };
+      if (c < nh) {
+#pragma unroll
+        for (int j = 0; j < NS / 2; ++j) rot8(qf[j], qf[j + NS / 2], 32 * j + 8 * g);
+      }
+      owns_new_token = !p.partitioned || t1 == seq_len;
+      if (owns_new_token && wave == 0) {
+        // lanes 0 .. D/16-1: one (x, y) chunk pair of the key row each; lanes 0 .. D/8-1: one chunk of the value row
+        int64_t slot = p.slot_mapping[seq];
+        if (slot >= p.num_slots) slot = -1;
+        const int64_t blk = slot >= 0 ? slot / BS : 0;
+        const int boff = slot >= 0 ? (int)(slot - blk * BS) : 0;
+        if (lane < D / 16) {
+          const S* krow = (const S*)p.k_new + (int64_t)seq * p.k_new_stride + (int64_t)kvh * D;
+          u32x4_t kx = *reinterpret_cast<const u32x4_t*>(krow + 8 * lane);
+          u32x4_t ky = *reinterpret_cast<const u32x4_t*>(krow + D / 2 + 8 * lane);
+          rot8(kx, ky, 8 * lane);
+          *reinterpret_cast<u32x4_t*>(sm_knew + 8 * lane) = kx;
+          *reinterpret_cast<u32x4_t*>(sm_knew + D / 2 + 8 * lane) = ky;
+          if (slot >= 0) {
+            S* kc = (S*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 8;
+            *reinterpret_cast<u32x4_t*>(kc + (int64_t)lane * BS * 8) = kx;
+            *reinterpret_cast<u32x4_t*>(kc + (int64_t)(D / 16 + lane) * BS * 8) = ky;
+          }
+        }
+        if (lane < D / 8) {
+          const S* vrow = (const S*)p.v_new + (int64_t)seq * p.v_new_stride + (int64_t)kvh * D;
+          const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vrow + 8 * lane);
+          *reinterpret_cast<u32x4_t*>(sm_vnew + 8 * lane) = vv;
+          if (slot >= 0) {
+            S* vc = (S*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
+                    (int64_t)(8 * lane) * BS + boff;
+            const S* ve = reinterpret_cast<const S*>(&vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vc[(int64_t)e * BS] = ve[e];
+          }
+        }
+      }
+    }
+    __syncthreads();  // the stash is visible to the wave that owns the last tile
+  }
   const bool k_scaled = KV8 && p.k_scale != 1.f, v_scaled = KV8 && p.v_scale != 1.f;
   const float alibi = (p.alibi_slopes != nullptr && c < nh) ? p.alibi_slopes[head0 + c] : 0.f;
 
@@ -264,8 +342,31 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   };
 
   // One tile: S = K.Q^T (NS MFMAs), online softmax, O^T += V^T.P^T (NDT MFMAs).
-  auto compute_tile = [&](const u32x4_t (&kraw)[NKL], const vraw_t (&v)[NDT], const int j)
+  auto compute_tile = [&](u32x4_t (&kraw)[NKL], vraw_t (&v)[NDT], const int j)
                           __attribute__((always_inline)) {
+    if constexpr (ROPE) {
+      // the tile that ends with the new token: its K chunks and V elements come from the stash, not from the
+      // cache (whose bytes at that slot this launch is only now writing)
+      const int P = seq_len - 1;
+      if (owns_new_token && (tile0 + wave + j * NWAVES) == (P >> 4)) {
+        const int cs = P & 15;
+        if (c == cs) {
+#pragma unroll
+          for (int jj = 0; jj < NS; ++jj)
+            kraw[jj] = *reinterpret_cast<const u32x4_t*>(sm_knew + (4 * jj + g) * 8);
+        }
+        if (g == (cs >> 2)) {
+          const int e = cs & 3;
+#pragma unroll
+          for (int t = 0; t < NDT; ++t) {
+            const uint32_t nv = sm_vnew[16 * t + c];
+            uint32_t w = (e & 2) ? v[t].y : v[t].x;
+            w = (e & 1) ? ((w & 0x0000ffffu) | (nv << 16)) : ((w & 0xffff0000u) | nv);
+            if (e & 2) v[t].y = w; else v[t].x = w;
+          }
+        }
+      }
+    }
     f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (KV8) {
 #pragma unroll
@@ -421,13 +522,20 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   const int nh_lds = G < 16 ? G : 16;
   constexpr int DPAD = ((D + 15) / 16) * 16;
   const size_t smem = (size_t)NWAVES * 16 * 2 * sizeof(float) +
-                      (size_t)NWAVES * nh_lds * DPAD * sizeof(float);
+                      (size_t)NWAVES * nh_lds * DPAD * sizeof(float) +
+                      (p.positions != nullptr ? (size_t)2 * D * 2 : 0);  // ROPE: the new token's k and v
   auto launch = [&](auto kern) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64), smem,
                        stream, p);
   };
+  if constexpr (D % 64 == 0) {
+    if (p.positions != nullptr) {  // fused rotation + cache write (host checked: 16-bit cache, G <= 16)
+      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false, true>);
+      return;
+    }
+  }
   if constexpr (D % 16 == 0) {
     if (p.kv_fp8) {
       launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true>);

@@ -36,6 +36,16 @@ struct AttnParams {
   // k > q - local_blocks ("local"), k / q = the block-sparse block of the cache block / of the
   // query, offset = (tp_rank * heads + head) * sliding_step + 1 (kv heads for a negative step).
   int bs_vert_stride, bs_local_blocks, bs_block_size, bs_head_sliding_step, tp_rank;
+  // ROPE instantiation (decode step, one new token per sequence): the kernel rotates q and the new k itself
+  // (NeoX pairing, rot_dim == head size, arithmetic and roundings of pos_encoding.hip's rotate<T>), writes the
+  // rotated k and v into the paged caches at slot_mapping[seq], and attends to them from registers: the
+  // launches rotary_embedding + reshape_and_cache + paged_attention in one, bit for bit.
+  const int64_t* positions;     // [num_seqs]
+  const void* cos_sin_cache;    // [max_pos, head_size] = [cos | sin]
+  const void* k_new;            // [num_seqs, num_kv_heads, D], row stride k_new_stride (NOT rotated in place)
+  const void* v_new;            // [num_seqs, num_kv_heads, D], row stride v_new_stride
+  const int64_t* slot_mapping;  // [num_seqs]; < 0 or beyond the caches: nothing is written
+  int64_t k_new_stride, v_new_stride, num_slots;
 };
 
 __host__ __device__ inline bool blocksparse_attended(const AttnParams& p, int token, int seq_len, int head,

@@ -459,6 +459,44 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
   return true;
 }
 
+// returns false when the arguments are outside the fused kernel's envelope (nothing was done)
+bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, torch::Tensor& max_logits,
+                                torch::Tensor& tmp_out, const torch::Tensor& positions, const torch::Tensor& query,
+                                const torch::Tensor& key, const torch::Tensor& value, int64_t head_size,
+                                const torch::Tensor& cos_sin_cache, bool is_neox, torch::Tensor& key_cache,
+                                torch::Tensor& value_cache, const torch::Tensor& slot_mapping, int64_t num_kv_heads,
+                                double scale, const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
+                                int64_t block_size, int64_t max_seq_len, const std::string& kv_cache_dtype) {
+  LV_CHECK_DEVICE(query);
+  TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
+  TORCH_CHECK(query.dim() == 2 && key.dim() == 2 && value.dim() == 2, "query / key / value must be [tokens, heads * head_size]");
+  TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt,
+              "block_tables / seq_lens must be int32");
+  TORCH_CHECK(out.is_contiguous() && tmp_out.is_contiguous() && exp_sums.is_contiguous() && max_logits.is_contiguous());
+  const int kv_code = kv_dtype_code(kv_cache_dtype);
+  check_cache_dtype(key_cache, query, kv_code, "rope_cache_paged_attention");
+  check_cache_dtype(value_cache, query, kv_code, "rope_cache_paged_attention");
+  const int64_t num_seqs = query.numel() / query.size(-1);
+  const int64_t num_heads = query.size(-1) / head_size;
+  TORCH_CHECK(key.size(-1) == num_kv_heads * head_size && value.size(-1) == num_kv_heads * head_size);
+  TORCH_CHECK(out.numel() == num_seqs * num_heads * head_size);
+  TORCH_CHECK(positions.numel() >= num_seqs && slot_mapping.numel() >= num_seqs && seq_lens.numel() >= num_seqs &&
+              block_tables.size(0) >= num_seqs);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
+  const int rc = lvllm_rope_cache_paged_attention(
+      out.data_ptr(), exp_sums.data_ptr<float>(), max_logits.data_ptr<float>(), tmp_out.data_ptr(), query.data_ptr(),
+      key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs, (int)num_heads,
+      (int)head_size, (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(), seq_lens.data_ptr<int32_t>(),
+      positions.data_ptr<int64_t>(), slot_mapping.data_ptr<int64_t>(), cos_sin_cache.data_ptr(),
+      (int)cos_sin_cache.size(1), is_neox ? 1 : 0, (int)block_size, (int)max_seq_len, (int)block_tables.size(1),
+      (int)exp_sums.size(-1), query.stride(-2), key.stride(-2), value.stride(-2), key_cache.stride(0),
+      key_cache.stride(1), dtype_code(query, "rope_cache_paged_attention"), kv_code,
+      cache_extent_bytes(key_cache, value_cache), current_stream(query));
+  if (rc == 3) return false;
+  check(rc);
+  return true;
+}
+
 void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, const torch::Tensor& key_cache,
                              const torch::Tensor& value_cache, int64_t num_kv_heads, double scale,
                              const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
@@ -862,6 +900,12 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.impl("skinny_linear_w8a8_swiglu", torch::kCUDA, &skinny_linear_w8a8_swiglu);
   amd.def("skinny_linear_w8a8_argmax(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K) -> Tensor");
   amd.impl("skinny_linear_w8a8_argmax", torch::kCUDA, &skinny_linear_w8a8_argmax);
+  amd.def("rope_cache_paged_attention(Tensor! out, Tensor! exp_sums, Tensor! max_logits, Tensor! tmp_out, "
+          "Tensor positions, Tensor query, Tensor key, Tensor value, int head_size, Tensor cos_sin_cache, "
+          "bool is_neox, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, int num_kv_heads, "
+          "float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, "
+          "str kv_cache_dtype) -> bool");
+  amd.impl("rope_cache_paged_attention", torch::kCUDA, &rope_cache_paged_attention);
   amd.def("advance_step_logged(int block_size, Tensor! input_tokens, Tensor sampled_token_ids, "
           "Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables, "
           "Tensor! token_log) -> ()");

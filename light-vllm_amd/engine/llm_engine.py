@@ -187,7 +187,9 @@ class Worker:
                                 for _ in range(self.num_slots)]
 
     @torch.inference_mode()
-    def execute(self, execute_input: ExecuteInput, slot: int = 0) -> ExecuteOutput:
+    def execute(self, execute_input: ExecuteInput, slot: int = 0, sampling=None) -> ExecuteOutput:
+        """`sampling`: a callable (sample_seq_ids) -> SamplingBatch for steps in which some request is not
+        plain greedy: the logits of the sampled rows then go through the sampler's front half."""
         wi, mi = execute_input.worker_input, execute_input.model_input
         ce = self.cache_engine
         if wi.blocks_to_swap_in.numel() > 0:
@@ -204,9 +206,15 @@ class Worker:
             g = graphs.get(mi.input_tokens.shape[0])
             g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor)
             tokens = g.replay()[:mi.input_tokens.shape[0]]
+            rows = None
             if len(mi.sample_indices) != mi.input_tokens.shape[0]:
-                tokens = tokens[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
-        elif (graphs is not None and self.mixed_graph_tokens > 0 and not self.capture_logits
+                rows = torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)
+                tokens = tokens[rows]
+            if sampling is not None:  # the captured step's hidden states -> logits -> sampler
+                hidden = g.hidden[:mi.input_tokens.shape[0]]
+                logits = self.model.compute_logits(hidden if rows is None else hidden[rows])
+                tokens = sampling(mi.sample_seq_ids).sample(logits)
+        elif (graphs is not None and self.mixed_graph_tokens > 0 and not self.capture_logits and sampling is None
               and mi.input_tokens.shape[0] <= self.mixed_graph_tokens
               and md.seq_lens_tensor.shape[0] <= self.mixed_graph_seqs
               and md.block_tables.shape[0] == md.seq_lens_tensor.shape[0]
@@ -223,7 +231,7 @@ class Worker:
             logits = self.model.compute_logits(hidden)
             if self.capture_logits:
                 self.last_logits = logits.float().cpu()
-            tokens = torch.argmax(logits, dim=-1)
+            tokens = torch.argmax(logits, dim=-1) if sampling is None else sampling(mi.sample_seq_ids).sample(logits)
         out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, mi.sample_seq_ids)
@@ -343,6 +351,7 @@ class LLMEngine:
         # the engine thread polls the steps' events instead of being woken by a waiter thread (+2 % tokens/s;
         # LVLLM_POLL_COMPLETION=0 brings the per-slot waiter threads back)
         self.poll_completion = os.environ.get("LVLLM_POLL_COMPLETION", "1") != "0"
+        self._sampler_generator = torch.Generator(device=self.device).manual_seed(seed)
         self._pending: List[Tuple[int, torch.cuda.Event, SchedulerOutput, ExecuteOutput]] = []
         self._last_event: Dict[int, Optional[torch.cuda.Event]] = {}  # latest step of each slot
         self._fence: Optional[torch.cuda.Event] = None                # latest block-moving step (see _launch)
@@ -361,10 +370,15 @@ class LLMEngine:
         torch.cuda.synchronize(self.device)
 
     # ---- requests ----
-    def add_request(self, request_id: str, prompt_token_ids: List[int], max_tokens: int = 16) -> None:
+    def add_request(self, request_id: str, prompt_token_ids: List[int], max_tokens: Optional[int] = 16,
+                    sampling_params=None) -> None:
+        """`sampling_params` (engine/sampling_params.py): None = plain greedy with `max_tokens`; otherwise its
+        max_tokens / stop_token_ids / ignore_eos are the stop criteria and its other fields drive the sampler."""
         seq = Sequence(self.seq_counter, list(prompt_token_ids), self.cache_config.block_size, self.eos_token_id)
         self.seq_counter += 1
-        g = SequenceGroup(request_id, [seq], time.time(), max_tokens=max_tokens)
+        if sampling_params is not None:
+            max_tokens = sampling_params.max_tokens
+        g = SequenceGroup(request_id, [seq], time.time(), max_tokens=max_tokens, sampling_params=sampling_params)
         self.groups[request_id] = g
         self.seq_to_group[seq.seq_id] = g
         self.scheduler.add_request(g)
@@ -388,7 +402,9 @@ class LLMEngine:
             for tok in tok_of[seq.seq_id]:
                 seq.data.update_num_computed_tokens(1)
                 seq.append_token_id(tok, 0.0)
-                if eos is not None and tok == eos:
+                sp = g.sampling_params
+                if (eos is not None and tok == eos and not (sp is not None and sp.ignore_eos)) or \
+                        (sp is not None and tok in sp.stop_token_ids):
                     seq.status = SequenceStatus.FINISHED_STOPPED
                 elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
                     seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
@@ -433,7 +449,9 @@ class LLMEngine:
                 seq.data.update_num_computed_tokens(s.token_chunk_size)
                 tok = tok_of[seq.seq_id]
                 seq.append_token_id(tok, 0.0)
-                if self.eos_token_id is not None and tok == self.eos_token_id:
+                sp = g.sampling_params
+                if ((self.eos_token_id is not None and tok == self.eos_token_id and not (sp is not None and sp.ignore_eos))
+                        or (sp is not None and tok in sp.stop_token_ids)):
                     seq.status = SequenceStatus.FINISHED_STOPPED
                 elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
                     seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
@@ -454,7 +472,9 @@ class LLMEngine:
                     continue  # a prompt chunk that sampled nothing
                 tok = tok_of[seq.seq_id]
                 seq.append_token_id(tok, 0.0)
-                if self.eos_token_id is not None and tok == self.eos_token_id:
+                sp = g.sampling_params
+                if ((self.eos_token_id is not None and tok == self.eos_token_id and not (sp is not None and sp.ignore_eos))
+                        or (sp is not None and tok in sp.stop_token_ids)):
                     seq.status = SequenceStatus.FINISHED_STOPPED
                 elif g.max_tokens is not None and seq.get_output_len() >= g.max_tokens:
                     seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
@@ -499,6 +519,9 @@ class LLMEngine:
     def _execute(self, sched: SchedulerOutput, slot: int) -> ExecuteOutput:
         """Decode-only steps go from the scheduler's metadata to the captured graph directly; every
         other step through the general input builder."""
+        sampling = self._sampling_for(sched)
+        if sampling is not None:
+            return self.worker.execute(self.input_builder(sched), slot, sampling=sampling)
         if self.fast_decode_inputs:
             from .input_builder import DecodeStepArrays, MixedStepArrays
             plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
@@ -513,6 +536,26 @@ class LLMEngine:
                 if out is not None:
                     return out
         return self.worker.execute(self.input_builder(sched), slot)
+
+    def _sampling_for(self, sched: SchedulerOutput):
+        """None when every request of the step is plain greedy (the captured arg-max serves it); otherwise a
+        factory of the step's SamplingBatch, called by the worker with the sequence ids of the sampled rows."""
+        if not any(s.seq_group.sampling_params is not None and not s.seq_group.sampling_params.plain_greedy
+                   for s in sched.scheduled_seq_groups):
+            return None
+        from ..sampling import SamplingBatch
+
+        def make(sample_seq_ids):
+            rows = []
+            for sid in sample_seq_ids:
+                g = self.seq_to_group[sid]
+                seq = g.seqs_dict[sid]
+                rows.append(dict(params=g.sampling_params, prompt=seq.prompt_token_ids,
+                                 output=seq.get_output_token_ids(), eos=self.eos_token_id))
+            batch = SamplingBatch(rows, self.model_config.vocab_size, self.device, self._sampler_generator)
+            batch._steps = [len(r["output"]) for r in rows]
+            return batch
+        return make
 
     def _burst_steps(self, sched: SchedulerOutput) -> int:
         """Model steps a decode-only step runs on the device before it returns to the host: the configured

@@ -77,6 +77,7 @@ _CALIBRATING = False
 _STREAM_GEMM_MAX_ROWS = int(os.environ.get("LVLLM_STREAM_GEMM_MAX_ROWS", "256"))
 _ARGMAX_EPILOGUE = os.environ.get("LVLLM_ARGMAX_EPILOGUE", "1") != "0"  # A/B switch
 _SWIGLU_EPILOGUE = os.environ.get("LVLLM_SWIGLU_EPILOGUE", "1") != "0"  # A/B switch
+_ROPE_IN_ATTENTION = os.environ.get("LVLLM_ROPE_IN_ATTENTION", "1") != "0"  # A/B switch
 
 
 def build_cos_sin_cache(head_dim: int, max_pos: int, base: float, dtype, device) -> torch.Tensor:
@@ -206,13 +207,20 @@ class DecoderModel:
             qkv = linear(hidden, lw.qkv, lw.qkv_bias)
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)  # strided views
             fused = False
+            attn_out = None
             if decode_only:
                 key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
-            if decode_only:
+            if decode_only and unified is None and _ROPE_IN_ATTENTION and hasattr(self.attn, "rope_cache_decode_attention"):
+                # rope + cache write + attention in one launch (bit-identical to the three)
+                attn_out = self.attn.rope_cache_decode_attention(positions, q, k, v, self.cos_sin_cache, key_cache,
+                                                                 value_cache, attn_metadata)
+            if decode_only and attn_out is None:
                 fused = torch.ops._C_amd.rotary_embedding_and_cache(
                     positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
                     slot_mapping, self.attn.kv_cache_dtype, 1.0, 1.0)
-            if unified is not None:
+            if attn_out is not None:
+                pass
+            elif unified is not None:
                 assert fused, "a captured mixed step needs the fused rope + cache write"
                 attn_out = self.attn.unified_attention(q, key_cache, value_cache, unified[0], unified[1],
                                                        unified[2], unified[3])

@@ -193,8 +193,11 @@ class SequenceGroup:
     """Sequences generated from one prompt (sequence.py:397-575)."""
 
     def __init__(self, request_id: str, seqs: List[Sequence], arrival_time: float = 0.0,
-                 max_tokens: Optional[int] = None, n: int = 1) -> None:
+                 max_tokens: Optional[int] = None, n: int = 1, sampling_params=None) -> None:
         self.request_id = request_id
+        # None or plain greedy: the captured step's arg-max; otherwise the sampler's front half runs on the
+        # logits of this group's rows (engine/sampling_params.py, sampling.py)
+        self.sampling_params = sampling_params
         self.seqs = seqs
         self.seqs_dict: Dict[int, Sequence] = {s.seq_id: s for s in seqs}
         self.arrival_time = arrival_time

@@ -4,9 +4,9 @@ penalties from the token histories, temperature, top-k, top-p, min-p, then greed
 exponential-race multinomial.  Torch ops on the device, as in the reference (no custom kernel there
 either); formulated independently (descending order, cumulative mass from the top) and checked
 against golden outputs of the reference functions (tests/golden/sampler_front_half.npz).
-The engine of this package samples greedily inside the captured step; this module serves hosts that
-want the other modes."""
-from typing import Optional
+The engine samples plain-greedy requests inside the captured step (arg-max epilogue of the lm_head
+projection); requests with any other SamplingParams go through `SamplingBatch` below."""
+from typing import List, Optional
 
 import torch
 
@@ -90,3 +90,65 @@ def sample(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None, top
         x = apply_min_p(x, min_p)
     drawn = random_sample(torch.softmax(x, dim=-1), generator)
     return torch.where(temperature > 0, drawn, greedy)
+
+
+class SamplingBatch:
+    """Per-row sampling state of one step (the job of SamplingMetadata / SamplingTensors in the reference,
+    decoding/backends/sampling_metadata.py): one row per sequence that samples, in the order of the step's
+    sampled rows.  `sample(logits)` is Sampler.forward's sequence (sampler.py:90-200): min-tokens mask ->
+    penalties -> temperature -> top-k / top-p -> min-p -> softmax -> draw, greedy rows by arg-max."""
+
+    def __init__(self, rows: List[dict], vocab_size: int, device, generator: Optional[torch.Generator] = None):
+        """rows[i]: dict(params=SamplingParams | None, prompt=[token ids], output=[token ids], eos=int | None)."""
+        from .engine.sampling_params import SamplingParams
+        self.n, self.vocab_size, self.device, self.generator = len(rows), vocab_size, device, generator
+        ps = [r["params"] or SamplingParams(temperature=0.0) for r in rows]
+        f = lambda vals, dt=torch.float32: torch.tensor(vals, dtype=dt, device=device)
+        self.temperature = f([p.temperature for p in ps])
+        self.top_p = f([p.top_p for p in ps])
+        self.top_k = f([vocab_size if p.top_k == -1 else min(p.top_k, vocab_size) for p in ps], torch.long)
+        self.min_p = f([p.min_p for p in ps])
+        self.presence, self.frequency = f([p.presence_penalty for p in ps]), f([p.frequency_penalty for p in ps])
+        self.repetition = f([p.repetition_penalty for p in ps])
+        self.do_penalties = any(p.presence_penalty != 0.0 or p.frequency_penalty != 0.0 or p.repetition_penalty != 1.0
+                                for p in ps)
+        self.do_top = any(p.top_p < 1.0 or p.top_k != -1 for p in ps)
+        self.do_min_p = any(p.min_p > 0.0 for p in ps)
+        self.all_greedy = all(p.greedy for p in ps)
+        self.seeds = [p.seed for p in ps]
+        if self.do_penalties:  # padded histories, pad id = vocab_size (sampler.py:_get_bin_counts_and_mask)
+            lp = max(1, max(len(r["prompt"]) for r in rows))
+            lo = max(1, max(len(r["output"]) for r in rows))
+            self.prompt = f([list(r["prompt"]) + [vocab_size] * (lp - len(r["prompt"])) for r in rows], torch.long)
+            self.output = f([list(r["output"]) + [vocab_size] * (lo - len(r["output"])) for r in rows], torch.long)
+        # min_tokens: stop tokens cannot be sampled before min_tokens outputs exist (sampler.py:238-277)
+        self.banned = [(i, t) for i, (p, r) in enumerate(zip(ps, rows)) if p.min_tokens > len(r["output"])
+                       for t in set(p.stop_token_ids) | ({r["eos"]} if r.get("eos") is not None and not p.ignore_eos else set())]
+
+    def sample(self, logits: torch.Tensor) -> torch.Tensor:
+        assert logits.shape[0] == self.n
+        x = logits.float()
+        if self.banned:
+            rows, toks = zip(*self.banned)
+            x[list(rows), list(toks)] = float("-inf")
+        if self.do_penalties:
+            x = apply_penalties(x, self.prompt, self.output, self.presence, self.frequency, self.repetition)
+        greedy = greedy_sample(x)
+        if self.all_greedy:
+            return greedy
+        t = torch.where(self.temperature > 0, self.temperature, torch.ones_like(self.temperature))
+        x = x / t[:, None]
+        if self.do_top:
+            x = apply_top_k_top_p(x, self.top_p, self.top_k)
+        if self.do_min_p:
+            x = apply_min_p(x, self.min_p)
+        probs = torch.softmax(x, dim=-1)
+        drawn = random_sample(probs, self.generator)
+        for i, seed in enumerate(self.seeds):  # a seeded request draws from its own stream (sampler.py:479-493)
+            if seed is not None:
+                g = torch.Generator(device=probs.device).manual_seed(seed + int(self._step_of(i)))
+                drawn[i] = random_sample(probs[i:i + 1], g)[0]
+        return torch.where(self.temperature > 0, drawn, greedy)
+
+    def _step_of(self, i: int) -> int:
+        return self._steps[i] if hasattr(self, "_steps") else 0

@@ -22,7 +22,7 @@ def load_bench():
 
 
 def args(**kw):
-    d = dict(steps=64, warmup=16, num_scheduler_steps=8, on_the_fly=2, scheduling="async", gpus=1)
+    d = dict(steps=64, warmup=16, num_scheduler_steps=8, on_the_fly=2, scheduling="async", gpus=1)  # two in flight
     d.update(kw)
     return types.SimpleNamespace(**d)
 
@@ -83,7 +83,7 @@ def check_line(d, batch):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # (avg_launch_us is printed with two decimals: allow for that on launches of a few microseconds)
-    tol = max(2e-3, 0.006 / r["avg_launch_us"])
+    tol = max(2e-3, 0.006 / r["avg_launch_us"], 0.06 / r["achieved"])  # ... and `achieved` with one
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < tol
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5
     assert "single pass" in r["kernel"] or "partition pass" in r["kernel"]

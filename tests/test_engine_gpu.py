@@ -518,3 +518,69 @@ def test_async_steps_with_swaps_and_prefix_caching_are_ordered_on_the_device(pre
     assert got == want
     if not prefix_caching:
         assert preempted > 0, "the pool was meant to be too small: nothing was swapped"
+
+
+# ------------------------------------------------------------------ sampler front half in the engine
+def test_engine_sampling_params_drive_the_sampler():
+    """Requests with SamplingParams leave the captured arg-max: seeded requests draw the same tokens under the
+    captured step, the eager step and two steps in flight; a repetition penalty changes the greedy continuation; a
+    seeded request repeats itself whatever else is in the batch; stop_token_ids / ignore_eos / min_tokens are honoured;
+    plain requests in the same batch keep their greedy tokens."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    ps = prompts()
+    greedy = run_to_completion(make_engine(graph=True), max_tokens=12)
+
+    def run(param_list, graph=True, eos=None, use_async=False, scheduling="sync"):
+        e = make_engine(graph=graph, scheduling=scheduling)
+        e.eos_token_id = eos
+        for i, p in enumerate(ps):
+            e.add_request(str(i), p, max_tokens=12, sampling_params=param_list[i])
+        final = {}
+        step = e.async_step if use_async else e.step
+        for _ in range(1000):
+            for out in step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not e.has_unfinished_requests() and e.num_on_the_fly == 0:
+                break
+        e.shutdown()
+        return [final[str(i)] for i in range(len(ps))]
+
+    # temperature 0 through SamplingParams is the captured arg-max
+    assert run([SamplingParams(temperature=0.0, max_tokens=12) for _ in ps]) == greedy
+    # every request sampled from its own seeded stream: the captured step draws the same tokens sync and with two
+    # steps in flight (same kernels, same padded batch, same noise).  The eager step pads differently (6 rows, not
+    # 8: attention cuts its contexts into a different number of shares), so its logits differ in the last bits and
+    # a draw may flip: it must agree on the prompt step's token, which both take through the same eager launches.
+    seeded = [SamplingParams(temperature=0.9, top_k=20, top_p=0.95, seed=100 + i, max_tokens=12) for i in range(len(ps))]
+    s_graph = run(seeded)
+    assert s_graph == run(seeded, use_async=True, scheduling="async")
+    assert s_graph == run(seeded)
+    s_eager = run(seeded, graph=False)
+    assert [t[0] for t in s_eager] == [t[0] for t in s_graph] and all(len(t) == 12 for t in s_eager)
+    assert s_graph != greedy and all(len(t) == 12 for t in s_graph)
+    # mixed batch: request 0 sampled with a seed, the rest plain greedy (None)
+    mixed = [SamplingParams(temperature=1.0, top_p=0.9, seed=5, max_tokens=12)] + [None] * (len(ps) - 1)
+    a, b = run(mixed), run(mixed, graph=False)
+    assert a[1:] == greedy[1:] and b[1:] == greedy[1:]
+    assert a[0][0] == b[0][0] and len(a[0]) == 12 and len(b[0]) == 12
+    alone = [SamplingParams(temperature=1.0, top_p=0.9, seed=5, max_tokens=12)] + \
+            [SamplingParams(temperature=1.3, seed=i, max_tokens=12) for i in range(1, len(ps))]
+    assert run(alone)[0] == a[0]
+    # a strong repetition penalty forbids what greedy repeats
+    rep = run([SamplingParams(temperature=0.0, repetition_penalty=2.0, max_tokens=12) for _ in ps])
+    assert rep != greedy
+    assert all(len(set(t)) >= len(set(g_)) for t, g_ in zip(rep, greedy))
+    # stop_token_ids: request 1 stops at its 4th greedy token; ignore_eos runs through an EOS that stops the others
+    stop_tok = greedy[1][3]
+    stops = [SamplingParams(temperature=0.0, max_tokens=12, stop_token_ids=[stop_tok] if i == 1 else []) for i in range(len(ps))]
+    out = run(stops)
+    assert out[1] == greedy[1][:greedy[1].index(stop_tok) + 1]
+    eos = greedy[2][5]
+    ign = [SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=(i == 2)) for i in range(len(ps))]
+    out = run(ign, eos=eos)
+    assert out[2] == greedy[2]
+    # min_tokens: the EOS cannot appear among the first 8 tokens
+    mt = [SamplingParams(temperature=0.0, max_tokens=12, min_tokens=8) for _ in ps]
+    out = run(mt, eos=eos)
+    assert all(eos not in t[:8] for t in out)

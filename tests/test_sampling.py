@@ -50,3 +50,72 @@ def test_sample_modes():
     draws = sampling.random_sample(probs, torch.Generator().manual_seed(2))
     freq = torch.bincount(draws, minlength=3).float() / 20000
     assert torch.allclose(freq, probs[0], atol=0.02)
+
+
+# ---- SamplingBatch: the sampler's order of operations on one step's rows (CPU) ----
+def _params(**kw):
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    return SamplingParams(**kw)
+
+
+def test_sampling_batch_follows_the_reference_order_of_operations():
+    """penalties -> temperature -> top-k / top-p -> min-p -> softmax -> draw (sampler.py:90-200), each stage
+    against the golden outputs of the reference's own functions."""
+    import numpy as np
+    import os
+    from light_vllm_amd.sampling import SamplingBatch, apply_penalties, apply_top_k_top_p
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_front_half.npz"))
+    logits = torch.from_numpy(z["logits"])
+    N, V = logits.shape
+    prompt, output = z["prompt"], z["output"]
+    rows = []
+    for i in range(N):
+        rows.append(dict(params=_params(temperature=0.0, presence_penalty=float(z["pres"][i]),
+                                        frequency_penalty=float(z["freq"][i]), repetition_penalty=float(z["rep"][i])),
+                         prompt=[t for t in prompt[i].tolist() if t < V], output=[t for t in output[i].tolist() if t < V],
+                         eos=None))
+    b = SamplingBatch(rows, V, "cpu")
+    # greedy with penalties = arg-max of the reference's penalised logits
+    assert b.sample(logits.clone()).tolist() == torch.from_numpy(z["penalised"]).argmax(-1).tolist()
+    # top-k = 1 at any temperature is the arg-max of the (unpenalised) logits
+    rows1 = [dict(params=_params(temperature=0.7, top_k=1), prompt=[], output=[], eos=None) for _ in range(N)]
+    assert SamplingBatch(rows1, V, "cpu").sample(logits.clone()).tolist() == logits.argmax(-1).tolist()
+    # draws only land on tokens the reference's top-k / top-p filter keeps
+    rows2 = [dict(params=_params(temperature=1.0, top_p=float(z["top_p"][i]), top_k=int(z["top_k"][i]) if z["top_k"][i] < V else -1),
+                  prompt=[], output=[], eos=None) for i in range(N)]
+    keep = torch.from_numpy(z["filtered"]) > float("-inf")
+    g = torch.Generator().manual_seed(0)
+    for _ in range(50):
+        drawn = SamplingBatch(rows2, V, "cpu", g).sample(logits.clone())
+        assert keep[torch.arange(N), drawn].all()
+
+
+def test_sampling_batch_min_tokens_seed_and_greedy_rows():
+    from light_vllm_amd.sampling import SamplingBatch
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(4, 50, generator=g)
+    eos = int(logits[0].argmax())
+    rows = [dict(params=_params(temperature=0.0, min_tokens=3), prompt=[1], output=[2], eos=eos),   # eos banned
+            dict(params=_params(temperature=0.0, min_tokens=1), prompt=[1], output=[2], eos=int(logits[1].argmax())),
+            dict(params=_params(temperature=1.0, seed=11), prompt=[1], output=[2, 3], eos=None),
+            dict(params=None, prompt=[1], output=[], eos=None)]
+    b = SamplingBatch(rows, 50, "cpu", torch.Generator().manual_seed(1))
+    b._steps = [1, 1, 2, 0]
+    out = b.sample(logits.clone())
+    assert out[0] != eos and out[0] == logits[0].topk(2).indices[1]   # the runner-up
+    assert out[1] == logits[1].argmax() and out[3] == logits[3].argmax()
+    # a seeded row repeats whatever the shared generator did before
+    b2 = SamplingBatch(rows, 50, "cpu", torch.Generator().manual_seed(999))
+    b2._steps = [1, 1, 2, 0]
+    assert b2.sample(logits.clone())[2] == out[2]
+
+
+def test_sampling_params_validation_and_greedy_normalisation():
+    import pytest
+    p = _params(temperature=0.0, top_p=0.5, top_k=7, min_p=0.3)
+    assert p.greedy and p.plain_greedy and (p.top_p, p.top_k, p.min_p) == (1.0, -1, 0.0)
+    assert not _params(temperature=0.0, repetition_penalty=1.2).plain_greedy
+    for bad in (dict(temperature=-1), dict(top_p=0.0), dict(top_k=0), dict(min_p=1.5), dict(repetition_penalty=0.0),
+                dict(presence_penalty=3.0), dict(max_tokens=0)):
+        with pytest.raises(ValueError):
+            _params(**bad)

@@ -189,3 +189,76 @@ def test_argmax_epilogue_gives_torch_argmax_of_the_projection(ops, dtype, M, N, 
     first = (logits == logits.max(dim=-1, keepdim=True).values).float().argmax(-1)
     assert torch.equal(tokens, first)
     assert torch.equal(first, want), "torch.argmax no longer returns the first maximal index on this backend"
+
+
+# ------------------------------------------------ rope + cache write inside the attention launch
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # S, H, KVH, D, BS, lens (context INCLUDING the step's new token), forced shares
+    (5, 32, 8, 128, 16, [1024, 1, 17, 512, 700], 0),
+    (4, 8, 2, 128, 32, [300, 33, 64, 1], 0),
+    (3, 4, 4, 64, 16, [100, 2050, 16], 0),       # long context: the library cuts shares by itself
+    (3, 16, 1, 256, 16, [40, 700, 129], 0),      # GQA 16
+    (6, 8, 2, 128, 16, [1500, 16, 17, 1, 0, 999], 3),  # forced shares; an empty padding row (slot -1)
+    (2, 14, 2, 128, 16, [77, 513], 2),           # GQA 7
+], ids=["metric", "bs32", "d64_long", "d256_gqa16", "forced3_padding", "gqa7"])
+def test_rope_cache_attention_in_one_launch_is_bit_identical(ops, dtype, case):
+    """rope_cache_paged_attention == rotary_embedding + reshape_and_cache + paged_attention_v2 (qwen2.py:151-154 +
+    paged_attn.py:65-85,87-191), bit for bit: attention output, key cache, value cache -- every byte, the
+    untouched blocks included."""
+    S, H, KVH, D, BS, lens, forced = case
+    from helpers import make_paged_inputs, v2_scratch
+    inp = make_paged_inputs(S, H, KVH, D, BS, [max(n, 1) for n in lens], dtype=dtype, seed=S * 3 + D)
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(S, (H + 2 * KVH) * D, generator=g) * 0.5).to(dtype).to(DEV)
+    max_pos = 4096
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(max_pos).float(), inv)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(DEV)
+    seq_lens = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    positions = (seq_lens.long() - 1).clamp_min(0)
+    bt = inp["block_tables"].to(DEV)
+    slots = torch.tensor([int(inp["block_tables"][i, (n - 1) // BS]) * BS + (n - 1) % BS if n > 0 else -1
+                          for i, n in enumerate(lens)], dtype=torch.int64, device=DEV)
+    max_len = max(lens)
+    scale = D ** -0.5
+    torch.ops._C_amd.set_tuning("attn_splits", forced)
+    try:
+        results = []
+        for fused in (False, True):
+            kc, vc = inp["key_cache"].to(DEV).clone(), inp["value_cache"].to(DEV).clone()
+            x = qkv.clone()
+            q, k, v = x.split([H * D, KVH * D, KVH * D], dim=-1)
+            es, ml, tmp = v2_scratch(S, H, D, max_len, dtype, DEV)
+            out = torch.zeros(S, H, D, dtype=dtype, device=DEV)
+            if fused:
+                ok = torch.ops._C_amd.rope_cache_paged_attention(out, es, ml, tmp, positions, q, k, v, D, cos_sin, True,
+                                                                 kc, vc, slots, KVH, scale, bt, seq_lens, BS, max_len,
+                                                                 "auto")
+                assert ok
+            else:
+                ops.rotary_embedding(positions, q, k, D, cos_sin, True)
+                ops.reshape_and_cache(k.view(S, KVH, D), v.view(S, KVH, D), kc, vc, slots, "auto", 1.0, 1.0)
+                ops.paged_attention_v2(out, es, ml, tmp, q.view(S, H, D), kc, vc, KVH, scale, bt, seq_lens, BS,
+                                       max_len, None, "auto", 1.0, 1.0)
+            results.append((out, kc, vc))
+    finally:
+        torch.ops._C_amd.set_tuning("attn_splits", 0)
+    (o0, k0, v0), (o1, k1, v1) = results
+    assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    assert torch.equal(o0, o1), (o0.float() - o1.float()).abs().max()
+
+
+def test_rope_cache_attention_declines_outside_its_envelope(ops):
+    S, H, KVH, D, BS = 2, 4, 2, 80, 16  # head size 80: the NeoX halves do not fall on k-slice boundaries
+    q = torch.zeros(S, H * D, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros(S, KVH * D, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(4, KVH, D // 8, BS, 8, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros(4, KVH, D, BS, dtype=torch.bfloat16, device=DEV)
+    es = torch.zeros(S, H, 1, device=DEV)
+    ok = torch.ops._C_amd.rope_cache_paged_attention(
+        torch.zeros(S, H, D, dtype=torch.bfloat16, device=DEV), es, es.clone(), torch.zeros(S, H, 1, D, dtype=torch.bfloat16, device=DEV),
+        torch.zeros(S, dtype=torch.int64, device=DEV), q, k, k.clone(), D, torch.zeros(16, D, dtype=torch.bfloat16, device=DEV), True,
+        kc, vc, torch.zeros(S, dtype=torch.int64, device=DEV), KVH, 0.1, torch.zeros(S, 2, dtype=torch.int32, device=DEV),
+        torch.ones(S, dtype=torch.int32, device=DEV), BS, 16, "auto")
+    assert ok is False
