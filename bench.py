@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--library-gemm", action="store_true", help="dense projections through hipBLASLt (F.linear)")
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
+    ap.add_argument("--no-rope-in-attention", action="store_true",
+                    help="rope + cache write as their own launch in front of attention (A/B of the fused kernel)")
+    ap.add_argument("--gemm-workgroups", type=int, default=None,
+                    help="workgroups per decode GEMM launch (default: 256 for one stream, 128 for several)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-ops-baseline", action="store_true", help="no per-op GPU / CPU timings of the small operators")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
@@ -390,6 +394,7 @@ def main():
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
     cfg.fuse_decode_ops = not a.no_fusion
+    cfg.rope_in_attention = not a.no_rope_in_attention
     cfg.quantization = a.quantization
     total_steps = a.steps + a.warmup
     max_len = ctx + (total_steps + a.steps) // min(on_the_fly, 2) + 2 * k_max + 8
@@ -400,7 +405,7 @@ def main():
                        SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
                                        max_model_len=max_model_len, scheduling=a.scheduling,
                                        max_num_on_the_fly=on_the_fly, use_v2_block_manager=k_max > 1,
-                                       num_scheduler_steps=k_max),
+                                       num_scheduler_steps=k_max, gemm_workgroups=a.gemm_workgroups),
                        device=dev, use_hip_graph=not a.no_graph,
                        decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
     engine.step_returns_outputs = False

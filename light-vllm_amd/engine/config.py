@@ -23,6 +23,11 @@ class ModelConfig:
     dtype: torch.dtype = torch.bfloat16
     pack_weights: bool = True       # keep an MFMA-ordered copy of each projection for decode
     fuse_decode_ops: bool = True    # rope+cache write in one launch, split-K sum inside add+norm
+    # the individual fused launches of a decode step (each bit-identical to what it replaces; off = A/B runs)
+    rope_in_attention: bool = True  # rotary_embedding + reshape_and_cache inside the attention launch
+    swiglu_epilogue: bool = True    # silu_and_mul in the gate_up projection's epilogue
+    argmax_epilogue: bool = True    # greedy arg-max in the lm_head projection's epilogue
+    stream_gemm_max_rows: int = 256  # 65..this many rows: projections through lvllm_stream_gemm where it wins
     # "fp8": W8A8 projections (BASELINE config 5): per-tensor e4m3 weights, static per-tensor
     # activation scales calibrated once on a random batch (the reference's activation_scheme="static")
     quantization: Optional[str] = None
@@ -71,6 +76,11 @@ class SchedulerConfig:
     # them, csrc/prepare_inputs/advance_step.cu) and returns to the host once; needs the lookahead slots
     # for the tokens in between, hence the v2 block manager (v1 refuses lookahead, block_manager_v1.py:353-355)
     num_scheduler_steps: int = 1
+    # workgroups of a decode GEMM (lvllm_set_tuning "gemm_workgroups"): None = 256 for one stream, 128 when
+    # steps run side by side on several streams (each GEMM then leaves CUs to the other steps' kernels)
+    gemm_workgroups: Optional[int] = None
+    fast_decode_inputs: bool = True   # decode / mixed steps staged straight from the scheduler's metadata
+    poll_completion: bool = True      # the engine thread polls the steps' events (False: per-slot waiter threads)
 
     def __post_init__(self) -> None:
         if self.num_scheduler_steps < 1:

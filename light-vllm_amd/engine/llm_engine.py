@@ -6,7 +6,6 @@ flight, legal because scheduled groups are marked busy).
 One engine = one GPU (replica).  Multi-GPU serving replicates engines, one process per GPU,
 with no collective on the kernel path.
 """
-import os
 import queue
 import threading
 import time
@@ -313,7 +312,7 @@ class LLMEngine:
         # path was fixed a lone 128-workgroup GEMM is as fast as a 256-workgroup one and the setting
         # is worth +-1.5 %: profiles/r01_tuning.md)
         concurrent = self.num_slots > 1 and scheduler_config.scheduling != "simple_async"
-        gemm_wgs = int(os.environ.get("LVLLM_ENGINE_GEMM_WGS", "0")) or (128 if concurrent else 256)
+        gemm_wgs = scheduler_config.gemm_workgroups or (128 if concurrent else 256)
         self.gemm_workgroups = gemm_wgs
         torch.ops._C_amd.set_tuning("gemm_workgroups", gemm_wgs)
         num_gpu, num_cpu = cache_config.num_gpu_blocks, cache_config.num_cpu_blocks
@@ -347,10 +346,10 @@ class LLMEngine:
         self._done_qs: List["queue.Queue"] = [queue.Queue() for _ in range(self.num_slots)]
         self.executor_out: "queue.Queue" = queue.Queue()
         self.num_on_the_fly = 0
-        self.fast_decode_inputs = os.environ.get("LVLLM_FAST_DECODE_INPUTS", "1") != "0"
+        self.fast_decode_inputs = scheduler_config.fast_decode_inputs
         # the engine thread polls the steps' events instead of being woken by a waiter thread (+2 % tokens/s;
-        # LVLLM_POLL_COMPLETION=0 brings the per-slot waiter threads back)
-        self.poll_completion = os.environ.get("LVLLM_POLL_COMPLETION", "1") != "0"
+        # SchedulerConfig.poll_completion = False brings the per-slot waiter threads back)
+        self.poll_completion = scheduler_config.poll_completion
         self._sampler_generator = torch.Generator(device=self.device).manual_seed(seed)
         self._pending: List[Tuple[int, torch.cuda.Event, SchedulerOutput, ExecuteOutput]] = []
         self._last_event: Dict[int, Optional[torch.cuda.Event]] = {}  # latest step of each slot

@@ -7,7 +7,6 @@ Follows light_vllm/decode_only/modelzoo/qwen2.py:144-292: per layer
 Dense projections are plain torch GEMMs (hipBLASLt / MFMA); everything else is a gfx950
 kernel of this package.  Weights are random-initialised: no checkpoint is available offline.
 """
-import os
 from typing import List, Optional
 
 import torch
@@ -74,10 +73,7 @@ def linear(x: torch.Tensor, w: "Weight", bias: Optional[torch.Tensor] = None) ->
 
 
 _CALIBRATING = False
-_STREAM_GEMM_MAX_ROWS = int(os.environ.get("LVLLM_STREAM_GEMM_MAX_ROWS", "256"))
-_ARGMAX_EPILOGUE = os.environ.get("LVLLM_ARGMAX_EPILOGUE", "1") != "0"  # A/B switch
-_SWIGLU_EPILOGUE = os.environ.get("LVLLM_SWIGLU_EPILOGUE", "1") != "0"  # A/B switch
-_ROPE_IN_ATTENTION = os.environ.get("LVLLM_ROPE_IN_ATTENTION", "1") != "0"  # A/B switch
+_STREAM_GEMM_MAX_ROWS = 256  # set from ModelConfig.stream_gemm_max_rows by DecoderModel
 
 
 def build_cos_sin_cache(head_dim: int, max_pos: int, base: float, dtype, device) -> torch.Tensor:
@@ -112,6 +108,8 @@ class DecoderModel:
     def __init__(self, cfg: ModelConfig, attn_impl, device="cuda:0", seed: int = 0):
         self.cfg = cfg
         self.device = torch.device(device)
+        global _STREAM_GEMM_MAX_ROWS
+        _STREAM_GEMM_MAX_ROWS = cfg.stream_gemm_max_rows
         gen = torch.Generator(device=self.device).manual_seed(seed)
         self.embed = (torch.randn(cfg.vocab_size, cfg.hidden_size, generator=gen, device=self.device) * 0.02).to(cfg.dtype)
         self.layers: List[DecoderLayerWeights] = [DecoderLayerWeights(cfg, self.device, gen)
@@ -210,7 +208,7 @@ class DecoderModel:
             attn_out = None
             if decode_only:
                 key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
-            if decode_only and unified is None and _ROPE_IN_ATTENTION and hasattr(self.attn, "rope_cache_decode_attention"):
+            if decode_only and unified is None and cfg.rope_in_attention and hasattr(self.attn, "rope_cache_decode_attention"):
                 # rope + cache write + attention in one launch (bit-identical to the three)
                 attn_out = self.attn.rope_cache_decode_attention(positions, q, k, v, self.cos_sin_cache, key_cache,
                                                                  value_cache, attn_metadata)
@@ -237,11 +235,11 @@ class DecoderModel:
             else:
                 hidden = linear(attn_out, lw.o)
             hidden = self._add_norm(hidden, residual, lw.post_norm)
-            if (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.w8_packed is not None and lw.gate_up.N % 32 == 0
+            if (decode_only and cfg.swiglu_epilogue and lw.gate_up.w8_packed is not None and lw.gate_up.N % 32 == 0
                     and T <= 64):
                 g = lw.gate_up
                 act = torch.ops._C_amd.skinny_linear_w8a8_swiglu(hidden, g.w8_packed, g.w_scale, g.x_scale, g.N, g.K, None)
-            elif (decode_only and _SWIGLU_EPILOGUE and lw.gate_up.packed is not None and lw.gate_up.N % 32 == 0
+            elif (decode_only and cfg.swiglu_epilogue and lw.gate_up.packed is not None and lw.gate_up.N % 32 == 0
                     and not _CALIBRATING):
                 # gate_up projection with silu_and_mul in its epilogue: one launch, no [T, 2 inter] round trip
                 act = torch.ops._C_amd.skinny_linear_packed_swiglu(hidden, lw.gate_up.packed, None,
@@ -265,8 +263,8 @@ class DecoderModel:
         """argmax of the logits, [T] int64.  Decode batches take it from the lm_head projection's
         epilogue (no [T, vocab] tensor, no separate arg-max launch; same tokens as the two ops)."""
         w = self.lm_head
-        if _ARGMAX_EPILOGUE and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.packed is not None:
+        if self.cfg.argmax_epilogue and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.packed is not None:
             return torch.ops._C_amd.skinny_linear_packed_argmax(hidden, w.packed, w.N, w.K)
-        if _ARGMAX_EPILOGUE and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.w8_packed is not None:
+        if self.cfg.argmax_epilogue and 0 < hidden.shape[0] <= 64 and hidden.is_cuda and w.w8_packed is not None:
             return torch.ops._C_amd.skinny_linear_w8a8_argmax(hidden, w.w8_packed, w.w_scale, w.x_scale, w.N, w.K)
         return torch.argmax(self.compute_logits(hidden), dim=-1)

@@ -7,7 +7,6 @@ Attention is this package's HIP varlen kernel (AttentionType.ENCODER); the resid
 behind it are one launch (`_C_amd.add_layer_norm`; the reference leaves both to torch),
 exact GELU is an in-place kernel of this package too; the projections are library GEMMs (prompt batches are hundreds to thousands of rows).
 Weights are random-initialised: no checkpoint is available offline."""
-import os
 from dataclasses import dataclass
 from typing import List
 
@@ -16,7 +15,6 @@ import torch.nn.functional as F
 
 from ..attention.prefill_only import AttentionType, PrefillOnlyHIPVarlenBackend
 
-_FUSED_LN = os.environ.get("LVLLM_FUSED_LAYER_NORM", "1") != "0"  # A/B switch
 
 
 @dataclass
@@ -30,6 +28,7 @@ class EncoderConfig:
     layer_norm_eps: float = 1e-5
     pad_token_id: int = 1
     dtype: torch.dtype = torch.bfloat16
+    fused_layer_norm: bool = True  # residual add + LayerNorm in one launch (lvllm_add_layer_norm); off = A/B runs
 
     @property
     def head_dim(self) -> int:
@@ -91,7 +90,7 @@ class EncoderModel:
         # xlm_roberta.py: position ids start after the padding index
         x = (F.embedding(input_ids, self.word_emb) + F.embedding(positions + cfg.pad_token_id + 1, self.pos_emb)
              + self.type_emb[0])
-        fused = x.is_cuda and hid % 8 == 0 and x.dtype in (torch.bfloat16, torch.float16) and _FUSED_LN
+        fused = x.is_cuda and hid % 8 == 0 and x.dtype in (torch.bfloat16, torch.float16) and self.cfg.fused_layer_norm
 
         def add_ln(a, b, ln):  # LayerNorm(a + b), b optional
             if fused:

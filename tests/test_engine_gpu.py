@@ -53,12 +53,14 @@ def dense_reference_logits(model, token_ids):
 
 def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048,
                 cache_dtype="auto", quantization=None, v2=False, prefix_caching=False, preemption_mode=None,
-                num_scheduler_steps=1, max_model_len=512):
+                num_scheduler_steps=1, max_model_len=512, stream_gemm_max_rows=None):
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
     cfg = ModelConfig.tiny()
     cfg.quantization = quantization
+    if stream_gemm_max_rows is not None:
+        cfg.stream_gemm_max_rows = stream_gemm_max_rows
     return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32,
                                       cache_dtype=cache_dtype, enable_prefix_caching=prefix_caching),
                      SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=max_model_len,
@@ -409,8 +411,7 @@ def test_decode_batches_of_65_to_128_rows_take_the_stream_gemm(monkeypatch):
     reqs = [torch.randint(0, 512, (int(torch.randint(2, 40, (1,), generator=g)),), generator=g).tolist() for _ in range(96)]
 
     def run(stream_rows):
-        monkeypatch.setattr(model_mod, "_STREAM_GEMM_MAX_ROWS", stream_rows)
-        e = make_engine(graph=True, num_blocks=1024, max_seqs=96, budget=4096)
+        e = make_engine(graph=True, num_blocks=1024, max_seqs=96, budget=4096, stream_gemm_max_rows=stream_rows)
         for i, p in enumerate(reqs):
             e.add_request(str(i), p, max_tokens=6)
         final = {}

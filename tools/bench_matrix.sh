@@ -1,0 +1,22 @@
+# The bench line of the tree and its A/B settings, one box (numbers of different boxes differ by +-3 %).
+ulimit -c 0
+O=gpurun_out/r02_matrix; mkdir -p $O
+run() { name=$1; shift; python bench.py "$@" > $O/$name.json 2> $O/$name.err; python -c "
+import json; d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1])
+o=d.get('other_settings',{}).get('max_num_on_the_fly=2',{})
+print('%-28s %8.1f tok/s  %.4f ms/step   (2 in flight: %s)' % ('$name', d['value'], d['ms_per_step'], o.get('value')))"; }
+run default
+run on_the_fly_2 --on-the-fly 2 --skip-cpu-baseline --skip-ops-baseline
+run on_the_fly_4 --on-the-fly 4 --skip-cpu-baseline --skip-ops-baseline
+run single_step --num-scheduler-steps 1 --skip-cpu-baseline --skip-ops-baseline
+run single_step_2 --num-scheduler-steps 1 --on-the-fly 2 --skip-cpu-baseline --skip-ops-baseline
+run no_rope_in_attention --no-rope-in-attention --skip-cpu-baseline --skip-ops-baseline
+run no_fusion --no-fusion --skip-cpu-baseline --skip-ops-baseline
+run library_gemm --library-gemm --skip-cpu-baseline --skip-ops-baseline
+run sync --scheduling sync --skip-cpu-baseline --skip-ops-baseline
+run fp8_kv --kv-cache-dtype fp8 --skip-cpu-baseline --skip-ops-baseline
+run fp8_w8a8 --quantization fp8 --skip-cpu-baseline --skip-ops-baseline
+run fp8_both --quantization fp8 --kv-cache-dtype fp8 --skip-cpu-baseline --skip-ops-baseline
+run bs64 --batch-size 64 --skip-cpu-baseline --skip-ops-baseline
+run ctx4096 --context 4096 --skip-cpu-baseline --skip-ops-baseline
+python tools/bench_chunked_prefill.py 2>&1 | grep -v amdgpu | tail -3
