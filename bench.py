@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--skip-ops-baseline", action="store_true", help="no per-op GPU / CPU timings of the small operators")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
+    ap.add_argument("--replica-backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend of the barrier / clock between replicas (default: nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="plumbing check of the N > 1 launch on a one-GPU box: every rank uses cuda:0 (needs "
+                         "--replica-backend gloo: RCCL refuses two ranks on one device)")
     return ap.parse_args()
 
 
@@ -374,7 +379,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_replicas(a))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = f"cuda:{local_rank}"
+    dev = "cuda:0" if a.single_device else f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
 
     import light_vllm_amd  # noqa: F401
@@ -383,7 +388,7 @@ def main():
     from light_vllm_amd.engine.replicas import ReplicaGroup
 
     # one process per GPU; RCCL is used for the barrier and the max-over-ranks clock only
-    group = ReplicaGroup(device=torch.device(dev))
+    group = ReplicaGroup(backend=a.replica_backend, device=torch.device(dev))
     rank, world = group.rank, group.world_size
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU"
 

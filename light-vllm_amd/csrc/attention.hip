@@ -43,6 +43,10 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
   const S* kc = (const S*)p.k_cache + (int64_t)kvh * p.kv_head_stride;
   const S* vc = (const S*)p.v_cache + (int64_t)kvh * p.kv_head_stride;
   const float alibi = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+  // 16-byte accesses when the layout allows them (caches, strides and blocks on 16-byte boundaries)
+  const bool vec16 = head_size % X == 0 && block_size % X == 0 &&
+                     ((((uintptr_t)p.k_cache | (uintptr_t)p.v_cache) & 15) == 0) &&
+                     (p.kv_block_stride * sizeof(S)) % 16 == 0 && (p.kv_head_stride * sizeof(S)) % 16 == 0;
 
   const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)head * head_size;
   for (int d = threadIdx.x; d < head_size; d += blockDim.x) qs[d] = T::to_float(qrow[d]);
@@ -61,8 +65,17 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
       const int off = tok % block_size;
       const S* kb = kc + bn * p.kv_block_stride + off * X;
       float dot = 0.f;
-      for (int d = 0; d < head_size; ++d)
-        dot += qs[d] * T::to_float(kb[(d / X) * block_size * X + (d % X)]);
+      if (vec16) {  // one 16-byte chunk (X head-dim values of this token) per load
+        for (int dx = 0; dx < head_size / X; ++dx) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(kb + (int64_t)dx * block_size * X);
+          const S* ke = reinterpret_cast<const S*>(&raw);
+#pragma unroll
+          for (int e = 0; e < X; ++e) dot += qs[dx * X + e] * T::to_float(ke[e]);
+        }
+      } else {
+        for (int d = 0; d < head_size; ++d)
+          dot += qs[d] * T::to_float(kb[(d / X) * block_size * X + (d % X)]);
+      }
       float x = dot * p.scale;
       x += (alibi != 0.f) ? alibi * (float)(tok - seq_len + 1) : 0.f;
       // a token of a block this head does not attend: logit -FLT_MAX, no contribution
@@ -91,14 +104,41 @@ __global__ __launch_bounds__(256) void paged_attn_generic_kernel(const AttnParam
     o0 *= alpha;
     o1 *= alpha;
     __syncthreads();
-    for (int tok = cs; tok < ce; ++tok) {
-      const int64_t bn = min((uint32_t)block_table[tok / block_size], (uint32_t)p.max_block);
-      const int off = tok % block_size;
-      const S* vb = vc + bn * p.kv_block_stride + off;
-      const float pr = logits[tok - cs];
+    if (vec16) {
+      // a thread owns V rows d0 (and d1): per cache block it reads the row's block_size tokens as 16-byte
+      // pieces (the row of a block is contiguous) instead of one element per token
       const int d0 = threadIdx.x, d1 = threadIdx.x + 256;
-      if (d0 < head_size) o0 += pr * T::to_float(vb[(int64_t)d0 * block_size]);
-      if (d1 < head_size) o1 += pr * T::to_float(vb[(int64_t)d1 * block_size]);
+      for (int bstart = (cs / block_size) * block_size; bstart < ce; bstart += block_size) {
+        const int64_t bn = min((uint32_t)block_table[bstart / block_size], (uint32_t)p.max_block);
+        const S* vb = vc + bn * p.kv_block_stride;
+        for (int o = 0; o < block_size; o += X) {
+          const int tok = bstart + o;
+          if (tok + X <= cs || tok >= ce) continue;
+          uint4 r0 = uint4{0, 0, 0, 0}, r1 = uint4{0, 0, 0, 0};
+          if (d0 < head_size) r0 = *reinterpret_cast<const uint4*>(vb + (int64_t)d0 * block_size + o);
+          if (d1 < head_size) r1 = *reinterpret_cast<const uint4*>(vb + (int64_t)d1 * block_size + o);
+          const S* e0 = reinterpret_cast<const S*>(&r0);
+          const S* e1 = reinterpret_cast<const S*>(&r1);
+#pragma unroll
+          for (int e = 0; e < X; ++e) {
+            const int t = tok + e;
+            if (t < cs || t >= ce) continue;  // V beyond the context may hold anything: never multiplied
+            const float pr = logits[t - cs];
+            o0 += pr * T::to_float(e0[e]);
+            o1 += pr * T::to_float(e1[e]);
+          }
+        }
+      }
+    } else {
+      for (int tok = cs; tok < ce; ++tok) {
+        const int64_t bn = min((uint32_t)block_table[tok / block_size], (uint32_t)p.max_block);
+        const int off = tok % block_size;
+        const S* vb = vc + bn * p.kv_block_stride + off;
+        const float pr = logits[tok - cs];
+        const int d0 = threadIdx.x, d1 = threadIdx.x + 256;
+        if (d0 < head_size) o0 += pr * T::to_float(vb[(int64_t)d0 * block_size]);
+        if (d1 < head_size) o1 += pr * T::to_float(vb[(int64_t)d1 * block_size]);
+      }
     }
     __syncthreads();
   }
@@ -251,7 +291,7 @@ extern "C" int lvllm_paged_attention_v1(
   const int kvb = p.kv_fp8 ? 1 : 2;
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
                       (q_stride * 2) % 16 == 0 && (kv_block_stride * kvb) % 16 == 0 &&
-                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 16;
+                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 8;
   LV_CHECK(!p.kv_fp8 || vec_ok, "fp8 kv cache: operands must be 16-byte aligned");
   int rc = 0;
   // block-sparse requests take the generic kernel (per-head masks; a niche of the reference's op)
@@ -331,7 +371,7 @@ static int paged_attention_v2_impl(
   const int kvb = p.kv_fp8 ? 1 : 2;
   const bool vec_ok = (((uintptr_t)query | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15) == 0 &&
                       (q_stride * 2) % 16 == 0 && (kv_block_stride * kvb) % 16 == 0 &&
-                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 16;
+                      (kv_head_stride * kvb) % 16 == 0 && block_size >= 8;
   LV_CHECK(!p.kv_fp8 || vec_ok, "fp8 kv cache: operands must be 16-byte aligned");
   // How many equal shares each context is cut into.  The reference always cuts at 512
   // tokens; here the cut exists only to fill the GPU: with >= 8 waves per CU from

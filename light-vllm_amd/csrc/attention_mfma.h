@@ -161,7 +161,8 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   using S = typename T::store_t;
   LVLLM_TRACE_BEGIN();
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
-  static_assert(BS == 16 || BS == 32, "one tile must lie inside one block");
+  static_assert(BS == 8 || BS == 16 || BS == 32, "a 16-token tile is one block, half a block, or two 8-token blocks");
+  static_assert(BS != 8 || (!KV8 && !ROPE), "8-token blocks: 16-bit caches, separate rope / cache-write launches");
   static_assert(NBUF >= 1 && NBUF <= 3, "register sets per wave");
   constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
   constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
@@ -205,8 +206,14 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   const int64_t bsb = p.kv_block_stride * KVB;
 
   // per-lane byte offsets inside a (block, kv head) region
-  const int koff = (g * BS + c) * 16;      // K chunk (d8 = g (+4j), token c)
-  const int voff = (c * BS + 4 * g) * KVB;  // V piece (row c (+16t), tokens 4g..4g+3)
+  // BS == 8: a tile is TWO blocks (tokens 0-7 | 8-15).  Every load is issued once per block with the lanes of the
+  // other block pushed out of the descriptor's range (they fetch nothing and return zeros) and the two results
+  // are OR-ed: the in-range lanes of each issue still read 512 (K) / 256 (V) contiguous bytes.
+  constexpr int kOut = 0x40000000;  // beyond any (block, head) region
+  const int koff = BS == 8 ? (g * 8 + (c & 7)) * 16 : (g * BS + c) * 16;  // K chunk (d8 = g (+4j), token c)
+  const int voff = BS == 8 ? (c * 8 + ((4 * g) & 7)) * KVB : (c * BS + 4 * g) * KVB;  // V piece (row c (+16t), tokens 4g..4g+3)
+  const bool in_a = BS != 8 || c < 8;    // K: this lane's token lies in the tile's first block
+  const bool vin_a = BS != 8 || g < 2;   // V: this lane's 4 tokens lie in the tile's first block
 
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
   u32x4_t qf[NSQ];
@@ -304,9 +311,15 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   // The index is clamped by the table width (a kernel argument), not by the sequence length,
   // so the first block-table loads do not wait for the seq_lens load.
   const int last_block = p.max_num_blocks_per_seq - 1;
-  auto block_number = [&](const int j) __attribute__((always_inline)) -> int {
+  // (BS == 8: two numbers per tile, packed low | high)
+  auto block_number = [&](const int j) __attribute__((always_inline)) -> int64_t {
     const int blk = ((tile0 + wave + j * NWAVES) << 4) / BS;
-    return (int)min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
+    const uint32_t a = min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
+    if constexpr (BS == 8) {
+      const uint32_t b = min((uint32_t)block_table[min(blk + 1, last_block)], (uint32_t)p.max_block);
+      return (int64_t)(((uint64_t)b << 32) | a);
+    }
+    return (int64_t)a;
   };
 
   // running softmax state of this wave: column c of lanes (g, c) is head head0 + c
@@ -316,11 +329,11 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 #pragma unroll
   for (int t = 0; t < NDT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto load_tile = [&](u32x4_t (&k)[NKL], vraw_t (&v)[NDT], const int j, const int bn32)
+  auto load_tile = [&](u32x4_t (&k)[NKL], vraw_t (&v)[NDT], const int j, const int64_t bnp)
                        __attribute__((always_inline)) {
     const int lt = wave + j * NWAVES;
     const bool valid = j < nmy;
-    const int64_t bn = bn32;
+    const int64_t bn = (int64_t)(uint32_t)bnp;
     const int tok_base = (tile0 + lt) << 4;
     const int off = (BS == 32) ? (tok_base & 16) : 0;  // second half of a 32-token block
     __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
@@ -329,6 +342,28 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
         (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
     // chunks past the head size and rows with d >= D fall outside kHeadBytes -> zeros
     // (a chunk is 16 bytes of one token in both cache types: 8 T or 16 fp8)
+    if constexpr (BS == 8) {
+      const int64_t bn2 = (int64_t)((uint64_t)bnp >> 32);
+      __amdgpu_buffer_rsrc_t kr2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(kbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+      __amdgpu_buffer_rsrc_t vr2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(vbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+      const int ka = in_a ? koff : kOut, kb = in_a ? kOut : koff;
+      const int va = vin_a ? voff : kOut, vb = vin_a ? kOut : voff;
+#pragma unroll
+      for (int jj = 0; jj < NKL; ++jj) {
+        const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(kr, ka + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
+        const u32x4_t y = __builtin_amdgcn_raw_buffer_load_b128(kr2, kb + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
+        k[jj] = x | y;
+      }
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(vr, va + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
+        const u32x2_t y = __builtin_amdgcn_raw_buffer_load_b64(vr2, vb + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
+        v[t] = x | y;
+      }
+      return;
+    }
 #pragma unroll
     for (int jj = 0; jj < NKL; ++jj)
       k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
@@ -430,7 +465,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   {
     u32x4_t k0[NKL], k1[NKL], k2[NKL];
     vraw_t v0[NDT], v1[NDT], v2[NDT];
-    int bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
+    int64_t bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
     load_tile(k0, v0, 0, bn0);
     bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
     if constexpr (NBUF == 3) {
@@ -530,13 +565,13 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
     hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64), smem,
                        stream, p);
   };
-  if constexpr (D % 64 == 0) {
+  if constexpr (D % 64 == 0 && BS != 8) {
     if (p.positions != nullptr) {  // fused rotation + cache write (host checked: 16-bit cache, G <= 16)
       launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false, true>);
       return;
     }
   }
-  if constexpr (D % 16 == 0) {
+  if constexpr (D % 16 == 0 && BS != 8) {
     if (p.kv_fp8) {
       launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true>);
       return;
@@ -569,6 +604,10 @@ static int launch_mfma_bs(const AttnParams& p, int block_size, int num_seqs, int
     case 16: launch_mfma_waves<T, D, 16>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
 #ifndef LVLLM_ATTN_TUNE_ONLY
     case 32: launch_mfma_waves<T, D, 32>(p, num_seqs, num_parts, max_tokens_per_wg, stream); break;
+    case 8:
+      LV_CHECK(!p.kv_fp8 && p.positions == nullptr, "8-token blocks: 16-bit caches, no fused rotation");
+      launch_mfma_waves<T, D, 8>(p, num_seqs, num_parts, max_tokens_per_wg, stream);
+      break;
 #endif
     default: LV_CHECK(false, "Unsupported block size: " + std::to_string(block_size));
   }
@@ -576,7 +615,7 @@ static int launch_mfma_bs(const AttnParams& p, int block_size, int num_seqs, int
 }
 
 // block sizes the MFMA kernel covers (8-token blocks go to the generic kernel)
-inline bool mfma_block_size(int bs) { return bs == 16 || bs == 32; }
+inline bool mfma_block_size(int bs) { return bs == 8 || bs == 16 || bs == 32; }
 
 template <typename T>
 int launch_mfma_hs(const AttnParams& p, int head_size, int block_size, int num_seqs,

@@ -30,6 +30,8 @@ class ReplicaGroup:
                 kw = {"device_id": self.device} if backend == "nccl" else {}
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world_size, **kw)
             self._dist = dist
+            if dist.get_backend() == "gloo":  # gloo reduces host tensors
+                self.device = torch.device("cpu")
 
     def barrier(self) -> None:
         if self._dist is not None:

@@ -118,3 +118,23 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
     ops = line["ops_baseline"]["ops"]
     assert set(ops) == {"reshape_and_cache", "rms_norm", "fused_add_rms_norm", "rotary_embedding", "silu_and_mul"}
     assert all(v["gpu_us"] > 0 and v["cpu_us"] > 0 for v in ops.values())
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_ranks_and_sums_them():
+    """`python bench.py --gpus 2` as ONE plain process: it starts two ranks through torch.distributed.run, they
+    meet at the barriers, the slowest clock and the summed tokens make one line with n_gpus = 2.  On a one-GPU box
+    both ranks share cuda:0 and the process group is gloo (RCCL refuses two ranks on one device); everything else
+    is the path the driver's multi-GPU run takes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tiny", "--steps", "16",
+                        "--warmup", "8", "--batch-size", "8", "--context", "64", "--kernel-iters", "64",
+                        "--replica-backend", "gloo", "--single-device"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"].startswith("dp2")
+    check_line(d, 8)  # value = 2 ranks x 8 sequences per step / the slowest rank's time
+    assert d["cpu_baseline"] is None  # rank 0 times the CPU baseline at N = 1 only

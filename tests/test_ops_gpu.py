@@ -233,7 +233,10 @@ ATTN_CASES = [
     (2, 4, 2, 120, 16, [200, 3]),
     (2, 4, 1, 192, 16, [90, 511]),
     (2, 4, 2, 256, 32, [600, 2]),
-    (3, 8, 2, 128, 8, [77, 8, 530]),           # 8-token blocks -> generic kernel
+    (3, 8, 2, 128, 8, [77, 8, 530]),           # 8-token blocks: a 16-token tile spans two blocks (fp32: generic kernel)
+    (4, 32, 8, 128, 8, [1024, 1000, 9, 1]),    # the metric's grouping on 8-token blocks
+    (2, 28, 4, 80, 8, [333, 15]),              # padded head size, 7 q heads per kv head
+    (2, 4, 4, 256, 8, [130, 7]),
     (2, 8, 2, 128, 32, [1025, 31]),
     (1, 32, 8, 128, 16, [4099]),               # long context: v1 with 8 waves, v2 with 9 partitions
 ]
@@ -358,17 +361,26 @@ def test_paged_attention_edge_cases(ops):
     o2 = run_v2(ops, dinp)[0]
     assert (o1[0] == 0).all() and (o1[2] == 0).all() and (o2[0] == 0).all() and (o2[2] == 0).all()
     check_attention(o1[1:2], oracle_v1(inp)[1:2])
-    # slots past the context hold NaN: they must not leak (attention_kernels.cu:420-430)
-    inp = make_paged_inputs(2, 8, 2, 128, 16, [37, 520], dtype=torch.bfloat16, seed=12)
-    for s, n in enumerate([37, 520]):
-        blk = inp["block_tables"][s, n // 16].long()
-        inp["value_cache"][blk, :, :, n % 16:] = float("nan")
-        inp["key_cache"][blk, :, :, n % 16:, :] = float("nan")
-    exp = dense_attention_fp64(inp)
-    dinp = to_dev(inp)
-    for out in (run_v1(ops, dinp), run_v2(ops, dinp)[0]):
-        assert torch.isfinite(out).all()
-        check_attention(out, exp.to(torch.bfloat16), exp)
+    # slots past the context hold NaN: they must not leak (attention_kernels.cu:420-430); with 8-token blocks the
+    # tile's second block may lie wholly past the context (its table entry is padding): NaN there too
+    for BS in (16, 8):
+        inp = make_paged_inputs(2, 8, 2, 128, BS, [37, 520], dtype=torch.bfloat16, seed=12)
+        for s, n in enumerate([37, 520]):
+            if n % BS == 0:
+                continue  # the context ends on a block boundary: no partly used block
+            blk = inp["block_tables"][s, n // BS].long()
+            inp["value_cache"][blk, :, :, n % BS:] = float("nan")
+            inp["key_cache"][blk, :, :, n % BS:, :] = float("nan")
+        used = {int(b) for s, n in enumerate([37, 520]) for b in inp["block_tables"][s, :(n + BS - 1) // BS]}
+        for b in range(inp["key_cache"].shape[0]):  # every block no context reaches (table entries past the
+            if b not in used:                        # context point at some of them) holds NaN as well
+                inp["value_cache"][b] = float("nan")
+                inp["key_cache"][b] = float("nan")
+        exp = dense_attention_fp64(inp)
+        dinp = to_dev(inp)
+        for out in (run_v1(ops, dinp), run_v2(ops, dinp)[0]):
+            assert torch.isfinite(out).all()
+            check_attention(out, exp.to(torch.bfloat16), exp)
     # a spike that forces the running max to jump late in the context (online-softmax rescale)
     inp = make_paged_inputs(1, 4, 1, 128, 16, [800], dtype=torch.bfloat16, seed=13)
     q = inp["query"]

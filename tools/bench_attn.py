@@ -25,7 +25,9 @@ def main():
     ap.add_argument("--kv", default="auto", choices=["auto", "fp8"])
     a = ap.parse_args()
     dev = "cuda:0"
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    esz = 4 if a.dtype == "f32" else 2
+    x = 16 // esz
     B, H, KVH, D, BS, L = a.bs, a.heads, a.kv_heads, a.head_size, a.block_size, a.seq
     nblk = (L + BS - 1) // BS
     NB = B * nblk + 7
@@ -36,7 +38,7 @@ def main():
             kc = (torch.randn(NB, KVH, D // 16, BS, 16, device=dev) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
             vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
         else:
-            kc = (torch.randn(NB, KVH, D // 8, BS, 8, device=dev) * 0.5).to(dt)
+            kc = (torch.randn(NB, KVH, D // x, BS, x, device=dev) * 0.5).to(dt)
             vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(dt)
         bt = torch.randperm(NB, device=dev)[: B * nblk].view(B, nblk).to(torch.int32)
         caches.append((kc, vc, bt))
@@ -48,8 +50,8 @@ def main():
     es = torch.zeros(B, H, P, dtype=torch.float32, device=dev)
     ml = torch.zeros_like(es)
     scale = 1 / math.sqrt(D)
-    kvb = 1 if a.kv == "fp8" else 2
-    algo_bytes = 2 * B * L * KVH * D * kvb + 2 * B * H * D * 2 + B * nblk * 4 + B * 4
+    kvb = 1 if a.kv == "fp8" else esz
+    algo_bytes = 2 * B * L * KVH * D * kvb + 2 * B * H * D * esz + B * nblk * 4 + B * 4
 
     def v1(i):
         kc, vc, bt = caches[i % a.ncaches]
