@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: decode tokens/s at Llama-3-8B shapes, bs=32, context ~1k, bf16, through
 the engine's async decoding scheduler (BASELINE.json configs[1]), plus the HBM roofline of the
-dominant hot-path kernel (paged_attention_v2's partition pass) and a CPU baseline.
+dominant hot-path kernel (paged_attention_v2's pass over the paged KV cache) and CPU baselines.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: launched by the driver through torch.distributed.run, or -- started as one plain process --
+      launching its own N ranks that way (one rank per GPU, independent replicas)
 
-A "step" is one engine step: the scheduler admits one batch of 32 decoding sequences (two such
-batches are in flight, `max_num_on_the_fly=2`, the reference's default for async scheduling; each
-runs on its own stream as in the reference's async_execute_loop, core/executor.py:62-93, so host
-scheduling and one step's launch gaps / kernel ramps overlap the other step's kernels), the
-block manager appends one slot per sequence, the step's inputs are built, and the captured HIP
-graph of the 32-layer decode forward (+ lm_head + greedy argmax) is replayed.  Every rank is an independent replica with its own weights, KV cache and scheduler
-(replicas only, no collective on the data path); `value` is the sum over ranks.
+A "step" is one MODEL step: 32 decoding sequences go through the 32-layer forward, lm_head and greedy
+arg-max (a captured HIP graph) and get one token each.  The scheduler admits one batch of 32 per engine step
+(`max_num_seqs`), `max_num_on_the_fly = 2` engine steps are in flight (the reference's default for async
+scheduling and the setting BASELINE.md section 4 quotes the headline on; each on its own stream as in the
+reference's async_execute_loop, core/executor.py:62-93), and an engine step is a burst of `--num-scheduler-steps`
+model steps chained on the device by advance_step over lookahead slots of the block manager.  The timed region
+holds exactly K model steps with an empty pipeline on both sides.  Every rank is an independent replica with its
+own weights, KV cache and scheduler (replicas only, no collective on the data path); `value`
+is the sum over ranks.
 
-Output: ONE JSON line on rank 0 (contract in the task description; roofline / cpu_baseline
-objects described in DESIGN.md §Measurement).
+Output: ONE JSON line on rank 0 (contract in the task description; roofline / cpu_baseline / ops_baseline /
+other_settings objects described in DESIGN.md section 5).
 """
 import argparse
 import ctypes
@@ -45,10 +49,14 @@ def parse():
                     help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
     ap.add_argument("--quantization", default=None, choices=["fp8"],
                     help="non-default runs only: W8A8 projections (BASELINE config 5; the headline is bf16)")
-    ap.add_argument("--on-the-fly", type=int, default=3,
+    ap.add_argument("--on-the-fly", type=int, default=2,
                     help="engine steps in flight with async scheduling = SchedulerConfig.max_num_on_the_fly of the "
-                         "reference (decoding/config.py:149-155: 2 by default, 3 for its double_buffer mode); the line "
-                         "also carries the same run at 2 in flight (`other_settings`)")
+                         "reference (decoding/config.py:149-155: 2 by default -- BASELINE.md section 4 step 4 quotes the "
+                         "headline on that -- 3 for its double_buffer mode)")
+    ap.add_argument("--also-on-the-fly", type=int, default=3,
+                    help="after the headline region: B more sequences per extra step in flight are admitted and the same "
+                         "number of model steps is timed again at this many steps in flight, reported as "
+                         "`other_settings` (never as `value`); 0 = skip")
     ap.add_argument("--num-scheduler-steps", type=int, default=8,
                     help="model steps per engine step (multi-step decode: advance_step on the device between them); "
                          "1 = one host round trip per model step.  The timed region holds exactly --steps MODEL steps: "
@@ -395,6 +403,9 @@ def main():
     B, ctx = a.batch_size, a.context
     k, kw, on_the_fly = plan_steps(a)
     k_max = max(k, kw)
+    extra = a.also_on_the_fly if (a.scheduling != "sync" and a.also_on_the_fly > on_the_fly
+                                  and a.steps // k >= a.also_on_the_fly) else 0
+    slots = max(on_the_fly, extra)
     n_req = B * on_the_fly
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
     cfg.pack_weights = not a.library_gemm
@@ -402,14 +413,14 @@ def main():
     cfg.rope_in_attention = not a.no_rope_in_attention
     cfg.quantization = a.quantization
     total_steps = a.steps + a.warmup
-    max_len = ctx + (total_steps + a.steps) // min(on_the_fly, 2) + 2 * k_max + 8
+    max_len = ctx + total_steps // on_the_fly + (a.steps + 2 * k) // max(1, slots) + 2 * k_max + 8
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
-    blocks = n_req * ((max_len + bs - 1) // bs + 1) + 64
+    blocks = B * slots * ((max_len + bs - 1) // bs + 1) + 64
     engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype),
                        SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
                                        max_model_len=max_model_len, scheduling=a.scheduling,
-                                       max_num_on_the_fly=on_the_fly, use_v2_block_manager=k_max > 1,
+                                       max_num_on_the_fly=slots, use_v2_block_manager=k_max > 1,
                                        num_scheduler_steps=k_max, gemm_workgroups=a.gemm_workgroups),
                        device=dev, use_hip_graph=not a.no_graph,
                        decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
@@ -455,20 +466,26 @@ def main():
     assert tokens == a.steps * B, (tokens, a.steps, B)
     elapsed = group.max(elapsed)            # slowest replica's clock
     value = group.sum(tokens) / elapsed      # whole-job tokens/s
-    # the same engine, the same step count, two engine steps in flight (the reference's default for "async"; the
-    # round-1 headline setting): a second timed region, reported beside the headline, never as `value`
+    # More steps in flight (a SchedulerConfig setting of the reference; BASELINE.md quotes the headline at 2): B more
+    # sequences per extra step are admitted at the same context, one burst per slot warms the new pipeline depth,
+    # then the same number of model steps is timed again.  Reported beside the headline, never as `value`.
     other = {}
-    if on_the_fly > 2 and a.steps // k >= 2:
+    if extra:
+        for i in range(n_req, B * extra):
+            prompt = torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist()
+            engine.add_request(str(i), prompt, max_tokens=2 * total_steps + 100)
+        engine.prefill_synthetic(seed=rank + 1000)
+        run(k * extra, k, in_flight=extra)
         torch.cuda.synchronize(dev)
         group.barrier()
         t1 = time.perf_counter()
-        tok2 = run(a.steps, k, in_flight=2)
+        tok2 = run(a.steps, k, in_flight=extra)
         torch.cuda.synchronize(dev)
         group.barrier()
         el2 = group.max(time.perf_counter() - t1)
-        other["max_num_on_the_fly=2"] = {"value": round(group.sum(tok2) / el2, 1), "unit": "tokens/s",
-                                         "ms_per_step": round(el2 / a.steps * 1e3, 4)}
-
+        other[f"max_num_on_the_fly={extra}"] = {"value": round(group.sum(tok2) / el2, 1), "unit": "tokens/s",
+                                                "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                                                "sequences_resident": B * extra}
     kl = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
     gm = gemm_leg(engine, B) if B <= 64 else None
     cpu = ops_base = None

@@ -264,6 +264,12 @@ int lvllm_add_layer_norm(void* out, const void* x, const void* y, const void* we
 int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,
                                     int num_partials, const void* weight, float epsilon,
                                     int num_tokens, int hidden_size, int dtype, void* stream);
+/* The same behind a W8A8 projection that left its raw partials (lvllm_skinny_gemm_w8a8_ex, act = 4):
+ * x = T(sum_s partials[s] * (*x_scale * *w_scale)), the value that projection's own reduce pass writes. */
+int lvllm_fused_add_rms_norm_splitk_scaled(void* out, void* residual, const float* partials,
+                                           int num_partials, const void* weight, float epsilon,
+                                           int num_tokens, int hidden_size, int dtype,
+                                           const float* x_scale, const float* w_scale, void* stream);
 /* rotary_embedding (rot_dim == head_size) and reshape_and_cache of the rotated key and the
  * value in one launch; returns 3 outside its envelope (use the two separate entry points). */
 int lvllm_rotary_embedding_and_cache(
@@ -381,7 +387,9 @@ int lvllm_skinny_gemm_w8a8(void* y, const void* x, const void* w_packed, const v
 /* As lvllm_skinny_gemm_w8a8 with act = 0; act = 2: W rows are [gate (N/2) | up (N/2)] and y is [M, N/2],
  * silu_and_mul applied in the epilogue (N % 32 == 0, K not split over workgroups); act = 3: y is int64 [M],
  * the arg-max over n of the rounded result (as lvllm_skinny_gemm_argmax; workspace of
- * lvllm_skinny_gemm_argmax_workspace_bytes(M), no bias, K not split over workgroups). */
+ * lvllm_skinny_gemm_argmax_workspace_bytes(M), no bias, K not split over workgroups); act = 4: K IS split over
+ * workgroups (lvllm_skinny_gemm_w8a8_workspace_bytes > 0) and the raw fp32 partial sums [ksplit, M, N] stay in
+ * `workspace` -- unscaled, y not written, no bias -- for lvllm_fused_add_rms_norm_splitk_scaled. */
 int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, const void* bias,
                               const float* x_scale, const float* w_scale, int M, int N, int K,
                               int64_t ldx, int dtype, int act, void* workspace,

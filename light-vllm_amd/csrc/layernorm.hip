@@ -91,7 +91,9 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
                                                  const float* __restrict__ partials, const int num_partials,
                                                  const int64_t partial_stride,  // M * hidden
                                                  const typename T::store_t* __restrict__ weight,
-                                                 const float epsilon, const int hidden_size) {
+                                                 const float epsilon, const int hidden_size,
+                                                 const float* __restrict__ scale_a = nullptr,
+                                                 const float* __restrict__ scale_b = nullptr) {
   LVLLM_TRACE_BEGIN();
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
@@ -103,6 +105,10 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
   V* out_v = reinterpret_cast<V*>(out) + row;
   const V* w_v = reinterpret_cast<const V*>(weight);
   const float* prow = partials + (int64_t)blockIdx.x * hidden_size;
+  // W8A8 partials are raw fp8 x fp8 sums: the GEMM's reduce pass would have multiplied them by
+  // x_scale * w_scale before rounding (skinny_gemm_reduce_kernel), so this kernel does
+  const bool scaled = scale_a != nullptr;
+  const float sc = scaled ? scale_a[0] * scale_b[0] : 1.f;
 
   V cache[kMaxCached];
   float var = 0.f;
@@ -121,6 +127,7 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
     V x;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
+      if (scaled) acc[j] *= sc;
       const typename T::store_t y = T::from_float(acc[j]);  // the GEMM output, rounded to T
       x.v[j] = T::from_float(T::to_float(y) + T::to_float(r.v[j]));
       const float f = T::to_float(x.v[j]);
@@ -373,7 +380,17 @@ extern "C" int lvllm_fused_add_rms_norm(void* input, void* residual, const void*
 extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,
                                                int num_partials, const void* weight, float epsilon,
                                                int num_tokens, int hidden_size, int dtype, void* stream) {
+  return lvllm_fused_add_rms_norm_splitk_scaled(out, residual, partials, num_partials, weight, epsilon, num_tokens,
+                                                hidden_size, dtype, nullptr, nullptr, stream);
+}
+
+// ... of a W8A8 projection: x = T(sum_s partials[s] * (*x_scale * *w_scale)) (scales: device pointers, both or none)
+extern "C" int lvllm_fused_add_rms_norm_splitk_scaled(void* out, void* residual, const float* partials,
+                                                      int num_partials, const void* weight, float epsilon,
+                                                      int num_tokens, int hidden_size, int dtype,
+                                                      const float* x_scale, const float* w_scale, void* stream) {
   if (num_tokens == 0) return 0;
+  LV_CHECK((x_scale == nullptr) == (w_scale == nullptr), "x_scale and w_scale: both or none");
   LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit element types only");
   LV_CHECK(hidden_size % 8 == 0 && num_partials >= 1, "hidden_size must be a multiple of 8");
   LV_CHECK((((uintptr_t)out | (uintptr_t)residual | (uintptr_t)partials | (uintptr_t)weight) & 15) == 0,
@@ -385,11 +402,11 @@ extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const 
   if (dtype == LVLLM_BF16)
     hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<BF16>), dim3(num_tokens), dim3(threads), 0,
                        (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale);
   else
     hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<F16>), dim3(num_tokens), dim3(threads), 0,
                        (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale);
   LV_LAUNCH_CHECK();
   return 0;
 }

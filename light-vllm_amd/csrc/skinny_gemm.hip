@@ -1174,7 +1174,9 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
                                          int64_t ldx, int dtype, int act, void* workspace,
                                          int64_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0) return 0;
-  LV_CHECK(act == 0 || act == 2 || act == 3, "lvllm_skinny_gemm_w8a8_ex: act must be 0, 2 or 3");
+  LV_CHECK(act == 0 || act == 2 || act == 3 || act == 4, "lvllm_skinny_gemm_w8a8_ex: act must be 0, 2, 3 or 4");
+  const bool leave_partials = act == 4;  // the raw fp32 split-K partials stay in `workspace`, y is not written
+  if (leave_partials) act = 0;
   LV_CHECK(x_scale != nullptr && w_scale != nullptr, "scales are device pointers to one float each");
   if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 64 || (K % 64) != 0 || (N % 16) != 0 ||
       (int64_t)N * K >= ((int64_t)1 << 32) - 16 || (ldx % 8) != 0 ||
@@ -1205,6 +1207,8 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
     y = workspace;
   }
   float* partial = nullptr;
+  LV_CHECK(!leave_partials || (ksplit > 1 && bias == nullptr),
+           "act = 4 needs K split over workgroups (lvllm_skinny_gemm_w8a8_workspace_bytes > 0) and no bias");
   if (ksplit > 1) {
     LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
              "workspace too small (see lvllm_skinny_gemm_w8a8_workspace_bytes)");
@@ -1239,7 +1243,7 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
     LV_LAUNCH_CHECK();
     return 0;
   }
-  if (ksplit > 1) {
+  if (ksplit > 1 && !leave_partials) {
     const int64_t MN = (int64_t)M * N;
     const int grid = (int)((MN / 4 + 255) / 256);
     if (dtype == LVLLM_BF16)

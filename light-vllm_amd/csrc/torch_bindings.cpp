@@ -421,17 +421,51 @@ void add_layer_norm(torch::Tensor& out, const torch::Tensor& x, const std::optio
                              dtype_code(x, "add_layer_norm"), current_stream(x)));
 }
 
-void fused_add_rms_norm_splitk(torch::Tensor& out, torch::Tensor& residual, const torch::Tensor& partials,
-                               const torch::Tensor& weight, double epsilon) {
+void fused_add_rms_norm_splitk_scaled(torch::Tensor& out, torch::Tensor& residual, const torch::Tensor& partials,
+                                      const torch::Tensor& weight, double epsilon,
+                                      const c10::optional<torch::Tensor>& x_scale,
+                                      const c10::optional<torch::Tensor>& w_scale) {
   TORCH_CHECK(partials.dim() == 3 && partials.scalar_type() == at::kFloat && partials.is_contiguous());
   TORCH_CHECK(out.is_contiguous() && residual.is_contiguous() && out.sizes() == residual.sizes());
+  TORCH_CHECK(x_scale.has_value() == w_scale.has_value(), "x_scale and w_scale: both or none");
+  if (x_scale.has_value())
+    TORCH_CHECK(x_scale->scalar_type() == at::kFloat && w_scale->scalar_type() == at::kFloat && x_scale->is_cuda() &&
+                w_scale->is_cuda() && x_scale->numel() == 1 && w_scale->numel() == 1, "scales: one float each, on the GPU");
   const int hidden = (int)out.size(-1);
   const int num_tokens = (int)(out.numel() / hidden);
   TORCH_CHECK(partials.size(1) == num_tokens && partials.size(2) == hidden);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(out));
-  check(lvllm_fused_add_rms_norm_splitk(out.data_ptr(), residual.data_ptr(), partials.data_ptr<float>(),
-                                        (int)partials.size(0), weight.data_ptr(), (float)epsilon, num_tokens,
-                                        hidden, dtype_code(out, "fused_add_rms_norm_splitk"), current_stream(out)));
+  check(lvllm_fused_add_rms_norm_splitk_scaled(
+      out.data_ptr(), residual.data_ptr(), partials.data_ptr<float>(), (int)partials.size(0), weight.data_ptr(),
+      (float)epsilon, num_tokens, hidden, dtype_code(out, "fused_add_rms_norm_splitk"),
+      x_scale.has_value() ? x_scale->data_ptr<float>() : nullptr,
+      w_scale.has_value() ? w_scale->data_ptr<float>() : nullptr, current_stream(out)));
+}
+
+void fused_add_rms_norm_splitk(torch::Tensor& out, torch::Tensor& residual, const torch::Tensor& partials,
+                               const torch::Tensor& weight, double epsilon) {
+  fused_add_rms_norm_splitk_scaled(out, residual, partials, weight, epsilon, c10::nullopt, c10::nullopt);
+}
+
+// A W8A8 projection whose K is split over workgroups, leaving the raw fp32 partials [S, M, N] for
+// fused_add_rms_norm_splitk_scaled.  Returns an EMPTY tensor when K is not split at this shape (nothing was done).
+torch::Tensor skinny_linear_w8a8_partials(const torch::Tensor& x, const torch::Tensor& w_packed,
+                                          const torch::Tensor& w_scale, const torch::Tensor& x_scale, int64_t N,
+                                          int64_t K) {
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.is_cuda() && x.stride(1) == 1, "bad x");
+  const int64_t M = x.size(0);
+  const int64_t ws_bytes = lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K);
+  if (ws_bytes == 0 || M == 0) return torch::empty({0}, x.options().dtype(torch::kFloat));
+  const int64_t S = ws_bytes / (M * N * 4);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x));
+  auto partials = torch::empty({S, M, N}, x.options().dtype(torch::kFloat));
+  const int rc = lvllm_skinny_gemm_w8a8_ex(nullptr, x.data_ptr(), w_packed.data_ptr(), nullptr,
+                                           x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N,
+                                           (int)K, x.stride(0), dtype_code(x, "skinny_linear_w8a8_partials"), 4,
+                                           partials.data_ptr(), ws_bytes, current_stream(x));
+  if (rc == 3) return torch::empty({0}, x.options().dtype(torch::kFloat));
+  check(rc);
+  return partials;
 }
 
 // returns false when the arguments are outside the fused kernel's envelope (nothing was done)
@@ -906,6 +940,11 @@ TORCH_LIBRARY(_C_amd, amd) {
           "float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, "
           "str kv_cache_dtype) -> bool");
   amd.impl("rope_cache_paged_attention", torch::kCUDA, &rope_cache_paged_attention);
+  amd.def("fused_add_rms_norm_splitk_scaled(Tensor! out, Tensor! residual, Tensor partials, Tensor weight, "
+          "float epsilon, Tensor? x_scale, Tensor? w_scale) -> ()");
+  amd.impl("fused_add_rms_norm_splitk_scaled", torch::kCUDA, &fused_add_rms_norm_splitk_scaled);
+  amd.def("skinny_linear_w8a8_partials(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K) -> Tensor");
+  amd.impl("skinny_linear_w8a8_partials", torch::kCUDA, &skinny_linear_w8a8_partials);
   amd.def("advance_step_logged(int block_size, Tensor! input_tokens, Tensor sampled_token_ids, "
           "Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables, "
           "Tensor! token_log) -> ()");

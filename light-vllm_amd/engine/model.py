@@ -172,6 +172,11 @@ class DecoderModel:
     def _add_norm(self, x, residual: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         """residual += x; return norm(residual) * weight.  `x` is either the projection output
         [T, hidden] or the fp32 split-K partials [S, T, hidden] of a fused down projection."""
+        if isinstance(x, tuple):  # (raw fp32 partials of a W8A8 projection, x_scale, w_scale)
+            out = torch.empty_like(residual)
+            torch.ops._C_amd.fused_add_rms_norm_splitk_scaled(out, residual, x[0], weight, self.cfg.rms_norm_eps,
+                                                              x[1], x[2])
+            return out
         if x.dim() == 3:
             out = torch.empty_like(residual)
             torch.ops._C_amd.fused_add_rms_norm_splitk(out, residual, x, weight, self.cfg.rms_norm_eps)
@@ -248,11 +253,18 @@ class DecoderModel:
                 gate_up = linear(hidden, lw.gate_up)
                 act = torch.empty(T, cfg.intermediate_size, dtype=gate_up.dtype, device=gate_up.device)
                 ops.silu_and_mul(act, gate_up)
+            hidden = None
             if decode_only and lw.down.packed is not None and lw.down.w8_t is None:
                 # [S, T, hidden] fp32 split-K partial sums; the next add+norm adds them up
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(act, lw.down.packed, lw.down.N,
                                                                         lw.down.K, False)
-            else:
+            elif decode_only and lw.down.w8_packed is not None and T <= 64:
+                # W8A8: the raw partials and the scales the reduce pass would have applied (empty: K not split here)
+                d = lw.down
+                part = torch.ops._C_amd.skinny_linear_w8a8_partials(act, d.w8_packed, d.w_scale, d.x_scale, d.N, d.K)
+                if part.numel() > 0:
+                    hidden = (part, d.x_scale, d.w_scale)
+            if hidden is None:
                 hidden = linear(act, lw.down)
         return self._add_norm(hidden, residual, self.final_norm)
 

@@ -108,12 +108,16 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
     """The whole script -- engine, bursts, ctypes kernel leg (16-bit and fp8 caches), GEMM leg, per-op baselines --
     in a child process on the tiny model; the line it prints satisfies the contract."""
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--steps", "16", "--warmup", "8",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--steps", "24", "--warmup", "8",
                         "--batch-size", "8", "--context", "64", "--kernel-iters", "64"] + extra,
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     check_line(line, 8)
+    if "sync" not in extra:  # the headline at two steps in flight (BASELINE.md section 4), three reported beside it
+        assert line["config"]["max_num_on_the_fly"] == 2
+        o = line["other_settings"]["max_num_on_the_fly=3"]
+        assert o["value"] > 0 and o["sequences_resident"] == 24
     assert line["cpu_baseline"]["value"] > 0
     ops = line["ops_baseline"]["ops"]
     assert set(ops) == {"reshape_and_cache", "rms_norm", "fused_add_rms_norm", "rotary_embedding", "silu_and_mul"}

@@ -389,3 +389,33 @@ def test_fp8_prefill_over_the_paged_cache(ops, dtype, block_size, head_size, H, 
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     check_attention(out, want, dense_prefill_fp64(twin))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 14336), (64, 4096, 14336), (7, 512, 8192), (33, 1024, 6144)])
+def test_w8a8_partials_into_add_norm_are_bit_identical_to_the_separate_launches(ops, dtype, M, N, K):
+    """W8A8 projection whose K is split over workgroups: leaving the raw fp32 partials to
+    fused_add_rms_norm_splitk_scaled == the projection's own reduce pass (scale, round) followed by
+    fused_add_rms_norm -- normed output and updated residual, bit for bit.  A shape whose K is not split returns
+    an empty tensor."""
+    from light_vllm_amd.quantization import pack_fp8_weight, skinny_fp8_linear
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    w_scale = (w.abs().max() / 448.0).reshape(1).float()
+    wp = pack_fp8_weight((w / w_scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+    x_scale = (x.float().abs().max() / 448.0).reshape(1)
+    res = torch.randn(M, N, generator=g, device=DEV).to(dtype)
+    weight = (1 + 0.1 * torch.randn(N, generator=g, device=DEV)).to(dtype)
+    part = torch.ops._C_amd.skinny_linear_w8a8_partials(x, wp, w_scale, x_scale, N, K)
+    assert part.dim() == 3 and part.shape[1:] == (M, N) and part.shape[0] > 1
+    out, res1 = torch.empty_like(res), res.clone()
+    torch.ops._C_amd.fused_add_rms_norm_splitk_scaled(out, res1, part, weight, 1e-5, x_scale, w_scale)
+    y = skinny_fp8_linear(x, wp, w_scale, x_scale, N, K, None)
+    res2 = res.clone()
+    ops.fused_add_rms_norm(y, res2, weight, 1e-5)
+    assert torch.equal(res1.view(torch.int16), res2.view(torch.int16))
+    assert torch.equal(out.view(torch.int16), y.view(torch.int16))
+    assert torch.ops._C_amd.skinny_linear_w8a8_partials(x[:, :4096].contiguous(), wp.view(-1)[: N * 4096], w_scale, x_scale,
+                                                        N, 4096).numel() == 0

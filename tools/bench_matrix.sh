@@ -3,13 +3,12 @@ ulimit -c 0
 O=gpurun_out/r02_matrix; mkdir -p $O
 run() { name=$1; shift; python bench.py "$@" > $O/$name.json 2> $O/$name.err; python -c "
 import json; d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1])
-o=d.get('other_settings',{}).get('max_num_on_the_fly=2',{})
-print('%-28s %8.1f tok/s  %.4f ms/step   (2 in flight: %s)' % ('$name', d['value'], d['ms_per_step'], o.get('value')))"; }
+o=d.get('other_settings',{})
+print('%-24s %8.1f tok/s  %.4f ms/step  (%d in flight)   %s' % ('$name', d['value'], d['ms_per_step'], d['config']['max_num_on_the_fly'], '  '.join('%s: %s' % (k.replace('max_num_on_the_fly=', 'in flight '), v['value']) for k, v in o.items())))"; }
 run default
-run on_the_fly_2 --on-the-fly 2 --skip-cpu-baseline --skip-ops-baseline
-run on_the_fly_4 --on-the-fly 4 --skip-cpu-baseline --skip-ops-baseline
+run also_4 --also-on-the-fly 4 --skip-cpu-baseline --skip-ops-baseline
+run on_the_fly_3 --on-the-fly 3 --also-on-the-fly 0 --skip-cpu-baseline --skip-ops-baseline
 run single_step --num-scheduler-steps 1 --skip-cpu-baseline --skip-ops-baseline
-run single_step_2 --num-scheduler-steps 1 --on-the-fly 2 --skip-cpu-baseline --skip-ops-baseline
 run no_rope_in_attention --no-rope-in-attention --skip-cpu-baseline --skip-ops-baseline
 run no_fusion --no-fusion --skip-cpu-baseline --skip-ops-baseline
 run library_gemm --library-gemm --skip-cpu-baseline --skip-ops-baseline
