@@ -134,8 +134,10 @@ int lvllm_paged_attention_v2_phases(
  * heads and the new key in registers (arithmetic and roundings of lvllm_rotary_embedding), writes the rotated key
  * and the value into the paged caches at the slot, and attends to them from registers.  `out`, the caches and the
  * scratch hold bit for bit what the three calls leave; query and key are NOT rotated in place (nothing downstream
- * of attention reads them).  NeoX pairing, rot_dim == head_size in {64, 128, 256}, 16-bit types, kv_dtype AUTO,
- * block_size 16 | 32, GQA group <= 16.  Returns 3 -- and does nothing -- outside that envelope. */
+ * of attention reads them).  NeoX pairing, rot_dim == head_size in {64, 128, 256}, 16-bit types, block_size
+ * 16 | 32, GQA group <= 16; kv_dtype AUTO (scales 1.0) or FP8_E4M3 (head size 128 | 256; the rotated key and the
+ * value are quantised with their scales on the way into the cache, as lvllm_reshape_and_cache does).  Returns 3 --
+ * and does nothing -- outside that envelope. */
 int lvllm_rope_cache_paged_attention(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key,
     const void* value, void* key_cache, void* value_cache, int num_seqs, int num_heads, int head_size,
@@ -143,7 +145,7 @@ int lvllm_rope_cache_paged_attention(
     const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
     int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
     int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
-    int kv_dtype, int64_t kv_cache_bytes, void* stream);
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream);
 
 /* ---- cache ops (replaces csrc/cache.h:9-33, cache_kernels.cu) ------------- */
 

@@ -372,7 +372,10 @@ class PagedAttnImpl:
         """rotary_embedding + reshape_and_cache + paged_attention_v2 of a decode-only step in ONE launch
         (lvllm_rope_cache_paged_attention; bit-identical to the three).  None when the shapes are outside the
         fused kernel's envelope -- nothing was done, the caller runs the separate launches."""
-        if self.alibi_slopes is not None or self.kv_cache_dtype != "auto" or self.decode_version == "v1":
+        # fp8 caches: the kernel supports them (bit-identical too), but measured SLOWER than the two launches there
+        # (13 030 vs 13 300 tokens/s, profiles/r02_tuning.md): the fp8 attention launch is instruction-bound, the
+        # prologue and its barrier cost more than the launch they save
+        if self.alibi_slopes is not None or self.decode_version == "v1" or self.kv_cache_dtype != "auto":
             return None
         num_tokens, hidden_size = query.shape
         md = attn_metadata.decode_metadata
@@ -382,7 +385,7 @@ class PagedAttnImpl:
         ok = torch.ops._C_amd.rope_cache_paged_attention(
             out, scratch[0], scratch[1], scratch[2], positions, query, key, value, self.head_size, cos_sin_cache, True,
             key_cache, value_cache, attn_metadata.slot_mapping, self.num_kv_heads, self.scale, md.block_tables,
-            md.seq_lens_tensor, value_cache.shape[3], max_len, self.kv_cache_dtype)
+            md.seq_lens_tensor, value_cache.shape[3], max_len, self.kv_cache_dtype, 1.0, 1.0)
         return out.view(num_tokens, hidden_size) if ok else None
 
     def unified_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,

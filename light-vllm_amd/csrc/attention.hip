@@ -365,7 +365,8 @@ static int paged_attention_v2_impl(
     p.positions = rope->positions; p.cos_sin_cache = rope->cos_sin_cache;
     p.k_new = rope->k_new; p.v_new = rope->v_new; p.slot_mapping = rope->slot_mapping;
     p.k_new_stride = rope->k_new_stride; p.v_new_stride = rope->v_new_stride;
-    p.num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_kv_heads * head_size * 2) : INT64_MAX;
+    p.num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_kv_heads * head_size * (p.kv_fp8 ? 1 : 2))
+                                     : INT64_MAX;
   }
   hipStream_t s = (hipStream_t)stream;
   const int kvb = p.kv_fp8 ? 1 : 2;
@@ -465,15 +466,18 @@ extern "C" int lvllm_rope_cache_paged_attention(
     const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
     int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
     int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
-    int kv_dtype, int64_t kv_cache_bytes, void* stream) {
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
+  const bool fp8 = kv_dtype == LVLLM_KV_FP8_E4M3;
   const bool ok =
-      (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && kv_dtype == LVLLM_KV_AUTO && is_neox && rot_dim == head_size &&
-      (head_size == 64 || head_size == 128 || head_size == 256) && (block_size == 16 || block_size == 32) &&
+      (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && (kv_dtype == LVLLM_KV_AUTO || fp8) && is_neox &&
+      rot_dim == head_size && (fp8 ? (head_size == 128 || head_size == 256) : (head_size == 64 || head_size == 128 || head_size == 256)) &&
+      (fp8 ? (k_scale > 0.f && v_scale > 0.f) : (k_scale == 1.f && v_scale == 1.f)) &&
+      (block_size == 16 || block_size == 32) &&
       num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_heads / num_kv_heads <= 16 &&
       (((uintptr_t)query | (uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache | (uintptr_t)value_cache |
         (uintptr_t)cos_sin_cache) & 15) == 0 &&
-      q_stride % 8 == 0 && key_stride % 8 == 0 && value_stride % 8 == 0 && kv_block_stride % 8 == 0 &&
-      kv_head_stride % 8 == 0 && max_num_blocks_per_seq > 0 && tuning().attn_splits != -1;
+      q_stride % 8 == 0 && key_stride % 8 == 0 && value_stride % 8 == 0 && kv_block_stride % 16 == 0 &&
+      kv_head_stride % 16 == 0 && max_num_blocks_per_seq > 0 && tuning().attn_splits != -1;
   if (!ok) {
     set_error("lvllm_rope_cache_paged_attention: arguments outside the fused kernel's envelope");
     return 3;
@@ -482,7 +486,7 @@ extern "C" int lvllm_rope_cache_paged_attention(
   return paged_attention_v2_impl(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
                                  num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens, block_size,
                                  max_seq_len, max_num_blocks_per_seq, max_num_partitions, nullptr, q_stride,
-                                 kv_block_stride, kv_head_stride, dtype, kv_dtype, 1.f, 1.f, 0, 0, 0, 64, 0,
+                                 kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, 0, 0, 64, 0,
                                  kv_cache_bytes, 3, stream, &r);
 }
 

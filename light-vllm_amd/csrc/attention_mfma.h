@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   static_assert(sizeof(S) == 2, "MFMA path is for 16-bit element types");
   static_assert(BS == 8 || BS == 16 || BS == 32, "a 16-token tile is one block, half a block, or two 8-token blocks");
   static_assert(BS != 8 || (!KV8 && !ROPE), "8-token blocks: 16-bit caches, separate rope / cache-write launches");
+  static_assert(!(ROPE && KV8) || D % 128 == 0, "fused rotation over an fp8 cache: Q fragment j pairs with j + NSQ/2");
   static_assert(NBUF >= 1 && NBUF <= 3, "register sets per wave");
   constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
   constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   constexpr int NKL = KV8 ? (D + 63) / 64 : NS;  // K wave loads (16 bytes per lane) per tile
   constexpr int NSQ = KV8 ? 2 * NKL : NS;        // k-slices actually multiplied (fp8: two per load)
   static_assert(!KV8 || D % 16 == 0, "fp8 cache: head size must be a multiple of x = 16");
-  static_assert(!ROPE || (!KV8 && D % 64 == 0), "fused rotation: 16-bit cache, NeoX halves on k-slice boundaries");
+  static_assert(!ROPE || D % 64 == 0, "fused rotation: NeoX halves on k-slice boundaries");
   using vraw_t = typename std::conditional<KV8, uint32_t, u32x2_t>::type;  // V piece as loaded
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
         }
       };
       if (c < nh) {
+        // 16-bit cache: fragment j holds d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8)
 #pragma unroll
-        for (int j = 0; j < NS / 2; ++j) rot8(qf[j], qf[j + NS / 2], 32 * j + 8 * g);
+        for (int j = 0; j < NSQ / 2; ++j)
+          rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
       }
       owns_new_token = !p.partitioned || t1 == seq_len;
       if (owns_new_token && wave == 0) {
@@ -279,24 +282,61 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
           u32x4_t kx = *reinterpret_cast<const u32x4_t*>(krow + 8 * lane);
           u32x4_t ky = *reinterpret_cast<const u32x4_t*>(krow + D / 2 + 8 * lane);
           rot8(kx, ky, 8 * lane);
-          *reinterpret_cast<u32x4_t*>(sm_knew + 8 * lane) = kx;
-          *reinterpret_cast<u32x4_t*>(sm_knew + D / 2 + 8 * lane) = ky;
-          if (slot >= 0) {
-            S* kc = (S*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 8;
-            *reinterpret_cast<u32x4_t*>(kc + (int64_t)lane * BS * 8) = kx;
-            *reinterpret_cast<u32x4_t*>(kc + (int64_t)(D / 16 + lane) * BS * 8) = ky;
+          if constexpr (KV8) {
+            // fp8 cache (x = 16): the rotated values -- already rounded to T, as the separate launches see them --
+            // are quantised with fp8_kv_quant4; 8 values = 8 bytes of the 16-byte chunk d16 = d / 16
+            auto q8 = [&](const u32x4_t& v) __attribute__((always_inline)) -> u32x2_t {
+              const S* e = reinterpret_cast<const S*>(&v);
+              u32x2_t r;
+              r.x = fp8_kv_quant4(T::to_float(e[0]), T::to_float(e[1]), T::to_float(e[2]), T::to_float(e[3]), p.k_scale);
+              r.y = fp8_kv_quant4(T::to_float(e[4]), T::to_float(e[5]), T::to_float(e[6]), T::to_float(e[7]), p.k_scale);
+              return r;
+            };
+            const u32x2_t qx = q8(kx), qy = q8(ky);
+            uint8_t* sk = reinterpret_cast<uint8_t*>(sm_knew);
+            *reinterpret_cast<u32x2_t*>(sk + 8 * lane) = qx;
+            *reinterpret_cast<u32x2_t*>(sk + D / 2 + 8 * lane) = qy;
+            if (slot >= 0) {
+              uint8_t* kc8 = (uint8_t*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 16;
+              const int dx = 8 * lane, dy = D / 2 + 8 * lane;
+              *reinterpret_cast<u32x2_t*>(kc8 + (int64_t)(dx / 16) * BS * 16 + (dx % 16)) = qx;
+              *reinterpret_cast<u32x2_t*>(kc8 + (int64_t)(dy / 16) * BS * 16 + (dy % 16)) = qy;
+            }
+          } else {
+            *reinterpret_cast<u32x4_t*>(sm_knew + 8 * lane) = kx;
+            *reinterpret_cast<u32x4_t*>(sm_knew + D / 2 + 8 * lane) = ky;
+            if (slot >= 0) {
+              S* kc = (S*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 8;
+              *reinterpret_cast<u32x4_t*>(kc + (int64_t)lane * BS * 8) = kx;
+              *reinterpret_cast<u32x4_t*>(kc + (int64_t)(D / 16 + lane) * BS * 8) = ky;
+            }
           }
         }
         if (lane < D / 8) {
           const S* vrow = (const S*)p.v_new + (int64_t)seq * p.v_new_stride + (int64_t)kvh * D;
           const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vrow + 8 * lane);
-          *reinterpret_cast<u32x4_t*>(sm_vnew + 8 * lane) = vv;
-          if (slot >= 0) {
-            S* vc = (S*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
-                    (int64_t)(8 * lane) * BS + boff;
-            const S* ve = reinterpret_cast<const S*>(&vv);
+          const S* ve = reinterpret_cast<const S*>(&vv);
+          if constexpr (KV8) {
+            u32x2_t qv;
+            qv.x = fp8_kv_quant4(T::to_float(ve[0]), T::to_float(ve[1]), T::to_float(ve[2]), T::to_float(ve[3]), p.v_scale);
+            qv.y = fp8_kv_quant4(T::to_float(ve[4]), T::to_float(ve[5]), T::to_float(ve[6]), T::to_float(ve[7]), p.v_scale);
+            uint8_t* sv = reinterpret_cast<uint8_t*>(sm_vnew);
+            *reinterpret_cast<u32x2_t*>(sv + 8 * lane) = qv;
+            if (slot >= 0) {
+              uint8_t* vc8 = (uint8_t*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
+                             (int64_t)(8 * lane) * BS + boff;
+              const uint8_t* qb = reinterpret_cast<const uint8_t*>(&qv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vc[(int64_t)e * BS] = ve[e];
+              for (int e = 0; e < 8; ++e) vc8[(int64_t)e * BS] = qb[e];
+            }
+          } else {
+            *reinterpret_cast<u32x4_t*>(sm_vnew + 8 * lane) = vv;
+            if (slot >= 0) {
+              S* vc = (S*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
+                      (int64_t)(8 * lane) * BS + boff;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vc[(int64_t)e * BS] = ve[e];
+            }
           }
         }
       }
@@ -385,19 +425,35 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       const int P = seq_len - 1;
       if (owns_new_token && (tile0 + wave + j * NWAVES) == (P >> 4)) {
         const int cs = P & 15;
-        if (c == cs) {
+        if constexpr (KV8) {
+          // fp8 tile: chunk (d16 = 4jj + g, token c) is 16 bytes; a V piece 4 bytes (tokens 4g..4g+3 of row 16t + c)
+          const uint8_t* sk = reinterpret_cast<const uint8_t*>(sm_knew);
+          const uint8_t* sv = reinterpret_cast<const uint8_t*>(sm_vnew);
+          if (c == cs) {
 #pragma unroll
-          for (int jj = 0; jj < NS; ++jj)
-            kraw[jj] = *reinterpret_cast<const u32x4_t*>(sm_knew + (4 * jj + g) * 8);
-        }
-        if (g == (cs >> 2)) {
-          const int e = cs & 3;
+            for (int jj = 0; jj < NKL; ++jj)
+              if ((4 * jj + g) * 16 < D) kraw[jj] = *reinterpret_cast<const u32x4_t*>(sk + (4 * jj + g) * 16);
+          }
+          if (g == (cs >> 2)) {
+            const int sh = 8 * (cs & 3);
 #pragma unroll
-          for (int t = 0; t < NDT; ++t) {
-            const uint32_t nv = sm_vnew[16 * t + c];
-            uint32_t w = (e & 2) ? v[t].y : v[t].x;
-            w = (e & 1) ? ((w & 0x0000ffffu) | (nv << 16)) : ((w & 0xffff0000u) | nv);
-            if (e & 2) v[t].y = w; else v[t].x = w;
+            for (int t = 0; t < NDT; ++t) v[t] = (v[t] & ~(0xffu << sh)) | ((uint32_t)sv[16 * t + c] << sh);
+          }
+        } else {
+          if (c == cs) {
+#pragma unroll
+            for (int jj = 0; jj < NS; ++jj)
+              kraw[jj] = *reinterpret_cast<const u32x4_t*>(sm_knew + (4 * jj + g) * 8);
+          }
+          if (g == (cs >> 2)) {
+            const int e = cs & 3;
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+              const uint32_t nv = sm_vnew[16 * t + c];
+              uint32_t w = (e & 2) ? v[t].y : v[t].x;
+              w = (e & 1) ? ((w & 0x0000ffffu) | (nv << 16)) : ((w & 0xffff0000u) | nv);
+              if (e & 2) v[t].y = w; else v[t].x = w;
+            }
           }
         }
       }
@@ -565,8 +621,14 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
     hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64), smem,
                        stream, p);
   };
+  if constexpr (D % 128 == 0 && BS != 8) {
+    if (p.positions != nullptr && p.kv_fp8) {  // fused rotation + quantised cache write (host checked the envelope)
+      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true, true>);
+      return;
+    }
+  }
   if constexpr (D % 64 == 0 && BS != 8) {
-    if (p.positions != nullptr) {  // fused rotation + cache write (host checked: 16-bit cache, G <= 16)
+    if (p.positions != nullptr) {  // fused rotation + cache write (host checked: G <= 16, NeoX)
       launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false, true>);
       return;
     }

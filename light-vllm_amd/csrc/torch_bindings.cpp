@@ -500,7 +500,8 @@ bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, tor
                                 const torch::Tensor& cos_sin_cache, bool is_neox, torch::Tensor& key_cache,
                                 torch::Tensor& value_cache, const torch::Tensor& slot_mapping, int64_t num_kv_heads,
                                 double scale, const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
-                                int64_t block_size, int64_t max_seq_len, const std::string& kv_cache_dtype) {
+                                int64_t block_size, int64_t max_seq_len, const std::string& kv_cache_dtype,
+                                double k_scale, double v_scale) {
   LV_CHECK_DEVICE(query);
   TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
   TORCH_CHECK(query.dim() == 2 && key.dim() == 2 && value.dim() == 2, "query / key / value must be [tokens, heads * head_size]");
@@ -524,7 +525,7 @@ bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, tor
       positions.data_ptr<int64_t>(), slot_mapping.data_ptr<int64_t>(), cos_sin_cache.data_ptr(),
       (int)cos_sin_cache.size(1), is_neox ? 1 : 0, (int)block_size, (int)max_seq_len, (int)block_tables.size(1),
       (int)exp_sums.size(-1), query.stride(-2), key.stride(-2), value.stride(-2), key_cache.stride(0),
-      key_cache.stride(1), dtype_code(query, "rope_cache_paged_attention"), kv_code,
+      key_cache.stride(1), dtype_code(query, "rope_cache_paged_attention"), kv_code, (float)k_scale, (float)v_scale,
       cache_extent_bytes(key_cache, value_cache), current_stream(query));
   if (rc == 3) return false;
   check(rc);
@@ -938,7 +939,7 @@ TORCH_LIBRARY(_C_amd, amd) {
           "Tensor positions, Tensor query, Tensor key, Tensor value, int head_size, Tensor cos_sin_cache, "
           "bool is_neox, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, int num_kv_heads, "
           "float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, "
-          "str kv_cache_dtype) -> bool");
+          "str kv_cache_dtype, float k_scale=1.0, float v_scale=1.0) -> bool");
   amd.impl("rope_cache_paged_attention", torch::kCUDA, &rope_cache_paged_attention);
   amd.def("fused_add_rms_norm_splitk_scaled(Tensor! out, Tensor! residual, Tensor partials, Tensor weight, "
           "float epsilon, Tensor? x_scale, Tensor? w_scale) -> ()");

@@ -262,3 +262,63 @@ def test_rope_cache_attention_declines_outside_its_envelope(ops):
         kc, vc, torch.zeros(S, dtype=torch.int64, device=DEV), KVH, 0.1, torch.zeros(S, 2, dtype=torch.int32, device=DEV),
         torch.ones(S, dtype=torch.int32, device=DEV), BS, 16, "auto")
     assert ok is False
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scales", [(1.0, 1.0), (0.5, 2.0)])
+@pytest.mark.parametrize("case", [
+    (5, 32, 8, 128, 16, [1024, 1, 17, 512, 700], 0),
+    (3, 8, 2, 128, 32, [300, 33, 64], 0),
+    (4, 16, 1, 256, 16, [40, 700, 129, 0], 2),
+], ids=["metric", "bs32", "d256_gqa16_forced2_padding"])
+def test_rope_cache_attention_in_one_launch_over_an_fp8_cache_is_bit_identical(ops, dtype, scales, case):
+    """The same fusion over an fp8 (e4m3fn) KV cache: the rotated key and the value are quantised with their scales on
+    the way into the cache exactly as reshape_and_cache("fp8") does, and the new token is attended to through the same
+    fp8 bytes: output and both caches equal rotary_embedding + reshape_and_cache + paged_attention_v2 bit for bit."""
+    S, H, KVH, D, BS, lens, forced = case
+    ks, vs = scales
+    g = torch.Generator().manual_seed(S * 5 + D)
+    NB = sum((max(n, 1) + BS - 1) // BS for n in lens) + 5
+    kc0 = (torch.randn(NB, KVH, D // 16, BS, 16, generator=g) * 0.5 / ks).to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    vc0 = (torch.randn(NB, KVH, D, BS, generator=g) * 0.5 / vs).to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    perm = torch.randperm(NB, generator=g).tolist()
+    W = max((max(n, 1) + BS - 1) // BS for n in lens)
+    bt = torch.zeros(S, W, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        nb = (max(n, 1) + BS - 1) // BS
+        bt[i, :nb] = torch.tensor(perm[:nb], dtype=torch.int32)
+        perm = perm[nb:]
+    qkv = (torch.randn(S, (H + 2 * KVH) * D, generator=g) * 0.5).to(dtype).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(4096).float(), inv)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(DEV)
+    seq_lens = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    positions = (seq_lens.long() - 1).clamp_min(0)
+    slots = torch.tensor([int(bt[i, (n - 1) // BS]) * BS + (n - 1) % BS if n > 0 else -1 for i, n in enumerate(lens)],
+                         dtype=torch.int64, device=DEV)
+    bt = bt.to(DEV)
+    max_len = max(lens)
+    from helpers import v2_scratch
+    torch.ops._C_amd.set_tuning("attn_splits", forced)
+    try:
+        results = []
+        for fused in (False, True):
+            kc, vc = kc0.clone(), vc0.clone()
+            x = qkv.clone()
+            q, k, v = x.split([H * D, KVH * D, KVH * D], dim=-1)
+            es, ml, tmp = v2_scratch(S, H, D, max_len, dtype, DEV)
+            out = torch.zeros(S, H, D, dtype=dtype, device=DEV)
+            if fused:
+                assert torch.ops._C_amd.rope_cache_paged_attention(out, es, ml, tmp, positions, q, k, v, D, cos_sin, True, kc, vc,
+                                                                   slots, KVH, D ** -0.5, bt, seq_lens, BS, max_len, "fp8", ks, vs)
+            else:
+                ops.rotary_embedding(positions, q, k, D, cos_sin, True)
+                ops.reshape_and_cache(k.view(S, KVH, D), v.view(S, KVH, D), kc, vc, slots, "fp8", ks, vs)
+                ops.paged_attention_v2(out, es, ml, tmp, q.view(S, H, D), kc, vc, KVH, D ** -0.5, bt, seq_lens, BS, max_len,
+                                       None, "fp8", ks, vs)
+            results.append((out, kc, vc))
+    finally:
+        torch.ops._C_amd.set_tuning("attn_splits", 0)
+    (o0, k0, v0), (o1, k1, v1) = results
+    assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    assert torch.equal(o0, o1), (o0.float() - o1.float()).abs().max()
