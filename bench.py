@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--no-rope-in-attention", action="store_true",
                     help="rope + cache write as their own launch in front of attention (A/B of the fused kernel)")
+    ap.add_argument("--o-proj-partials-min-rows", type=int, default=None,
+                    help="A/B: decode steps of at least this many rows split o_proj's K over workgroups (default 33)")
+    ap.add_argument("--gemm-partials-ksplit", type=int, default=None,
+                    help="A/B: projections that leave split-K partials split K at least this many ways")
     ap.add_argument("--gemm-workgroups", type=int, default=None,
                     help="workgroups per decode GEMM launch (default: 256 for one stream, 128 for several)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -411,6 +415,8 @@ def main():
     cfg.pack_weights = not a.library_gemm
     cfg.fuse_decode_ops = not a.no_fusion
     cfg.rope_in_attention = not a.no_rope_in_attention
+    if a.o_proj_partials_min_rows is not None:
+        cfg.o_proj_partials_min_rows = a.o_proj_partials_min_rows
     cfg.quantization = a.quantization
     total_steps = a.steps + a.warmup
     max_len = ctx + total_steps // on_the_fly + (a.steps + 2 * k) // max(1, slots) + 2 * k_max + 8
@@ -425,6 +431,8 @@ def main():
                        device=dev, use_hip_graph=not a.no_graph,
                        decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
     engine.step_returns_outputs = False
+    if a.gemm_partials_ksplit is not None:
+        torch.ops._C_amd.set_tuning("gemm_partials_ksplit", a.gemm_partials_ksplit)
     g = torch.Generator().manual_seed(1234 + rank)
     for i in range(n_req):
         prompt = torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist()

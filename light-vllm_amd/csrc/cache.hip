@@ -9,6 +9,8 @@
 // The launch shapes are not the reference's: work is cut into 16-byte chunks so
 // that every global access is a dwordx4 wherever the layout allows it, and
 // copy_blocks takes device pointer tables so it never synchronises the host.
+#include <string.h>
+
 #include "common.h"
 
 namespace lvllm {
@@ -411,6 +413,66 @@ extern "C" int lvllm_copy_blocks(const void* const* key_cache_ptrs,
   return 0;
 }
 
+namespace lvllm {
+
+// Scattered swaps: one workgroup per (pair, 16 KiB slice of the block), 16 bytes per lane.  The host side of
+// the transfer is PINNED memory mapped into the device's address space: the kernel reads / writes it over the
+// host link itself, so n scattered blocks are one launch instead of n DMA submissions (10 us each: 3 GB/s for
+// 32 KiB blocks against the link's 63 GB/s).  `mapping` is read from device-mapped pinned memory too.
+__global__ __launch_bounds__(256) void swap_blocks_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                          const int64_t* __restrict__ mapping,
+                                                          const int64_t block_bytes) {
+  const int64_t s0 = mapping[2 * blockIdx.x], d0 = mapping[2 * blockIdx.x + 1];
+  const uint4* sp = reinterpret_cast<const uint4*>(src + s0 * block_bytes);
+  uint4* dp = reinterpret_cast<uint4*>(dst + d0 * block_bytes);
+  const int64_t nvec = block_bytes >> 4;
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.y * blockDim.x)
+    dp[i] = sp[i];
+}
+
+// Pinned, device-mapped ring for the pair lists of in-flight scattered swaps (the caller's list is pageable host
+// memory and may change as soon as the call returns).  A slot is reused only after the launch that read it ended.
+struct SwapRing {
+  static constexpr int kSlots = 128;    // a swap of one sequence group is 2 * L calls: none of them waits for a slot
+  static constexpr int kMaxPairs = 4096;  // 64 KiB per slot
+  int64_t* host[kSlots] = {};
+  int64_t* dev[kSlots] = {};
+  hipEvent_t done[kSlots] = {};
+  bool used[kSlots] = {};
+  int next = 0;
+  bool ok = false, tried = false;
+  bool init() {
+    if (tried) return ok;
+    tried = true;
+    for (int i = 0; i < kSlots; ++i) {
+      if (hipHostMalloc((void**)&host[i], (size_t)kMaxPairs * 16, hipHostMallocMapped) != hipSuccess) return false;
+      if (hipHostGetDevicePointer((void**)&dev[i], host[i], 0) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    ok = true;
+    return true;
+  }
+};
+static thread_local SwapRing g_swap_ring;
+
+// device-visible address of a host buffer, or nullptr when it is not pinned / mapped
+static void* mapped_host_pointer(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error of ours
+    return nullptr;
+  }
+  if (attr.type != hipMemoryTypeHost) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
+
+}  // namespace lvllm
+
 extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* block_mapping,
                                  int num_pairs, int64_t block_bytes, int src_is_device,
                                  int dst_is_device, void* stream) {
@@ -420,9 +482,33 @@ extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* bloc
                                                      : hipMemcpyHostToDevice;
   const char* s = (const char*)src;
   char* d = (char*)dst;
-  // Merge runs where both block numbers advance by one: one DMA per run
-  // instead of one per block (the reference issues one per block,
-  // cache_kernels.cu:54-62; the bytes moved are identical).
+  if (num_pairs <= 0) return 0;
+  // Runs where both block numbers advance by one move as ONE DMA (the reference issues one per block,
+  // cache_kernels.cu:54-62; the bytes moved are identical).  When the mapping is scattered -- more than a few
+  // runs -- and the host side is pinned, one kernel launch moves all of them (swap_blocks_kernel).
+  int runs = 1;
+  for (int i = 1; i < num_pairs; ++i)
+    if (block_mapping[2 * i] != block_mapping[2 * (i - 1)] + 1 || block_mapping[2 * i + 1] != block_mapping[2 * (i - 1) + 1] + 1)
+      ++runs;
+  if (runs > tuning().swap_kernel_min_runs && (block_bytes & 15) == 0 && num_pairs <= SwapRing::kMaxPairs &&
+      ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0)) {
+    const void* ks = src_is_device ? src : mapped_host_pointer(src);
+    void* kd = dst_is_device ? dst : mapped_host_pointer(dst);
+    SwapRing& ring = g_swap_ring;
+    if (ks != nullptr && kd != nullptr && ring.init()) {
+      const int slot = ring.next;
+      ring.next = (ring.next + 1) % SwapRing::kSlots;
+      if (ring.used[slot] && hipEventSynchronize(ring.done[slot]) != hipSuccess) LV_CHECK(false, "hipEventSynchronize failed");
+      memcpy(ring.host[slot], block_mapping, (size_t)num_pairs * 16);
+      const int slices = (int)((block_bytes + 16383) / 16384);
+      hipLaunchKernelGGL(swap_blocks_kernel, dim3(num_pairs, slices < 1 ? 1 : (slices > 64 ? 64 : slices)), dim3(256), 0,
+                         (hipStream_t)stream, (const char*)ks, (char*)kd, ring.dev[slot], block_bytes);
+      LV_LAUNCH_CHECK();
+      if (hipEventRecord(ring.done[slot], (hipStream_t)stream) != hipSuccess) LV_CHECK(false, "hipEventRecord failed");
+      ring.used[slot] = true;
+      return 0;
+    }
+  }
   int i = 0;
   while (i < num_pairs) {
     const int64_t s0 = block_mapping[2 * i], d0 = block_mapping[2 * i + 1];

@@ -34,12 +34,18 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "gemm_wide_min_tiles") {
     LV_CHECK(value >= 1, "gemm_wide_min_tiles must be positive");
     lvllm::tuning().gemm_wide_min_tiles = value;
+  } else if (k == "gemm_partials_ksplit") {
+    LV_CHECK(value >= 0 && value <= 16, "gemm_partials_ksplit must be in [0, 16]");
+    lvllm::tuning().gemm_partials_ksplit = value;
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
   } else if (k == "attn_splits") {
     LV_CHECK(value >= -1, "attn_splits must be -1 (512-token partitions), 0 (automatic) or a share count");
     lvllm::tuning().attn_splits = value;
+  } else if (k == "swap_kernel_min_runs") {
+    LV_CHECK(value >= 0, "swap_kernel_min_runs must be non-negative");
+    lvllm::tuning().swap_kernel_min_runs = value;
   } else if (k == "cache_tile_min_tokens") {
     LV_CHECK(value >= 1, "cache_tile_min_tokens must be positive");
     lvllm::tuning().cache_tile_min_tokens = value;

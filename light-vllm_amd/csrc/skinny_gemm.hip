@@ -1027,7 +1027,12 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
   }
   const int total_steps = K / 32;
   const int cap = kGemmWaves * max_steps_per_wave(M);
-  const int ksplit = (total_steps + cap - 1) / cap;
+  int ksplit = (total_steps + cap - 1) / cap;
+  // a caller that sums the partials itself may ask for a finer split of K (each workgroup then reads only its
+  // K slice of X; the price is ksplit fp32 slabs): tuning "gemm_partials_ksplit"
+  if (partial_out && act == 0 && tuning().gemm_partials_ksplit > ksplit &&
+      total_steps >= tuning().gemm_partials_ksplit * kGemmWaves)
+    ksplit = tuning().gemm_partials_ksplit;
   const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
   const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;  // <= max_steps_per_wave(M)
   const int ntiles = N / 16;

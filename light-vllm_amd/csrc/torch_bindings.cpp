@@ -385,15 +385,17 @@ torch::Tensor skinny_linear_packed_partials(const torch::Tensor& gate_up, const 
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(gate_up));
   int64_t ws_bytes = lvllm_skinny_gemm_workspace_bytes((int)M, (int)N, (int)K);
   if (ws_bytes == 0) ws_bytes = M * N * 4;
-  const int64_t S = ws_bytes / (M * N * 4);
+  int64_t S = ws_bytes / (M * N * 4);
+  if (S < 16) S = 16;  // room for a forced finer split (tuning "gemm_partials_ksplit"); the slabs used are returned
+  ws_bytes = S * M * N * 4;
   auto partials = torch::empty({S, M, N}, gate_up.options().dtype(torch::kFloat));
   int ksplit = 0;
   check(lvllm_skinny_gemm_ex(nullptr, gate_up.data_ptr(), w_packed.data_ptr(), nullptr, (int)M, (int)N, (int)K,
                              gate_up.stride(0), dtype_code(gate_up, "skinny_linear_packed_partials"), 1,
                              swiglu ? 1 : 0, 1, &ksplit,
                              partials.data_ptr(), ws_bytes, current_stream(gate_up)));
-  TORCH_CHECK(ksplit == S, "split count mismatch");
-  return partials;
+  TORCH_CHECK(ksplit >= 1 && ksplit <= S, "split count mismatch");
+  return ksplit == S ? partials : partials.narrow(0, 0, ksplit);
 }
 
 void gelu(torch::Tensor& out, const torch::Tensor& x) {

@@ -28,6 +28,9 @@ class ModelConfig:
     swiglu_epilogue: bool = True    # silu_and_mul in the gate_up projection's epilogue
     argmax_epilogue: bool = True    # greedy arg-max in the lm_head projection's epilogue
     stream_gemm_max_rows: int = 256  # 65..this many rows: projections through lvllm_stream_gemm where it wins
+    # decode steps of at least this many rows split o_proj's K over workgroups and leave the fp32 partials to the
+    # add + norm launch (as the down projection always does); below, K is split inside a workgroup only
+    o_proj_partials_min_rows: int = 33
     # "fp8": W8A8 projections (BASELINE config 5): per-tensor e4m3 weights, static per-tensor
     # activation scales calibrated once on a random batch (the reference's activation_scheme="static")
     quantization: Optional[str] = None

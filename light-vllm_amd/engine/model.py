@@ -233,7 +233,7 @@ class DecoderModel:
                 ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin_cache, True)
                 attn_out = self.attn.forward(q, k, v, kv_caches[i] if kv_caches is not None else None,
                                              attn_metadata)
-            if decode_only and 32 < T <= 64 and lw.o.packed is not None and lw.o.w8_t is None:
+            if decode_only and cfg.o_proj_partials_min_rows <= T <= 64 and lw.o.packed is not None and lw.o.w8_t is None:
                 # K is split over workgroups at this many rows: the add+norm launch sums the fp32 partials
                 # itself (as for the down projection), one reduce launch less
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(attn_out, lw.o.packed, lw.o.N, lw.o.K, False)

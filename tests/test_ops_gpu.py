@@ -149,6 +149,43 @@ def test_swap_blocks_round_trip(ops):
         ops.swap_blocks(gpu, cpu, mapping.to(DEV))  # block_mapping must be on CPU
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("min_runs", [0, 1 << 20], ids=["kernel", "dma"])
+def test_swap_blocks_scattered_both_paths_bit_exact(ops, pinned, min_runs):
+    """Scattered mappings move through ONE kernel launch when the host side is pinned (device-mapped), through one
+    DMA per run otherwise: same bytes either way, in both directions, repeated calls (the pinned ring of pair lists
+    wraps), a pair list changed right after the call, untouched blocks untouched."""
+    torch.ops._C_amd.set_tuning("swap_kernel_min_runs", min_runs)
+    try:
+        g = torch.Generator().manual_seed(21)
+        NB, E = 300, 8 * 128 * 16  # one layer's K blocks of the Llama-3-8B shape: 32 KiB each
+        gpu = torch.randn(NB, E, generator=g).to(torch.bfloat16).to(DEV)
+        host = torch.zeros(NB, E, dtype=torch.bfloat16)
+        host = host.pin_memory() if pinned else host
+        exp = host.clone()
+        gpu_cpu = gpu.cpu()
+        for it in range(140):  # more calls than the ring has slots
+            n = 1 + (it * 7) % 40
+            src = torch.randperm(NB, generator=g)[:n]
+            dst = torch.randperm(NB, generator=g)[:n]
+            mapping = torch.stack([src, dst], 1).to(torch.int64).contiguous()
+            ops.swap_blocks(gpu, host, mapping)
+            oracle.swap_blocks(gpu_cpu, exp, mapping)
+            mapping.fill_(0)  # the caller's list is free to change once the call has returned
+        torch.cuda.synchronize()
+        assert torch.equal(host.view(torch.int16), exp.view(torch.int16))
+        back = torch.zeros_like(gpu)
+        exp_back = torch.zeros(NB, E, dtype=torch.bfloat16)
+        src = torch.randperm(NB, generator=g)[:200]
+        dst = torch.randperm(NB, generator=g)[:200]
+        mapping = torch.stack([src, dst], 1).to(torch.int64).contiguous()
+        ops.swap_blocks(host, back, mapping)
+        oracle.swap_blocks(exp, exp_back, mapping)
+        assert torch.equal(back.cpu().view(torch.int16), exp_back.view(torch.int16))
+    finally:
+        torch.ops._C_amd.set_tuning("swap_kernel_min_runs", 3)
+
+
 # ---------------------------------------------------------------- norm / rope / activation
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("num_tokens,hidden", [(1, 64), (32, 4096), (7, 8192), (300, 1024), (5, 5120), (3, 100), (2, 16384)])
