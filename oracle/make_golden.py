@@ -18,7 +18,10 @@ oracle/_ref).  The fixtures are data: inputs and the reference's outputs.
                               Worker.determine_num_available_blocks on scripted memory readings, block
                               bytes of CacheEngine.get_cache_block_size, prompt lengths of profile_run
 
-usage: python oracle/make_golden.py [block_manager] [ops] [prefill_only] [sampler] [input_builder] [kv_sizing]
+  scheduler_<name>.json       what the reference's DecodingScheduler returns step by step for the seeded programs of
+                              tests/sched_driver.py
+
+usage: python oracle/make_golden.py [block_manager] [ops] [prefill_only] [sampler] [input_builder] [kv_sizing] [scheduler]
 """
 import json
 import os
@@ -346,9 +349,75 @@ def make_kv_sizing_vectors():
     print(f"{path}: {len(cases)} sizing cases, {len(profiles)} profile shapes")
 
 
+def make_scheduler_traces():
+    """What the reference's DecodingScheduler (decoding/scheduler.py:235-1132) returns, step by step, for the seeded
+    programs of tests/sched_driver.py (default and chunked-prefill policies, v1 / v2 managers, recompute and swap
+    preemption, prefix caching, lookahead slots), stepping synchronously as core/llm_engine.py:119-130 does."""
+    import contextlib
+    import io
+    import types
+    import bm_driver
+    import sched_driver
+    from oracle import ref_block_manager
+    ns = ref_block_manager.load_input_builder()
+    from light_vllm.decoding.scheduler import DecodingScheduler
+    adapter = bm_driver.ReferenceAdapter(ns)
+
+    def make(cfg):
+        sc = types.SimpleNamespace(max_num_batched_tokens=cfg["max_num_batched_tokens"], max_num_seqs=cfg["max_num_seqs"],
+                                   max_model_len=cfg["max_model_len"], use_v2_block_manager=cfg["version"] == "v2",
+                                   num_lookahead_slots=cfg.get("lookahead", 0), delay_factor=0.0,
+                                   chunked_prefill_enabled=cfg["chunked"], preemption_mode=cfg["preemption_mode"])
+        cc = types.SimpleNamespace(block_size=cfg["block_size"], num_gpu_blocks=cfg["num_gpu_blocks"],
+                                   num_cpu_blocks=cfg["num_cpu_blocks"], sliding_window=None,
+                                   enable_prefix_caching=cfg["enable_caching"])
+        return DecodingScheduler(sc, cc, None)
+
+    def recording_hook(bm, _recorded):
+        """Only the releases made inside _free_block_table are order-sensitive (set() order); swap_in / swap_out
+        release block by block in table order on both sides."""
+        inner = _recording_free_hook(bm, 0, None)
+        orig_table_free = bm._free_block_table
+        log, depth = [], [0]
+        for alloc in (bm.gpu_allocator, bm.cpu_allocator):
+            logged = alloc.free
+
+            def gated(block, _logged=logged, _dev=(0 if alloc is bm.gpu_allocator else 1)):
+                if depth[0]:
+                    log.append([_dev, block.block_number])
+                return _logged(block)
+            alloc.free = gated
+
+        def table_free(table):
+            depth[0] += 1
+            try:
+                return orig_table_free(table)
+            finally:
+                depth[0] -= 1
+        bm._free_block_table = table_free
+
+        def finish():
+            del bm._free_block_table  # back to the class's method
+            inner()
+            return log
+        return finish
+
+    for name, cfg in sched_driver.CONFIGS:
+        hook = recording_hook if cfg["version"] == "v1" else None
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference's _schedule_prefills prints its token counts
+            trace = sched_driver.run_program(make, adapter, cfg, free_hook=hook)
+        path = os.path.join(GOLDEN, f"scheduler_{name}.json")
+        with open(path, "w") as f:
+            json.dump({"config": cfg, "trace": trace}, f, separators=(",", ":"))
+        steps = [t for t in trace if "groups" in t]
+        print(f"{path}: {len(steps)} steps, {sum(len(t['groups']) for t in steps)} scheduled groups, "
+              f"{steps[-1]['cumulative_preemption']} preemptions, {sum(len(t['swap_out']) for t in steps)} blocks swapped out, "
+              f"{sum(len(t['ignored']) for t in steps)} ignored ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only", "sampler", "input_builder", "kv_sizing"]
+    what = sys.argv[1:] or ["block_manager", "ops", "prefill_only", "sampler", "input_builder", "kv_sizing", "scheduler"]
     if "block_manager" in what:
         make_block_manager_traces()
     if "ops" in what:
@@ -361,3 +430,5 @@ if __name__ == "__main__":
         make_input_builder_vectors()
     if "kv_sizing" in what:
         make_kv_sizing_vectors()
+    if "scheduler" in what:
+        make_scheduler_traces()

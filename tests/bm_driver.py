@@ -42,6 +42,9 @@ class ProductAdapter:
     def status(self, name):
         return getattr(self.S, name)
 
+    def free_finished(self, scheduler, finished):
+        scheduler.free_finished_request([f.request_id for f in finished])
+
 
 class ReferenceAdapter:
     """The reference's Sequence / SequenceGroup (via oracle/ref_block_manager.py)."""
@@ -64,6 +67,9 @@ class ReferenceAdapter:
 
     def status(self, name):
         return getattr(self.ns.SequenceStatus, name)
+
+    def free_finished(self, scheduler, finished):
+        scheduler.free_finished_request(finished)  # the reference takes RequestOutputs (anything with .request_id)
 
 
 def run_program(make_manager, adapter, config: Dict[str, Any], seed: int, num_ops: int,

@@ -360,3 +360,78 @@ def test_lookahead_needs_v2():
     import pytest
     with pytest.raises(ValueError):
         SchedulerConfig(num_lookahead_slots=2)
+
+
+# ---- the reference's DecodingScheduler, step by step (tests/golden/scheduler_*.json) ----
+import glob as _glob
+import json as _json
+import os as _os
+
+import pytest as _pytest
+
+_SCHED_TRACES = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "scheduler_*.json")))
+
+
+def _make_product_scheduler(cfg):
+    cc = CacheConfig(block_size=cfg["block_size"], num_gpu_blocks=cfg["num_gpu_blocks"],
+                     num_cpu_blocks=cfg["num_cpu_blocks"], enable_prefix_caching=cfg["enable_caching"])
+    sc = SchedulerConfig(max_num_batched_tokens=cfg["max_num_batched_tokens"], max_num_seqs=cfg["max_num_seqs"],
+                         max_model_len=cfg["max_model_len"], use_v2_block_manager=cfg["version"] == "v2",
+                         preemption_mode=cfg["preemption_mode"], chunked_prefill_enabled=cfg["chunked"],
+                         num_lookahead_slots=cfg.get("lookahead", 0))
+    return DecodingScheduler(sc, cc, chunked_prefill_enabled=cfg["chunked"])
+
+
+@_pytest.mark.parametrize("path", _SCHED_TRACES, ids=[_os.path.basename(p)[10:-5] for p in _SCHED_TRACES])
+def test_scheduler_replays_the_reference_scheduler_step_by_step(path):
+    """Every schedule() of the seeded programs returns what the reference's DecodingScheduler returned: the same
+    groups in the same order, prompt / decode, chunk sizes, do_sample, block tables, computed-prefix blocks, swap-in /
+    swap-out / copy lists, ignored requests, token counts, preemption counters and free-block counts (integer work:
+    exact).  Default and chunked-prefill policies, v1 / v2 managers, recompute and swap preemption on pools too small
+    for their load, prefix caching, lookahead slots; synchronous stepping (see tests/sched_driver.py)."""
+    import bm_driver
+    import sched_driver
+    with open(path) as f:
+        gold = _json.load(f)
+
+    def replay_free_hook(bm, recorded_order):
+        """The reference's v1 manager releases a freed table's blocks in `set()` order (object addresses): the
+        trace carries the order it used in each step and the replay imposes it, table by table, after checking it
+        names the same blocks."""
+        if not hasattr(bm, "_free_order"):
+            return None
+        default = bm._free_order
+        log = [b for _dev, b in (recorded_order or [])]
+        pos = [0]
+
+        def order(blocks):
+            n = len(set(blocks))
+            want = log[pos[0]:pos[0] + n]
+            pos[0] += n
+            assert sorted(want) == sorted(set(blocks)), (want, blocks)
+            return want
+        if recorded_order:
+            bm._free_order = order
+
+        def finish():
+            bm._free_order = default
+            assert not recorded_order or pos[0] == len(log), "the reference released blocks this replay did not"
+            return recorded_order
+        return finish
+
+    trace = sched_driver.run_program(_make_product_scheduler, bm_driver.ProductAdapter(), gold["config"],
+                                     free_hook=replay_free_hook, recorded=gold["trace"])
+    assert len(trace) == len(gold["trace"]), (len(trace), len(gold["trace"]))
+    for i, (got, want) in enumerate(zip(trace, gold["trace"])):
+        assert got == want, f"step {i}: first difference {[k for k in want if got.get(k) != want[k]]}\n got {got}\n want {want}"
+
+
+def test_scheduler_traces_exist_and_preempt():
+    assert len(_SCHED_TRACES) >= 8
+    preempt = swapped = 0
+    for p in _SCHED_TRACES:
+        with open(p) as f:
+            steps = [t for t in _json.load(f)["trace"] if "groups" in t]
+        preempt += steps[-1]["cumulative_preemption"]
+        swapped += sum(len(t["swap_out"]) for t in steps)
+    assert preempt > 100 and swapped > 100
