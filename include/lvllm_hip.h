@@ -59,8 +59,11 @@ const char* lvllm_version(void);
 /* Launch-shape knobs for the host's concurrency level (process-wide): "gemm_workgroups" (default
  * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4), "attn_splits" (paged_attention_v2:
  * 0 = shares chosen per call, n >= 1 = n shares, -1 = the reference's 512-token partitions),
- * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used). */
+ * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used),
+ * "prefill_mfma32_min_query" (paged_prefill_attention: plain chunks of at least this many query tokens, head size
+ * 64 or 128, 16-bit cache, take the 32x32-MFMA body; 0 = never).  lvllm_get_tuning reads a knob back. */
 int lvllm_set_tuning(const char* key, int value);
+int lvllm_get_tuning(const char* key, int* value);
 
 /* ---- attention (replaces csrc/ops.h:8-27, attention_kernels.cu:808-997) --- */
 

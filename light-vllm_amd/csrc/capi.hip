@@ -15,6 +15,7 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
+    if (const char* e = getenv("LVLLM_PREFILL_MFMA32_MIN_QUERY")) v.prefill_mfma32_min_query = atoi(e);
     return v;
   }();
   return t;
@@ -51,9 +52,30 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
     lvllm::tuning().cache_tile_min_tokens = value;
   } else if (k == "prefill_lds") {
     lvllm::tuning().prefill_lds = value != 0;
+  } else if (k == "prefill_mfma32_min_query") {
+    LV_CHECK(value >= 0, "prefill_mfma32_min_query must be non-negative (0: never)");
+    lvllm::tuning().prefill_mfma32_min_query = value;
   } else {
     LV_CHECK(false, "unknown tuning key '" + k + "'");
   }
+  return 0;
+}
+
+extern "C" int lvllm_get_tuning(const char* key, int* value) {
+  const std::string k = key ? key : "";
+  LV_CHECK(value != nullptr, "null result pointer");
+  const lvllm::Tuning& t = lvllm::tuning();
+  if (k == "gemm_workgroups") *value = t.gemm_workgroups;
+  else if (k == "gemm_workgroups_wide") *value = t.gemm_workgroups_wide;
+  else if (k == "gemm_wide_min_tiles") *value = t.gemm_wide_min_tiles;
+  else if (k == "gemm_partials_ksplit") *value = t.gemm_partials_ksplit;
+  else if (k == "attn_waves") *value = t.attn_waves;
+  else if (k == "attn_splits") *value = t.attn_splits;
+  else if (k == "swap_kernel_min_runs") *value = t.swap_kernel_min_runs;
+  else if (k == "cache_tile_min_tokens") *value = t.cache_tile_min_tokens;
+  else if (k == "prefill_lds") *value = t.prefill_lds;
+  else if (k == "prefill_mfma32_min_query") *value = t.prefill_mfma32_min_query;
+  else LV_CHECK(false, "unknown tuning key '" + k + "'");
   return 0;
 }
 

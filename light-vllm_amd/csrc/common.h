@@ -24,6 +24,7 @@ void set_error(const std::string& msg);
 //   attn_splits      how paged_attention_v2 cuts contexts: 0 automatic, n >= 1 forced, -1 the reference's
 //                    512-token partitions (scratch contents then equal the reference's)
 //   prefill_lds      1 | 0, see Tuning
+//   prefill_mfma32_min_query   see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
   int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
@@ -34,6 +35,7 @@ struct Tuning {
   int swap_kernel_min_runs = 3;  // swap_blocks: more contiguous runs than this (and a pinned host side) -> one kernel
   int cache_tile_min_tokens = 64;  // reshape_and_cache: >= this many tokens take the LDS-tiled kernel
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
+  int prefill_mfma32_min_query = 0;  // chunks at least this long take the 32x32-MFMA body (prefill_mfma32.h); 0 = never
 };
 Tuning& tuning();
 

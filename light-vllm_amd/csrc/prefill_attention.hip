@@ -2,7 +2,7 @@
 #include <algorithm>
 
 #include "../../include/lvllm_hip.h"
-#include "prefill_mfma.h"
+#include "prefill_mfma32.h"
 
 using namespace lvllm;
 

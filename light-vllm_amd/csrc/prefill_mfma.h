@@ -552,9 +552,19 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
 #define LVLLM_PREFILL_NB 2
 #endif
 
+// the 32x32-MFMA body for long plain chunks (prefill_mfma32.h)
+template <typename T, int D, int BS>
+static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream);
+
 template <typename T, int D, int BS>
 static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
   constexpr int NB = D > 128 ? 1 : LVLLM_PREFILL_NB;  // accumulators: NB * D/4 VGPRs per lane
+  if constexpr (D == 64 || D == 128) {
+    const int min_query = tuning().prefill_mfma32_min_query;
+    if (min_query > 0 && max_query_len >= min_query && !p0.kv_fp8 && p0.alibi_slopes == nullptr &&
+        p0.softcap <= 0.f && p0.sliding_window <= 0)
+      return launch_prefill_mfma32<T, D, BS>(p0, num_seqs, max_query_len, stream);
+  }
   PrefillParams p = p0;
   const int G = p.num_heads / p.num_kv_heads;
   const int HG = (G + 15) / 16;

@@ -1,0 +1,381 @@
+// Causal varlen attention of LONG prompt chunks over the paged cache: the 32x32x16-MFMA body
+// (prefill_mfma.h is the 16x16x32 body and the owner of every other case: fp8 caches, ALiBi,
+// soft cap, sliding windows, head sizes other than 64 / 128, short chunks).
+//
+// Same call, same semantics, same parameter block as prefill_mfma.h (flash_attn.py:538-555); what
+// changes is the shape of the work:
+//   * a workgroup = 8 waves = 256 columns = (query token, head of the GQA group) pairs, 32 per wave; the
+//     waves share ONE 64-key tile stream through LDS (4 stages, copies run two tiles ahead by direct-to-LDS
+//     buffer loads, one barrier per tile): half the K/V bytes per FLOP of the 128-column workgroup;
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16: a lane holds 32 keys of ONE column, so the column maximum is
+//     in-lane v_max's plus one half-swap, and an MFMA holds the vector issue port for 8 of its 32 cycles
+//     (16x16x32: 8 of 16) -- the softmax of a wave fits in the gaps of its own MFMAs;
+//   * the paged layouts stay MFMA operands: a K fragment (32 keys x 16 d) is one 16-byte chunk per lane of
+//     the [D/8][BS][8] block, a V^T fragment (32 d x 16 keys) 8 consecutive tokens of a [D][BS] row.  The
+//     LDS images are the blocks' head slices, K verbatim, V with the lanes of each copy permuted so that a
+//     fragment read (ds_read_b128) is 32 consecutive chunks: no bank conflicts, no padding;
+//   * P moves from the S^T accumulator layout (keys 4hi..4hi+3 of every 8) to the B-operand layout (keys
+//     8hi..8hi+7 of every 16) by v_permlane32_swap of the packed words, one swap per 4 probabilities;
+//   * accumulators are rescaled only when some column's maximum grew by more than 2^kGrow over the value
+//     the exponentials use (probabilities stay below 2^kGrow; fp32 sums and the bf16/f16 rounding of P are
+//     relative, so nothing is lost).
+#pragma once
+#include "prefill_mfma.h"
+
+#ifndef LVLLM_PREFILL32_PINGPONG
+#define LVLLM_PREFILL32_PINGPONG 1  // the two waves of a SIMD run half a tile out of phase (needs 4 stages)
+#endif
+#ifndef LVLLM_PREFILL32_STAGES
+#define LVLLM_PREFILL32_STAGES (LVLLM_PREFILL32_PINGPONG ? 4 : 3)
+#endif
+#ifndef LVLLM_PREFILL32_GROW
+#define LVLLM_PREFILL32_GROW 6  // log2 of the growth of a column maximum that forces a rescale
+#endif
+
+namespace lvllm {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <typename T>
+__device__ __forceinline__ f32x16_t mfma32(u32x4_t a, u32x4_t b, f32x16_t c);
+template <>
+__device__ __forceinline__ f32x16_t mfma32<BF16>(u32x4_t a, u32x4_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16_t mfma32<F16>(u32x4_t a, u32x4_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0,
+                                                0, 0);
+}
+
+// lanes 32..63 of a <-> lanes 0..31 of b
+__device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+// Accumulator layout of the 32x32 MFMA: lane (col = lane & 31, hi = lane >> 5), register r holds row
+// (r & 3) + 8 * (r >> 2) + 4 * hi.
+template <typename T, int D, int BS>
+__global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const PrefillParams p) {
+  using S = typename T::store_t;
+  static_assert(sizeof(S) == 2, "16-bit element types");
+  static_assert(BS == 16 || BS == 32, "block size 16 or 32");
+  static_assert(D % 32 == 0 && D <= 128, "head size 32..128, a multiple of 32");
+  constexpr int KT = 64;                         // keys per tile
+  constexpr int NKS = D / 16;                    // k-steps of S^T = K.Q^T
+  constexpr int NDB = D / 32;                    // 32-row blocks of O^T
+  constexpr int kSlice = D * BS * 2;             // bytes of a block's head slice (K or V)
+  constexpr int kBlocksPerTile = KT / BS;
+  constexpr int kImage = kBlocksPerTile * kSlice;  // bytes of the K (or V) image of a tile
+  constexpr int kStage = 2 * kImage;
+  constexpr int kStages = LVLLM_PREFILL32_STAGES;
+  constexpr bool kPingPong = LVLLM_PREFILL32_PINGPONG != 0;
+  constexpr int kAhead = 2;  // tiles between the issue of a copy and the barrier that publishes it
+  static_assert(kStages >= kAhead + (kPingPong ? 2 : 1), "stage count");
+  constexpr int kPiecesPerWave = D / 32;         // 1-KiB copies per wave and tile: 2 * kImage / 1024 / 8
+  constexpr int kPiecesPerSlice = kSlice / 1024;
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr float kMasked = -FLT_MAX;
+  constexpr float kMInit = -1e30f;
+  constexpr float kGrow = (float)LVLLM_PREFILL32_GROW;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, hi = lane >> 5;
+
+  const int GP = 1 << p.gp_shift;    // heads per query token among the 32 columns (group size rounded up)
+  const int TQW = 32 >> p.gp_shift;  // query tokens per wave
+  const int TQWG = 8 * TQW;
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 31) >> 5;
+  const int kvh = blockIdx.x / HG;
+  const int hg = blockIdx.x - kvh * HG;
+  const int head0 = kvh * G + hg * 32;
+  const int nh = min(GP, G - hg * 32);
+  const int seq = blockIdx.y;
+  const int qtile = gridDim.z - 1 - blockIdx.z;  // heaviest first
+
+  const int qbeg = p.query_start_loc[seq];
+  const int qlen = p.query_start_loc[seq + 1] - qbeg;
+  const int seq_len = p.seq_lens != nullptr ? p.seq_lens[seq] : qlen;
+  const int ctx = seq_len - qlen;
+  if (qtile * TQWG >= qlen || ctx < 0) return;
+  const int t_first = qtile * TQWG + wave * TQW;
+  const int nq = max(0, min(TQW, qlen - t_first));  // live query tokens of this wave (0: copies only)
+
+  // keys: the workgroup walks [0, khi_walk), this wave computes the tiles below khi
+  const int khi = nq == 0 ? 0 : (p.causal ? ctx + t_first + nq : seq_len);
+  const int khi_walk = p.causal ? ctx + min(qlen, (qtile + 1) * TQWG) : seq_len;
+  const int ntiles = (khi_walk + KT - 1) / KT;
+  const int my_ntiles = (khi + KT - 1) / KT;
+
+  const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
+  const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const char* vbytes = (const char*)p.v_cache + (int64_t)kvh * p.kv_head_stride * 2;
+  const int64_t bsb = p.kv_block_stride * 2;
+
+  // ---- this lane's column: query token t_first + col / GP, head head0 + col % GP ----
+  const int cq = col >> p.gp_shift, ch = col & (GP - 1);
+  const bool live = ch < nh && cq < nq;
+  const int vlast = live ? (p.causal ? ctx + t_first + cq : seq_len - 1) : -1;  // last visible key
+  u32x4_t qf[NKS];
+  {
+    const S* qrow = (const S*)p.q + (int64_t)(qbeg + t_first + cq) * p.q_stride + (int64_t)(head0 + ch) * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[ks] = u32x4_t{0, 0, 0, 0};
+      if (live) qf[ks] = *reinterpret_cast<const u32x4_t*>(qrow + 16 * ks + 8 * hi);
+    }
+  }
+  const float kf = p.scale * kLog2e;
+
+  const int last_block = p.max_num_blocks_per_seq - 1;
+  const bool arithmetic_blocks = p.block_tables == nullptr;  // the dense twin's scratch tiles (prefill_attention.hip)
+  const int first_block = qbeg / BS + seq;
+  typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;  // scalar loads: prefill_mfma.h
+  const const_i32_ptr block_table_c = (const_i32_ptr)(uintptr_t)block_table;
+  auto block_number = [&](const int blk_idx) __attribute__((always_inline)) -> int {
+    const int blk = min(blk_idx, last_block);
+    return arithmetic_blocks ? first_block + blk : (int)min((uint32_t)block_table_c[blk], (uint32_t)p.max_block);
+  };
+
+  // ---- copies: wave w moves kPiecesPerWave KiB of every tile: K (w < 4) or V, all inside one block ----
+  extern __shared__ __attribute__((aligned(16))) char kv_lds[];
+  const int ld_kind = wave >> 2;
+  const int ld_piece_first = (wave & 3) * kPiecesPerWave;
+  const int ld_blk = ld_piece_first / kPiecesPerSlice;     // block of the tile
+  const int ld_piece0 = ld_piece_first % kPiecesPerSlice;  // first piece inside the block's slice
+  // lane -> source offset inside a piece.  K: verbatim.  V, BS 16: piece = 32 rows of 32 bytes, lane i reads
+  // chunk (row i & 31, half i >> 5); BS 32: piece = 16 rows of 64 bytes, lane i reads (row i & 15, chunk i >> 4).
+  const int ld_voffset = ld_kind == 0 ? lane * 16
+                         : BS == 16   ? (lane & 31) * 32 + (lane >> 5) * 16
+                                      : (lane & 15) * 64 + (lane >> 4) * 16;
+  const char* ld_base = ld_kind ? vbytes : kbytes;
+  auto issue_tile_loads = [&](const int j, const int bn32) __attribute__((always_inline)) {
+    const bool valid = (j * kBlocksPerTile + ld_blk) * BS < khi_walk;
+    __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(ld_base + (int64_t)bn32 * bsb), 0, valid ? kSlice : 0, kSrdFlags);
+    char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024;
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               ld_voffset, (ld_piece0 + i) * 1024, 0, 0);
+  };
+
+  // ---- fragment addresses inside a stage ----
+  // K fragment (half kh, k-step ks): key 32 kh + col, chunk d8 = 2 ks + hi
+  int koff[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const int key = 32 * kh + col;
+    koff[kh] = (key / BS) * kSlice + hi * (BS * 16) + (key % BS) * 16;
+  }
+  constexpr int kKStep = 2 * BS * 16;
+  // V^T fragment (row block db, k-step ks = keys 16 ks + 8 hi ..): row 32 db + col
+  auto voff = [&](const int db, const int ks) __attribute__((always_inline)) -> int {
+    if constexpr (BS == 16) return kImage + ks * kSlice + db * 1024 + hi * 512 + col * 16;
+    else return kImage + (ks >> 1) * kSlice + (2 * db + (col >> 4)) * 1024 + (2 * (ks & 1) + hi) * 256 + (col & 15) * 16;
+  };
+
+  float m_run = kMInit, l_run = 0.f;
+  f32x16_t acc[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+
+  auto half_max = [&](float x) __attribute__((always_inline)) -> float {
+    uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+    half_swap(a, b);
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  };
+
+  // One tile = three phases.  qk and pv are MFMA + LDS reads only, softmax is vector ALU only.
+  auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
+    const char* st = kv_lds + (j % kStages) * kStage;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4_t kfrag = *reinterpret_cast<const u32x4_t*>(st + koff[kh] + ks * kKStep);
+        s[kh] = mfma32<T>(kfrag, qf[ks], s[kh]);
+      }
+    }
+  };
+  // (masked: a wave-uniform run-time flag.  The two cases share ONE body and differ by a branch around the
+  // selects only: with a copy of softmax + P.V per case the accumulators were defined on both arms of a branch,
+  // and the register allocator kept two sets of them -- 256 VGPRs and spills, against 151 for one body.)
+  auto softmax = [&](const int j, const f32x16_t (&s)[2], u32x4_t (&pb)[4], const bool masked) __attribute__((always_inline)) {
+    const int base = j * KT;
+    // ---- column maximum (the logits leave the accumulator tuples as scalars and never go back) ----
+    float y[2][16];
+    const int rel = vlast - base - 4 * hi;  // register r of half kh is key base + 4 hi + (32 kh + (r & 3) + 8 (r >> 2))
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[kh][r] = s[kh][r];
+    if (masked) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[kh][r] = 32 * kh + (r & 3) + 8 * (r >> 2) <= rel ? y[kh][r] : kMasked;
+    }
+    float m_loc = fmaxf(y[0][0], y[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, fmaxf(y[0][r], y[1][r]));
+    m_loc = half_max(m_loc);
+    // ---- rescale (wave-uniform branch) only when some column outgrew the maximum in use by 2^kGrow ----
+    // (the new maximum is taken per column, so a column's arithmetic never depends on its neighbours)
+    const bool grew = (m_loc - m_run) * kf > kGrow;
+    if (__builtin_amdgcn_ballot_w64(grew) != 0) {
+      const float m_new = grew ? fmaxf(m_run, m_loc) : m_run;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kf);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
+      m_run = m_new;
+    }
+    // ---- probabilities, packed and moved to the B-operand layout ----
+    const float mk = m_run * kf;
+    float psum = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      __builtin_amdgcn_sched_barrier(0);  // one half at a time: keeps the live registers at what is written here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        y[kh][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(y[kh][r], kf, -mk));
+        psum += y[kh][r];
+      }
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const int r0 = 8 * g2;
+        uint32_t w0 = pack2<T>(y[kh][r0 + 0], y[kh][r0 + 1]), w1 = pack2<T>(y[kh][r0 + 2], y[kh][r0 + 3]);
+        uint32_t w2 = pack2<T>(y[kh][r0 + 4], y[kh][r0 + 5]), w3 = pack2<T>(y[kh][r0 + 6], y[kh][r0 + 7]);
+        half_swap(w0, w2);
+        half_swap(w1, w3);
+        pb[2 * kh + g2] = u32x4_t{w0, w1, w2, w3};
+      }
+    }
+    l_run += psum;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // O^T += V^T.P^T
+  auto pv = [&](const int j, const u32x4_t (&pb)[4]) __attribute__((always_inline)) {
+    const char* st = kv_lds + (j % kStages) * kStage;
+    const int base = j * KT;
+    const bool tail = base + KT > seq_len;  // V past the sequence may hold anything (NaN included)
+    const int nv0 = seq_len - base - 8 * hi;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t vfrag = *reinterpret_cast<const u32x4_t*>(st + voff(db, ks));
+        if (tail) {  // zero the tokens at or past seq_len: this lane's 8 start at base + 16 ks + 8 hi
+          const int nvalid = nv0 - 16 * ks;  // <= 0: none, >= 8: all
+          const uint32_t w[4] = {vfrag.x, vfrag.y, vfrag.z, vfrag.w};
+          uint32_t z[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            z[i] = nvalid >= 2 * i + 2 ? w[i] : nvalid == 2 * i + 1 ? (w[i] & 0x0000ffffu) : 0u;
+          vfrag = u32x4_t{z[0], z[1], z[2], z[3]};
+        }
+        acc[db] = mfma32<T>(vfrag, pb[ks], acc[db]);
+      }
+    }
+  };
+
+  {
+    // the stages start as zeros: a block past the walk is never copied (zero-size descriptor) and must
+    // still read as finite numbers
+    for (int i = threadIdx.x; i < kStages * kStage / 16; i += 512)
+      reinterpret_cast<u32x4_t*>(kv_lds)[i] = u32x4_t{0, 0, 0, 0};
+    __syncthreads();
+    // copies run kAhead tiles ahead of the barrier that publishes a tile
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) issue_tile_loads(a, block_number(a * kBlocksPerTile + ld_blk));
+    int bn = block_number(kAhead * kBlocksPerTile + ld_blk);
+    // tiles wholly at or before the wave's first query need no mask
+    const int q_first_pos = p.causal ? ctx + t_first : seq_len - 1;
+    const int n_plain = min(my_ntiles, min((q_first_pos + 1) / KT, seq_len / KT));
+    constexpr int kInFlight = (kAhead - 1) * kPiecesPerWave;
+    constexpr int kWait = (kInFlight & 15) | (7 << 4) | (0 << 8) | ((kInFlight >> 4) << 14);
+    // between barrier j and barrier j+1 ("interval j") the copies of tile j + kAhead are issued into the stage
+    // of tile j + kAhead - kStages, which nobody reads any more
+    // "publish(j)": wait for this wave's copies of tile j, meet everybody (all copies of tile j have landed),
+    // issue the copies of tile j + kAhead.  Every wave publishes tiles 0 .. ntiles-1, in order.
+    auto publish = [&](const int j) __attribute__((always_inline)) {
+      __builtin_amdgcn_s_waitcnt(kWait);
+      __builtin_amdgcn_s_barrier();
+      issue_tile_loads(j + kAhead, bn);
+      bn = block_number((j + kAhead + 1) * kBlocksPerTile + ld_blk);
+    };
+    // The second wave of every SIMD (waves w and w + 4 share one) runs half a tile out of phase: it publishes
+    // tile j+1 between K.Q^T and the softmax of tile j, the first wave before K.Q^T of tile j+1.  Between two
+    // barriers the first wave runs {K.Q^T, softmax, P.V} of one tile, the second {softmax, P.V} of the tile
+    // before and K.Q^T of this one: the vector-ALU phase of each falls under MFMAs of the other.
+    const bool late = kPingPong && (wave >> 2) != 0;
+    if (late) publish(0);
+#pragma nounroll
+    for (int j = 0; j < ntiles; ++j) {
+      if (!late) publish(j);
+      if (j < my_ntiles) {
+        f32x16_t s[2];
+        u32x4_t pb[4];
+        qk(j, s);
+        if (late && j + 1 < ntiles) publish(j + 1);
+        softmax(j, s, pb, j >= n_plain);
+        pv(j, pb);
+      } else if (late && j + 1 < ntiles) {
+        publish(j + 1);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // no copy may still be landing when the workgroup's LDS is released
+  }
+
+  // ---- normalise and store: register r of block db is d = 32 db + 8 (r >> 2) + 4 hi + (r & 3) ----
+  {
+    uint32_t a = __builtin_bit_cast(uint32_t, l_run), b = a;
+    half_swap(a, b);
+    const float l = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    const float inv = l > 0.f ? __fdividef(1.f, l) : 0.f;
+    if (live) {
+      S* orow = (S*)p.out + (int64_t)(qbeg + t_first + cq) * p.out_stride + (int64_t)(head0 + ch) * D;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          u32x2_t o;
+          o.x = pack2<T>(acc[db][4 * rq + 0] * inv, acc[db][4 * rq + 1] * inv);
+          o.y = pack2<T>(acc[db][4 * rq + 2] * inv, acc[db][4 * rq + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(orow + 32 * db + 8 * rq + 4 * hi) = o;
+        }
+    }
+  }
+}
+
+// 0 = launched; -1 = not this kernel's case (the caller falls back to prefill_mfma.h)
+template <typename T, int D, int BS>
+static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
+  PrefillParams p = p0;
+  const int G = p.num_heads / p.num_kv_heads;
+  const int HG = (G + 31) / 32;
+  p.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : G <= 16 ? 4 : 5;
+  const int tqwg = 8 * (32 >> p.gp_shift);
+  const int qtiles = (max_query_len + tqwg - 1) / tqwg;
+  const dim3 grid(p.num_kv_heads * HG, num_seqs, qtiles);
+  const size_t smem = (size_t)LVLLM_PREFILL32_STAGES * 2 * D * 64 * 2;
+  auto kern = paged_prefill_mfma32_kernel<T, D, BS>;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+  return 0;
+}
+
+}  // namespace lvllm

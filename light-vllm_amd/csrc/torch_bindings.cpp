@@ -955,6 +955,11 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });
+  amd.def("get_tuning(str key) -> int", [](const std::string& key) {
+    int v = 0;
+    check(lvllm_get_tuning(key.c_str(), &v));
+    return (int64_t)v;
+  });
   amd.def("varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads, "
           "int head_size) -> int", &varlen_attention_workspace_bytes);
   amd.def("varlen_attention(Tensor! out, Tensor query, Tensor key, Tensor value, Tensor cu_seqlens, "

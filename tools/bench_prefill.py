@@ -24,10 +24,14 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--sdpa", action="store_true")
+    ap.add_argument("--mfma32-min-query", type=int, default=None,
+                    help="tuning prefill_mfma32_min_query: chunks at least this long take the 32x32-MFMA body (0: never)")
     ap.add_argument("--dense", action="store_true", help="lvllm_varlen_attention on dense q/k/v (no cache)")
     ap.add_argument("--encoder", action="store_true", help="with --dense: bidirectional attention")
     a = ap.parse_args()
     dev = "cuda:0"
+    if a.mfma32_min_query is not None:
+        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", a.mfma32_min_query)
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     B, H, KVH, D, BS = a.seqs, a.heads, a.kv_heads, a.head_size, a.block_size
     S = a.ctx + a.qlen
