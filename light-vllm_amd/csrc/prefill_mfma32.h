@@ -5,8 +5,10 @@
 // Same call, same semantics, same parameter block as prefill_mfma.h (flash_attn.py:538-555); what
 // changes is the shape of the work:
 //   * a workgroup = 8 waves = 256 columns = (query token, head of the GQA group) pairs, 32 per wave; the
-//     waves share ONE 64-key tile stream through LDS (4 stages, copies run two tiles ahead by direct-to-LDS
-//     buffer loads, one barrier per tile): half the K/V bytes per FLOP of the 128-column workgroup;
+//     waves share ONE 64-key tile stream through LDS (2 or 3 stages, one barrier per tile): half the K/V bytes
+//     per FLOP of the 128-column workgroup.  Each wave copies 1/8 of every tile through registers
+//     (buffer_load_dwordx4 when the tile before is published, ds_write_b128 a phase later): direct-to-LDS
+//     copies cost their wave 60-185 issue cycles per KiB among MFMAs and were 22 % of the time;
 //   * S^T = K.Q^T with v_mfma_f32_32x32x16: a lane holds 32 keys of ONE column, so the column maximum is
 //     in-lane v_max's plus one half-swap, and an MFMA holds the vector issue port for 8 of its 32 cycles
 //     (16x16x32: 8 of 16) -- the softmax of a wave fits in the gaps of its own MFMAs;
@@ -23,18 +25,34 @@
 #include "prefill_mfma.h"
 
 #ifndef LVLLM_PREFILL32_PINGPONG
-#define LVLLM_PREFILL32_PINGPONG 1  // the two waves of a SIMD run half a tile out of phase (needs 4 stages)
+#define LVLLM_PREFILL32_PINGPONG 1  // the two waves of a SIMD run half a tile out of phase (3 stages instead of 2)
 #endif
 #ifndef LVLLM_PREFILL32_STAGES
-#define LVLLM_PREFILL32_STAGES (LVLLM_PREFILL32_PINGPONG ? 4 : 3)
+#define LVLLM_PREFILL32_STAGES (LVLLM_PREFILL32_PINGPONG ? 3 : 2)
+#endif
+#ifndef LVLLM_PREFILL32_PRIO
+#define LVLLM_PREFILL32_PRIO 0  // 1: s_setprio 1 for waves 4..7; 2: s_setprio 1 around the MFMA phases of every wave
+#endif
+#ifndef LVLLM_PREFILL32_DIAG
+// timing-diagnosis builds (WRONG results; tools/ab_prefill32.sh): 1 = no copies after the prologue, 2 = no
+// exponentials, 4 = no barriers, 8 = no maximum / rescale, 16 = no LDS reads (fragments = registers)
+#define LVLLM_PREFILL32_DIAG 0
 #endif
 #ifndef LVLLM_PREFILL32_GROW
 #define LVLLM_PREFILL32_GROW 6  // log2 of the growth of a column maximum that forces a rescale
 #endif
 
+#ifndef LVLLM_PREFILL32_STAMPS
+#define LVLLM_PREFILL32_STAMPS 0  // diagnosis build: s_memtime at the phase boundaries of one workgroup (tools/stamps_prefill32.py)
+#endif
+
 namespace lvllm {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#if LVLLM_PREFILL32_STAMPS
+constexpr int kStampTiles = 24, kStampPerTile = 8;
+__device__ unsigned long long g_prefill32_stamps[8 * kStampTiles * kStampPerTile];
+#endif
 
 template <typename T>
 __device__ __forceinline__ f32x16_t mfma32(u32x4_t a, u32x4_t b, f32x16_t c);
@@ -73,8 +91,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   constexpr int kStage = 2 * kImage;
   constexpr int kStages = LVLLM_PREFILL32_STAGES;
   constexpr bool kPingPong = LVLLM_PREFILL32_PINGPONG != 0;
-  constexpr int kAhead = 2;  // tiles between the issue of a copy and the barrier that publishes it
-  static_assert(kStages >= kAhead + (kPingPong ? 2 : 1), "stage count");
+  static_assert(kStages >= (kPingPong ? 3 : 2), "stage count");
   constexpr int kPiecesPerWave = D / 32;         // 1-KiB copies per wave and tile: 2 * kImage / 1024 / 8
   constexpr int kPiecesPerSlice = kSlice / 1024;
   constexpr float kLog2e = 1.4426950408889634f;
@@ -154,15 +171,32 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
                          : BS == 16   ? (lane & 31) * 32 + (lane >> 5) * 16
                                       : (lane & 15) * 64 + (lane >> 4) * 16;
   const char* ld_base = ld_kind ? vbytes : kbytes;
-  auto issue_tile_loads = [&](const int j, const int bn32) __attribute__((always_inline)) {
+  // through registers: fetch(j) issues the loads of tile j, stash(j) writes them to tile j's stage (a block past
+  // the walk reads as zeros through its zero-size descriptor)
+  u32x4_t staged[kPiecesPerWave];
+  auto fetch = [&](const int j, const int bn32) __attribute__((always_inline)) {
     const bool valid = (j * kBlocksPerTile + ld_blk) * BS < khi_walk;
     __amdgpu_buffer_rsrc_t r =
         __builtin_amdgcn_make_buffer_rsrc((void*)(ld_base + (int64_t)bn32 * bsb), 0, valid ? kSlice : 0, kSrdFlags);
-    char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024;
 #pragma unroll
     for (int i = 0; i < kPiecesPerWave; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                               ld_voffset, (ld_piece0 + i) * 1024, 0, 0);
+      staged[i] = __builtin_amdgcn_raw_buffer_load_b128(r, ld_voffset, (ld_piece0 + i) * 1024, 0);
+  };
+  // V past the sequence may hold anything (NaN included) and 0 * NaN is NaN: the copying wave zeroes those tokens
+  // on their way to LDS (branch-free: four dword masks per tile, all ones for K and for tiles inside the
+  // sequence).  K needs nothing: a logit of a key past the sequence is replaced, not used.
+  // This lane's 16 bytes of a V piece are 8 consecutive tokens of one row, starting at ld_tok0 of the tile.
+  const int ld_tok0 = ld_blk * BS + (BS == 16 ? (lane >> 5) : (lane >> 4)) * 8;
+  auto stash = [&](const int j) __attribute__((always_inline)) {
+    char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024 + lane * 16;
+    const int nvalid = ld_kind == 0 ? 8 : seq_len - (j * KT + ld_tok0);  // <= 0: none, >= 8: all
+    uint32_t m[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) m[q2] = nvalid >= 2 * q2 + 2 ? 0xffffffffu : nvalid == 2 * q2 + 1 ? 0x0000ffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      *reinterpret_cast<u32x4_t*>(dst + i * 1024) =
+          u32x4_t{staged[i].x & m[0], staged[i].y & m[1], staged[i].z & m[2], staged[i].w & m[3]};
   };
 
   // ---- fragment addresses inside a stage ----
@@ -193,19 +227,49 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
   };
 
-  // One tile = three phases.  qk and pv are MFMA + LDS reads only, softmax is vector ALU only.
+  // One tile = three phases.  qk and pv are MFMA + LDS reads only, softmax is vector ALU only.  The LDS reads
+  // run a window of kWin fragments ahead of the MFMAs that consume them (a ds_read_b128 takes a few hundred
+  // cycles to return with 8 waves reading; two in flight per wave, as the compiler arranges by itself, left the
+  // MFMA pipe waiting for operands a quarter of the time), and the first window of V is read BEFORE the softmax.
+  constexpr int kWin = 8;
+  constexpr int NV = 4 * NDB;  // V^T fragments of a tile, in the order (row block db, k-step ks)
+  auto kread = [&](const char* st, const int kh, const int ks) __attribute__((always_inline)) -> u32x4_t {
+    if constexpr (LVLLM_PREFILL32_DIAG & 16) return qf[(ks + 1) % NKS];
+    return *reinterpret_cast<const u32x4_t*>(st + koff[kh] + ks * kKStep);
+  };
+  auto vread = [&](const char* st, const int i) __attribute__((always_inline)) -> u32x4_t {
+    if constexpr (LVLLM_PREFILL32_DIAG & 16) return qf[i % NKS];
+    return *reinterpret_cast<const u32x4_t*>(st + voff(i >> 2, i & 3));
+  };
   auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
     const char* st = kv_lds + (j % kStages) * kStage;
+    if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);  // MFMA phases win the issue arbitration
+    static_assert(NKS <= kWin, "one half of K.Q^T fits the window");
+    u32x4_t kw[NKS];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
+    for (int ks = 0; ks < NKS; ++ks) kw[ks] = kread(st, 0, ks);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+    // (a scheduling fence after every step: the order written is the order wanted -- left alone, the scheduler
+    // sinks every read to just before its use, and sched_group_barrier cannot say WHICH reads go first)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const u32x4_t kfrag = *reinterpret_cast<const u32x4_t*>(st + koff[kh] + ks * kKStep);
-        s[kh] = mfma32<T>(kfrag, qf[ks], s[kh]);
-      }
+    for (int ks = 0; ks < NKS; ++ks) {
+      s[0] = mfma32<T>(kw[ks], qf[ks], s[0]);
+      kw[ks] = kread(st, 1, ks);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) s[1] = mfma32<T>(kw[ks], qf[ks], s[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+  };
+  auto vpre = [&](const int j, u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
+    const char* st = kv_lds + (j % kStages) * kStage;
+#pragma unroll
+    for (int i = 0; i < kWin; ++i) vw[i] = vread(st, i);
   };
   // (masked: a wave-uniform run-time flag.  The two cases share ONE body and differ by a branch around the
   // selects only: with a copy of softmax + P.V per case the accumulators were defined on both arms of a branch,
@@ -225,117 +289,168 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[kh][r] = 32 * kh + (r & 3) + 8 * (r >> 2) <= rel ? y[kh][r] : kMasked;
     }
-    float m_loc = fmaxf(y[0][0], y[1][0]);
+    // ---- probabilities against the maximum in use, issued before the new maximum is known: the maximum is a
+    // dependent chain (4 short ones here) ending in a branch, and the exponentials need not wait for it ----
+    // (fused multiply-adds and sums as 2-wide packed instructions: half the issue slots of this phase's
+    // full-rate arithmetic; the MFMA pipe of this wave is idle here, so the packed forms cost nothing beside it)
+    float e[2][16];
+    auto exps = [&](const float mk) __attribute__((always_inline)) {
+      const f32x2_t kf2 = {kf, kf}, nmk2 = {-mk, -mk};
 #pragma unroll
-    for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, fmaxf(y[0][r], y[1][r]));
-    m_loc = half_max(m_loc);
-    // ---- rescale (wave-uniform branch) only when some column outgrew the maximum in use by 2^kGrow ----
-    // (the new maximum is taken per column, so a column's arithmetic never depends on its neighbours)
-    const bool grew = (m_loc - m_run) * kf > kGrow;
-    if (__builtin_amdgcn_ballot_w64(grew) != 0) {
-      const float m_new = grew ? fmaxf(m_run, m_loc) : m_run;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kf);
-      l_run *= alpha;
+      for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int db = 0; db < NDB; ++db)
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t t = __builtin_elementwise_fma(f32x2_t{y[kh][r], y[kh][r + 1]}, kf2, nmk2);
+          if constexpr (LVLLM_PREFILL32_DIAG & 2) {
+            e[kh][r] = t.x;
+            e[kh][r + 1] = t.y;
+          } else {
+            e[kh][r] = __builtin_amdgcn_exp2f(t.x);
+            e[kh][r + 1] = __builtin_amdgcn_exp2f(t.y);
+          }
+        }
+    };
+    exps(m_run * kf);
+    if constexpr (!(LVLLM_PREFILL32_DIAG & 8)) {
+      float m4[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
-      m_run = m_new;
+      for (int c4 = 0; c4 < 4; ++c4) {
+        m4[c4] = fmaxf(y[0][4 * c4], y[1][4 * c4]);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) m4[c4] = fmaxf(m4[c4], fmaxf(y[0][4 * c4 + r], y[1][4 * c4 + r]));
+      }
+      const float m_loc = half_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+      // ---- some column outgrew the maximum in use by 2^kGrow (wave-uniform branch): rescale, and redo the
+      // exponentials.  The new maximum is taken per column, so a column's arithmetic never depends on its
+      // neighbours. ----
+      const bool grew = (m_loc - m_run) * kf > kGrow;
+      if (__builtin_amdgcn_ballot_w64(grew) != 0) {
+        const float m_new = grew ? fmaxf(m_run, m_loc) : m_run;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kf);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
+        m_run = m_new;
+        exps(m_run * kf);
+      }
     }
-    // ---- probabilities, packed and moved to the B-operand layout ----
-    const float mk = m_run * kf;
-    float psum = 0.f;
+    // ---- row sums, packing, and the move to the B-operand layout ----
+    f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      __builtin_amdgcn_sched_barrier(0);  // one half at a time: keeps the live registers at what is written here
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        y[kh][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(y[kh][r], kf, -mk));
-        psum += y[kh][r];
-      }
+      for (int r = 0; r < 16; r += 2) psum2 += f32x2_t{e[kh][r], e[kh][r + 1]};
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int r0 = 8 * g2;
-        uint32_t w0 = pack2<T>(y[kh][r0 + 0], y[kh][r0 + 1]), w1 = pack2<T>(y[kh][r0 + 2], y[kh][r0 + 3]);
-        uint32_t w2 = pack2<T>(y[kh][r0 + 4], y[kh][r0 + 5]), w3 = pack2<T>(y[kh][r0 + 6], y[kh][r0 + 7]);
+        uint32_t w0 = pack2<T>(e[kh][r0 + 0], e[kh][r0 + 1]), w1 = pack2<T>(e[kh][r0 + 2], e[kh][r0 + 3]);
+        uint32_t w2 = pack2<T>(e[kh][r0 + 4], e[kh][r0 + 5]), w3 = pack2<T>(e[kh][r0 + 6], e[kh][r0 + 7]);
         half_swap(w0, w2);
         half_swap(w1, w3);
         pb[2 * kh + g2] = u32x4_t{w0, w1, w2, w3};
       }
     }
-    l_run += psum;
+    l_run += psum2.x + psum2.y;
     __builtin_amdgcn_sched_barrier(0);
   };
   // O^T += V^T.P^T
-  auto pv = [&](const int j, const u32x4_t (&pb)[4]) __attribute__((always_inline)) {
+  auto pv = [&](const int j, const u32x4_t (&pb)[4], u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
     const char* st = kv_lds + (j % kStages) * kStage;
-    const int base = j * KT;
-    const bool tail = base + KT > seq_len;  // V past the sequence may hold anything (NaN included)
-    const int nv0 = seq_len - base - 8 * hi;
+    static_assert(NV >= kWin, "the window is at most one tile of V");
+    if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t vfrag = *reinterpret_cast<const u32x4_t*>(st + voff(db, ks));
-        if (tail) {  // zero the tokens at or past seq_len: this lane's 8 start at base + 16 ks + 8 hi
-          const int nvalid = nv0 - 16 * ks;  // <= 0: none, >= 8: all
-          const uint32_t w[4] = {vfrag.x, vfrag.y, vfrag.z, vfrag.w};
-          uint32_t z[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            z[i] = nvalid >= 2 * i + 2 ? w[i] : nvalid == 2 * i + 1 ? (w[i] & 0x0000ffffu) : 0u;
-          vfrag = u32x4_t{z[0], z[1], z[2], z[3]};
-        }
-        acc[db] = mfma32<T>(vfrag, pb[ks], acc[db]);
+    for (int i = 0; i < NV; ++i) {
+      acc[i >> 2] = mfma32<T>(vw[i % kWin], pb[i & 3], acc[i >> 2]);
+      if (i + kWin < NV) {
+        vw[i % kWin] = vread(st, i + kWin);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
   };
 
   {
-    // the stages start as zeros: a block past the walk is never copied (zero-size descriptor) and must
-    // still read as finite numbers
-    for (int i = threadIdx.x; i < kStages * kStage / 16; i += 512)
-      reinterpret_cast<u32x4_t*>(kv_lds)[i] = u32x4_t{0, 0, 0, 0};
-    __syncthreads();
-    // copies run kAhead tiles ahead of the barrier that publishes a tile
-#pragma unroll
-    for (int a = 0; a < kAhead; ++a) issue_tile_loads(a, block_number(a * kBlocksPerTile + ld_blk));
-    int bn = block_number(kAhead * kBlocksPerTile + ld_blk);
     // tiles wholly at or before the wave's first query need no mask
     const int q_first_pos = p.causal ? ctx + t_first : seq_len - 1;
     const int n_plain = min(my_ntiles, min((q_first_pos + 1) / KT, seq_len / KT));
-    constexpr int kInFlight = (kAhead - 1) * kPiecesPerWave;
-    constexpr int kWait = (kInFlight & 15) | (7 << 4) | (0 << 8) | ((kInFlight >> 4) << 14);
-    // between barrier j and barrier j+1 ("interval j") the copies of tile j + kAhead are issued into the stage
-    // of tile j + kAhead - kStages, which nobody reads any more
-    // "publish(j)": wait for this wave's copies of tile j, meet everybody (all copies of tile j have landed),
-    // issue the copies of tile j + kAhead.  Every wave publishes tiles 0 .. ntiles-1, in order.
+    // Copies: fetch(j+1) is issued when tile j is published, stash(j+1) writes it to LDS one phase before the
+    // barrier that publishes it -- after the softmax of tile j, so that the loads have had K.Q^T and the softmax
+    // to arrive and the writes drain under P.V.  The stage of tile j+1 held tile j+1-kStages, which every wave
+    // has left behind before the barrier of tile j.
+    fetch(0, block_number(ld_blk));
+    int bn = block_number(kBlocksPerTile + ld_blk);
+    stash(0);
+#if LVLLM_PREFILL32_STAMPS
+    // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
+    const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 8 && lane == 0;
+    auto stamp = [&](const int j, const int k) __attribute__((always_inline)) {
+      if (stamping && j >= 8 && j < 8 + kStampTiles)
+        g_prefill32_stamps[(wave * kStampTiles + (j - 8)) * kStampPerTile + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](const int, const int) __attribute__((always_inline)) {};
+#endif
+    // "publish(j)": this wave's part of tile j is in LDS; meet everybody (all of tile j is); start loading tile j+1.
+    // Every wave publishes tiles 0 .. ntiles-1, in order.
     auto publish = [&](const int j) __attribute__((always_inline)) {
-      __builtin_amdgcn_s_waitcnt(kWait);
-      __builtin_amdgcn_s_barrier();
-      issue_tile_loads(j + kAhead, bn);
-      bn = block_number((j + kAhead + 1) * kBlocksPerTile + ld_blk);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's writes have reached LDS
+      stamp(j, 6);
+      if constexpr (!(LVLLM_PREFILL32_DIAG & 4)) __builtin_amdgcn_s_barrier();
+      stamp(j, 7);
+      if constexpr (!(LVLLM_PREFILL32_DIAG & 1)) {
+        fetch(j + 1, bn);
+        bn = block_number((j + 2) * kBlocksPerTile + ld_blk);
+      }
     };
     // The second wave of every SIMD (waves w and w + 4 share one) runs half a tile out of phase: it publishes
     // tile j+1 between K.Q^T and the softmax of tile j, the first wave before K.Q^T of tile j+1.  Between two
     // barriers the first wave runs {K.Q^T, softmax, P.V} of one tile, the second {softmax, P.V} of the tile
     // before and K.Q^T of this one: the vector-ALU phase of each falls under MFMAs of the other.
-    const bool late = kPingPong && (wave >> 2) != 0;
-    if (late) publish(0);
+    // (One straight-line loop per role, and the tiles a wave only copies in a loop of their own: a tile body
+    // under a condition leaves the 64 accumulator registers defined on two paths, and the compiler then moves
+    // all of them at every loop end.)
+    auto run = [&](auto late_tag) __attribute__((always_inline)) {
+      constexpr bool late = decltype(late_tag)::value;
+      if constexpr (late) publish(0);
+      int j = 0;
 #pragma nounroll
-    for (int j = 0; j < ntiles; ++j) {
-      if (!late) publish(j);
-      if (j < my_ntiles) {
+      for (; j < my_ntiles; ++j) {
+        stamp(j, 0);
+        if constexpr (!late) publish(j);
+        stamp(j, 1);
         f32x16_t s[2];
-        u32x4_t pb[4];
+        u32x4_t pb[4], vw[kWin];
         qk(j, s);
-        if (late && j + 1 < ntiles) publish(j + 1);
+        stamp(j, 2);
+        if constexpr (late) {
+          stash(j + 1);
+          if (j + 1 < ntiles) publish(j + 1);
+        }
+        stamp(j, 3);
+        vpre(j, vw);  // the first window of V: in flight during the softmax
+        __builtin_amdgcn_sched_barrier(0);
         softmax(j, s, pb, j >= n_plain);
-        pv(j, pb);
-      } else if (late && j + 1 < ntiles) {
-        publish(j + 1);
+        stamp(j, 4);
+        if constexpr (!late) stash(j + 1);
+        pv(j, pb, vw);
+        stamp(j, 5);
       }
-    }
+#pragma nounroll
+      for (; j < ntiles; ++j) {  // tiles this wave copies for the others
+        if constexpr (!late) publish(j);
+        stash(j + 1);
+        if constexpr (late)
+          if (j + 1 < ntiles) publish(j + 1);
+      }
+    };
+#if LVLLM_PREFILL32_PRIO == 1
+    if (wave >> 2) __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise
+#endif
+    if (LVLLM_PREFILL32_PINGPONG == 2 || (kPingPong && (wave >> 2) != 0)) run(std::true_type{});  // 2: diagnosis
+    else run(std::false_type{});
     __builtin_amdgcn_s_waitcnt(0);  // no copy may still be landing when the workgroup's LDS is released
   }
 
@@ -375,6 +490,23 @@ static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+#if LVLLM_PREFILL32_STAMPS
+  if (getenv("LVLLM_PREFILL32_STAMP_FILE")) {
+    static unsigned long long host[8 * kStampTiles * kStampPerTile];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prefill32_stamps), sizeof(host));
+    FILE* f = fopen(getenv("LVLLM_PREFILL32_STAMP_FILE"), "w");
+    if (f) {
+      for (int w = 0; w < 8; ++w)
+        for (int t = 0; t < kStampTiles; ++t) {
+          fprintf(f, "%d %d", w, t + 8);
+          for (int k = 0; k < kStampPerTile; ++k) fprintf(f, " %llu", host[(w * kStampTiles + t) * kStampPerTile + k]);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    }
+  }
+#endif
   return 0;
 }
 

@@ -7,6 +7,9 @@
                                                                  (FETCH_SIZE, WRITE_SIZE; KB units), with the gfx950 correction of
                                                                  /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE x 2 for wide
                                                                  coalesced streaming reads)
+  python tools/prof_summary.py counters <kernel substring> <out.json> <dir>...
+                                                                 per-launch means of every counter found under the dirs
+                                                                 (one --pmc pass each) for one kernel
 """
 import csv
 import glob
@@ -67,8 +70,24 @@ def pmc(fetch_dir, write_dir, kernel, algo, out):
     print(json.dumps(res, indent=1))
 
 
+def counters(kernel, out, dirs):
+    res = {}
+    for d in dirs:
+        acc = {}
+        for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for name, vals in acc.items():
+            vals = vals[len(vals) // 4:]
+            res[name] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]), sys.argv[6])
