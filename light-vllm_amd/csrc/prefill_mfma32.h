@@ -25,7 +25,7 @@
 #include "prefill_mfma.h"
 
 #ifndef LVLLM_PREFILL32_PINGPONG
-#define LVLLM_PREFILL32_PINGPONG 1  // the two waves of a SIMD run half a tile out of phase (3 stages instead of 2)
+#define LVLLM_PREFILL32_PINGPONG 0  // 1: the two waves of a SIMD run half a tile out of phase (3 stages instead of 2)
 #endif
 #ifndef LVLLM_PREFILL32_STAGES
 #define LVLLM_PREFILL32_STAGES (LVLLM_PREFILL32_PINGPONG ? 3 : 2)
@@ -152,11 +152,16 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   const int last_block = p.max_num_blocks_per_seq - 1;
   const bool arithmetic_blocks = p.block_tables == nullptr;  // the dense twin's scratch tiles (prefill_attention.hip)
   const int first_block = qbeg / BS + seq;
-  typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;  // scalar loads: prefill_mfma.h
-  const const_i32_ptr block_table_c = (const_i32_ptr)(uintptr_t)block_table;
-  auto block_number = [&](const int blk_idx) __attribute__((always_inline)) -> int {
-    const int blk = min(blk_idx, last_block);
-    return arithmetic_blocks ? first_block + blk : (int)min((uint32_t)block_table_c[blk], (uint32_t)p.max_block);
+  // Block numbers: lane l of `bt_chunk` holds the block this wave copies in tile 64 c + l of the current chunk c of
+  // 64 tiles -- one vector load per 64 tiles, then a v_readlane per tile.  (A scalar load per tile sat in the
+  // loop with its wait right behind it: a few hundred cycles of every wave's tile.)
+  int bt_chunk = 0;
+  auto load_block_chunk = [&](const int c, const int ld_blk_) __attribute__((always_inline)) {
+    const int blk = min(((c << 6) + lane) * kBlocksPerTile + ld_blk_, last_block);
+    bt_chunk = arithmetic_blocks ? first_block + blk : (int)min((uint32_t)block_table[blk], (uint32_t)p.max_block);
+  };
+  auto block_of_tile = [&](const int j) __attribute__((always_inline)) -> int {
+    return __builtin_amdgcn_readlane(bt_chunk, j & 63);
   };
 
   // ---- copies: wave w moves kPiecesPerWave KiB of every tile: K (w < 4) or V, all inside one block ----
@@ -183,20 +188,25 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
       staged[i] = __builtin_amdgcn_raw_buffer_load_b128(r, ld_voffset, (ld_piece0 + i) * 1024, 0);
   };
   // V past the sequence may hold anything (NaN included) and 0 * NaN is NaN: the copying wave zeroes those tokens
-  // on their way to LDS (branch-free: four dword masks per tile, all ones for K and for tiles inside the
-  // sequence).  K needs nothing: a logit of a key past the sequence is replaced, not used.
+  // on their way to LDS (only in the tile that holds the end of the sequence).  K needs nothing: a logit of a key
+  // past the sequence is replaced, not used.
   // This lane's 16 bytes of a V piece are 8 consecutive tokens of one row, starting at ld_tok0 of the tile.
   const int ld_tok0 = ld_blk * BS + (BS == 16 ? (lane >> 5) : (lane >> 4)) * 8;
   auto stash = [&](const int j) __attribute__((always_inline)) {
     char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024 + lane * 16;
-    const int nvalid = ld_kind == 0 ? 8 : seq_len - (j * KT + ld_tok0);  // <= 0: none, >= 8: all
-    uint32_t m[4];
+    if (ld_kind == 1 && j * KT + KT > seq_len) {  // (wave-uniform; the copy registers themselves are never modified)
+      const int nvalid = seq_len - (j * KT + ld_tok0);  // <= 0: none, >= 8: all
+      uint32_t m[4];
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) m[q2] = nvalid >= 2 * q2 + 2 ? 0xffffffffu : nvalid == 2 * q2 + 1 ? 0x0000ffffu : 0u;
+      for (int q2 = 0; q2 < 4; ++q2) m[q2] = nvalid >= 2 * q2 + 2 ? 0xffffffffu : nvalid == 2 * q2 + 1 ? 0x0000ffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < kPiecesPerWave; ++i)
-      *reinterpret_cast<u32x4_t*>(dst + i * 1024) =
-          u32x4_t{staged[i].x & m[0], staged[i].y & m[1], staged[i].z & m[2], staged[i].w & m[3]};
+      for (int i = 0; i < kPiecesPerWave; ++i)
+        *reinterpret_cast<u32x4_t*>(dst + i * 1024) =
+            u32x4_t{staged[i].x & m[0], staged[i].y & m[1], staged[i].z & m[2], staged[i].w & m[3]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < kPiecesPerWave; ++i) *reinterpret_cast<u32x4_t*>(dst + i * 1024) = staged[i];
+    }
   };
 
   // ---- fragment addresses inside a stage ----
@@ -244,10 +254,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
     const char* st = kv_lds + (j % kStages) * kStage;
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);  // MFMA phases win the issue arbitration
-    static_assert(NKS <= kWin, "one half of K.Q^T fits the window");
-    u32x4_t kw[NKS];
+    u32x4_t kw[kWin];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) kw[ks] = kread(st, 0, ks);
+    for (int i = 0; i < kWin; ++i) kw[i] = kread(st, i / NKS, i % NKS);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -256,14 +265,11 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     // sinks every read to just before its use, and sched_group_barrier cannot say WHICH reads go first)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      s[0] = mfma32<T>(kw[ks], qf[ks], s[0]);
-      kw[ks] = kread(st, 1, ks);
+    for (int i = 0; i < 2 * NKS; ++i) {
+      s[i / NKS] = mfma32<T>(kw[i % kWin], qf[i % NKS], s[i / NKS]);
+      if (i + kWin < 2 * NKS) kw[i % kWin] = kread(st, (i + kWin) / NKS, (i + kWin) % NKS);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) s[1] = mfma32<T>(kw[ks], qf[ks], s[1]);
-    __builtin_amdgcn_sched_barrier(0);
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
   };
   auto vpre = [&](const int j, u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
@@ -380,8 +386,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     // barrier that publishes it -- after the softmax of tile j, so that the loads have had K.Q^T and the softmax
     // to arrive and the writes drain under P.V.  The stage of tile j+1 held tile j+1-kStages, which every wave
     // has left behind before the barrier of tile j.
-    fetch(0, block_number(ld_blk));
-    int bn = block_number(kBlocksPerTile + ld_blk);
+    load_block_chunk(0, ld_blk);
+    fetch(0, block_of_tile(0));
     stash(0);
 #if LVLLM_PREFILL32_STAMPS
     // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
@@ -401,8 +407,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
       if constexpr (!(LVLLM_PREFILL32_DIAG & 4)) __builtin_amdgcn_s_barrier();
       stamp(j, 7);
       if constexpr (!(LVLLM_PREFILL32_DIAG & 1)) {
-        fetch(j + 1, bn);
-        bn = block_number((j + 2) * kBlocksPerTile + ld_blk);
+        if (((j + 1) & 63) == 0) load_block_chunk((j + 1) >> 6, ld_blk);
+        fetch(j + 1, block_of_tile(j + 1));
       }
     };
     // The second wave of every SIMD (waves w and w + 4 share one) runs half a tile out of phase: it publishes

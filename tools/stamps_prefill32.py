@@ -18,5 +18,6 @@ for w in range(8):
         v = rows[(w, t)]
         if not v[0]:
             continue
-        print(f"wave {w} tile {t}: top {v[0] - t0:6d} | publish {v[1] - v[0]:5d} | qk {v[2] - v[1]:5d} | mid {v[3] - v[2]:5d} | "
-              f"softmax {v[4] - v[3]:5d} | pv {v[5] - v[4]:5d} | barrier wait {v[7] - v[6]:5d}")
+        names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["publish", "qk", "mid", "softmax", "pv"]
+        print(f"wave {w} tile {t}: top {v[0] - t0:6d} | " + " | ".join(f"{n} {v[i + 1] - v[i]:5d}" for i, n in enumerate(names))
+              + f" | barrier wait {v[7] - v[6]:5d}")
