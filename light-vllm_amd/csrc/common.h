@@ -35,7 +35,8 @@ struct Tuning {
   int swap_kernel_min_runs = 3;  // swap_blocks: more contiguous runs than this (and a pinned host side) -> one kernel
   int cache_tile_min_tokens = 64;  // reshape_and_cache: >= this many tokens take the LDS-tiled kernel
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
-  int prefill_mfma32_min_query = 0;  // chunks at least this long take the 32x32-MFMA body (prefill_mfma32.h); 0 = never
+  int prefill_mfma32_min_query = 64;  // launches whose longest chunk has at least this many query tokens take the
+                                      // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache); 0 = never
 };
 Tuning& tuning();
 

@@ -30,6 +30,9 @@
 #ifndef LVLLM_PREFILL32_STAGES
 #define LVLLM_PREFILL32_STAGES (LVLLM_PREFILL32_PINGPONG ? 3 : 2)
 #endif
+#ifndef LVLLM_PREFILL32_KWIN
+#define LVLLM_PREFILL32_KWIN 8
+#endif
 #ifndef LVLLM_PREFILL32_PRIO
 #define LVLLM_PREFILL32_PRIO 0  // 1: s_setprio 1 for waves 4..7; 2: s_setprio 1 around the MFMA phases of every wave
 #endif
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   // cycles to return with 8 waves reading; two in flight per wave, as the compiler arranges by itself, left the
   // MFMA pipe waiting for operands a quarter of the time), and the first window of V is read BEFORE the softmax.
   constexpr int kWin = 8;
+  constexpr int kWinK = LVLLM_PREFILL32_KWIN;  // window of the K fragments
   constexpr int NV = 4 * NDB;  // V^T fragments of a tile, in the order (row block db, k-step ks)
   auto kread = [&](const char* st, const int kh, const int ks) __attribute__((always_inline)) -> u32x4_t {
     if constexpr (LVLLM_PREFILL32_DIAG & 16) return qf[(ks + 1) % NKS];
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
     const char* st = kv_lds + (j % kStages) * kStage;
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);  // MFMA phases win the issue arbitration
-    u32x4_t kw[kWin];
+    u32x4_t kw[kWinK];
 #pragma unroll
-    for (int i = 0; i < kWin; ++i) kw[i] = kread(st, i / NKS, i % NKS);
+    for (int i = 0; i < kWinK; ++i) kw[i] = kread(st, i / NKS, i % NKS);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 2 * NKS; ++i) {
-      s[i / NKS] = mfma32<T>(kw[i % kWin], qf[i % NKS], s[i / NKS]);
-      if (i + kWin < 2 * NKS) kw[i % kWin] = kread(st, (i + kWin) / NKS, (i + kWin) % NKS);
+      s[i / NKS] = mfma32<T>(kw[i % kWinK], qf[i % NKS], s[i / NKS]);
+      if (i + kWinK < 2 * NKS) kw[i % kWinK] = kread(st, (i + kWinK) / NKS, (i + kWinK) % NKS);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(0);

@@ -18,6 +18,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def first_body_everywhere(ops, request):
+    """These cases pin prefill_mfma.h (the 16x16x32 body: every head size, fp8 caches, masks and biases, short
+    chunks); tests/test_prefill_mfma32_gpu.py runs the same cases through the 32x32-MFMA body, and
+    test_prefill_dispatch_* below the shipped choice between the two."""
+    default = int(torch.ops._C_amd.get_tuning("prefill_mfma32_min_query"))
+    if "dispatch" not in request.node.name:
+        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 0)
+    yield
+    torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", default)
+
+
 def run_hip(ops, inp, alibi=None, window=0, softcap=0.0, out=None, causal=True):
     d = to_dev(inp)
     if out is None:
@@ -207,3 +219,17 @@ def test_prefill_non_causal_sees_the_whole_context(ops, block_size):
             logits = (q[qsl[s]:qsl[s + 1], h].double() @ k[:, h // 4].T) * inp["scale"]
             want[qsl[s]:qsl[s + 1], h] = torch.softmax(logits, dim=1) @ v[:, h // 4]
     check_attention(out, want)
+
+
+def test_prefill_dispatch_default_threshold(ops):
+    """As shipped: a launch whose longest chunk has >= 64 query tokens takes the 32x32-MFMA body, shorter ones the
+    first body; both meet the bar, and a launch is bit-identical to the body it is documented to take."""
+    assert int(torch.ops._C_amd.get_tuning("prefill_mfma32_min_query")) == 64
+    for seq, ql in (([300, 90, 17], [300, 10, 1]), ([300, 90, 17], [63, 10, 1]), ([64], [64])):
+        inp = make_prefill_inputs(8, 2, 128, 16, seq, ql, dtype=torch.bfloat16, seed=31)
+        out = run_hip(ops, inp)
+        check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 1 if max(ql) >= 64 else 0)
+        same = run_hip(ops, inp)
+        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 64)
+        assert torch.equal(out.view(torch.int16), same.view(torch.int16))
