@@ -17,3 +17,10 @@ done
 python3 tools/prof_summary.py counters paged_prefill_mfma32_kernel $O/pmc_prefill32.json $O/p[0-9] > /dev/null
 cat $O/pmc_prefill32.json
 rm -rf $O/p[0-9]
+# kernel time under the profiler, both headline shapes (the stats csv is what profiles/ keeps)
+for q in 4096 16384; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$q -- python3 tools/bench_prefill.py --qlen $q --iters 20 > $O/stats_$q.log 2> $O/stats_$q.err
+  python3 tools/prof_summary.py stats $O/stats_$q $O/r02_prefill32_${q}_kernel_stats.csv > /dev/null
+  rm -rf $O/stats_$q
+done
+grep "hip prefill" $O/stats_*.log
