@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity), same guide
 
 
 def parse():
@@ -75,6 +76,8 @@ def parse():
                     help="workgroups per decode GEMM launch (default: 256 for one stream, 128 for several)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-ops-baseline", action="store_true", help="no per-op GPU / CPU timings of the small operators")
+    ap.add_argument("--skip-prefill-roofline", action="store_true",
+                    help="no roofline_prefill object (one 16k-token prompt through the prefill kernel)")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
     ap.add_argument("--replica-backend", default=None, choices=["nccl", "gloo"],
@@ -324,6 +327,13 @@ def ops_baseline_leg(engine, B, iters=200, cpu_budget_s=1.5):
         cpu_calls = calls(_P, _P, cd)
         kind, cores = "port", port.num_threads()
     out = {}
+    # (the engine's step threads have just gone idle and the code objects of these kernels may not be loaded yet: a
+    # pass over every operator and a short pause first, or the first one measured pays for both -- 41 us once)
+    for fn, _ in gpu_calls.values():
+        for _ in range(30):
+            fn()
+    torch.cuda.synchronize(dev)
+    time.sleep(0.3)
     for name, (fn, nbytes) in gpu_calls.items():
         for _ in range(10):
             fn()
@@ -350,6 +360,51 @@ def ops_baseline_leg(engine, B, iters=200, cpu_budget_s=1.5):
                      "cpu_us": round(cpu_us, 1), "cpu_GB/s": round(nbytes / cpu_us / 1e3, 2), "cpu_calls": n}
     return {"tokens": T, "dtype": "bf16", "cpu_kind": kind, "cpu_cores": int(cores),
             "note": "eager launches back to back, launch gap included; T = batch rows of one decode step", "ops": out}
+
+
+def prefill_leg(engine, qlen=16384, iters=12):
+    """Row f-1 of the scope table next to the headline: causal attention of ONE prompt of `qlen` tokens over the
+    paged cache (the call that replaces flash_attn_varlen_func(..., block_table=...), flash_attn.py:538-555) at the
+    model's head shapes, timed with HIP events on the launch stream.  MFMA-bound: FLOPs = 4 D (visible query-key
+    pairs) H against the dense bf16 peak."""
+    from light_vllm_amd import _custom_ops as ops
+    cfg = engine.model_config
+    dev = engine.device
+    H, KVH, D, BS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, engine.cache_config.block_size
+    if cfg.dtype != torch.bfloat16 or BS not in (16, 32):
+        return None
+    nblk = (qlen + BS - 1) // BS
+    g = torch.Generator(device="cpu").manual_seed(5)
+    kc = (torch.randn(nblk + 3, KVH, D // 8, BS, 8, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    vc = (torch.randn(nblk + 3, KVH, D, BS, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    bt = torch.randperm(nblk + 3, generator=g)[:nblk].view(1, nblk).to(torch.int32).to(dev)
+    q = (torch.randn(qlen, H, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    out = torch.empty_like(q)
+    seq_lens = torch.tensor([qlen], dtype=torch.int32, device=dev)
+    qsl = torch.tensor([0, qlen], dtype=torch.int32, device=dev)
+
+    def run():
+        ops.paged_prefill_attention(out, q, kc, vc, KVH, 1 / math.sqrt(D), bt, seq_lens, qsl, qlen, BS, None, 0, 0.0, "auto")
+
+    for _ in range(6):  # (the clock needs a few launches of this kind of load to settle)
+        run()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        run()
+        b.record()
+        torch.cuda.synchronize(dev)
+        ts.append(a.elapsed_time(b) * 1e-3)
+    avg = sum(ts) / len(ts)
+    flops = 4.0 * D * (qlen * (qlen + 1) // 2) * H
+    return {"bound": "mfma",
+            "kernel": f"paged_prefill_mfma32_kernel (one causal prompt of {qlen} tokens over the paged cache, H {H} KVH {KVH} "
+                      f"D {D}, block {BS}; SURVEY 8f-1)",
+            "achieved": round(flops / avg / 1e12, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / avg / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4), "flops_per_launch": flops,
+            "avg_launch_us": round(avg * 1e6, 1), "min_launch_us": round(min(ts) * 1e6, 1)}
 
 
 def largest_divisor_at_most(n, k):
@@ -501,6 +556,9 @@ def main():
         cpu = cpu_baseline_leg(engine, B)
     if rank == 0 and world == 1 and not a.skip_ops_baseline:
         ops_base = ops_baseline_leg(engine, B)
+    pf = None
+    if rank == 0 and world == 1 and not a.skip_prefill_roofline and not a.tiny:
+        pf = prefill_leg(engine)
     ctx_end = sum(s.get_len() for grp in engine.scheduler.running for s in grp.seqs) / max(1, len(engine.scheduler.running))
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the microarch guide prescribes for gfx950),
@@ -548,6 +606,8 @@ def main():
             line["other_settings"] = other
         if ops_base is not None:
             line["ops_baseline"] = ops_base
+        if pf is not None:  # the MFMA-bound kernel of the path's next row
+            line["roofline_prefill"] = pf
         if gm is not None:  # the second HBM stream of the step: one layer's four projections
             g_ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
             gm_traffic = None

@@ -142,3 +142,20 @@ def test_bench_gpus_2_launches_its_ranks_and_sums_them():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"].startswith("dp2")
     check_line(d, 8)  # value = 2 ranks x 8 sequences per step / the slowest rank's time
     assert d["cpu_baseline"] is None  # rank 0 times the CPU baseline at N = 1 only
+
+
+@pytest.mark.gpu
+def test_prefill_roofline_leg_reports_the_kernel_against_the_mfma_peak():
+    """`roofline_prefill` of the bench line (row f-1): FLOPs = 4 D (visible pairs) H over the HIP-event time of the
+    launch, against the dense bf16 MFMA peak; the leg runs the shipped dispatch (32x32-MFMA body at this size)."""
+    import torch
+    bench = load_bench()
+    eng = types.SimpleNamespace(
+        model_config=types.SimpleNamespace(num_attention_heads=8, num_key_value_heads=2, head_dim=128, dtype=torch.bfloat16),
+        cache_config=types.SimpleNamespace(block_size=16), device=torch.device("cuda:0"))
+    r = bench.prefill_leg(eng, qlen=1024, iters=3)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert r["flops_per_launch"] == 4.0 * 128 * (1024 * 1025 // 2) * 8
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) <= 0.02 * r["achieved"] + 0.1
+    assert abs(r["frac"] - r["achieved"] / 2500.0) < 1e-3 and 0 < r["frac"] < 1
+    assert r["min_launch_us"] <= r["avg_launch_us"]

@@ -703,7 +703,7 @@ def test_slots_beyond_the_stated_extent_are_skipped(ops):
         kc_o, vc_o = torch.zeros_like(big_k[:NB]).cpu(), torch.zeros_like(big_v[:NB]).cpu()
         oracle.reshape_and_cache(key.cpu(), value.cpu(), kc_o, vc_o, ok)
         assert torch.equal(big_k[:NB].cpu(), kc_o) and torch.equal(big_v[:NB].cpu(), vc_o)
-    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 64)
+    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 384)  # the default (csrc/common.h)
 
 
 # ------------------------------------------------ reshape_and_cache at prompt sizes (LDS-tiled kernel)
@@ -769,7 +769,7 @@ def test_reshape_and_cache_full_size_round_trip(ops):
         vc = torch.zeros(NB, H, D, BS, dtype=torch.bfloat16, device=DEV)
         ops.reshape_and_cache(key, value, kc, vc, slots, "auto", 1.0, 1.0)
         caches.append((kc, vc))
-    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 64)
+    torch.ops._C_amd.set_tuning("cache_tile_min_tokens", 384)  # the default (csrc/common.h)
     assert torch.equal(caches[0][0], caches[1][0]) and torch.equal(caches[0][1], caches[1][1])
     kc, vc = caches[0]
     blk, off = slots // BS, slots % BS
