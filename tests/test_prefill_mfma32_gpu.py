@@ -190,3 +190,27 @@ def test_mfma32_dense_varlen_twin(ops):
                     logits = logits.masked_fill(torch.ones(n, n).triu(1).bool(), float("-inf"))
                 want[a:b, h] = torch.softmax(logits, 1) @ v[a:b, h // 2].double()
         check_attention(out.cpu(), want)
+
+
+def test_mfma32_block_numbers_beyond_the_stated_extent_are_clamped_not_followed(ops):
+    """The caches are the FRONT of a larger allocation whose tail holds NaN: a block table that points past the
+    caches' last block reads inside the stated extent (kv_cache_bytes of the C-ABI, which the torch binding states):
+    the result is finite and equals the run with the numbers clamped by hand."""
+    inp = make_prefill_inputs(8, 2, 128, 16, [300, 150], [300, 70], dtype=torch.bfloat16, seed=41)
+    NB = inp["key_cache"].shape[0]
+    d = to_dev(inp)
+    big_k = torch.full((3 * NB,) + tuple(inp["key_cache"].shape[1:]), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_v = torch.full((3 * NB,) + tuple(inp["value_cache"].shape[1:]), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big_k[:NB], big_v[:NB] = d["key_cache"], d["value_cache"]
+    bad = d["block_tables"].clone()
+    bad[0, 3] = NB + 5
+    bad[1, 1] = 3 * NB - 1
+    outs = []
+    for bt in (bad, bad.clamp(max=NB - 1)):
+        out = torch.full_like(d["query"], float("nan"))
+        ops.paged_prefill_attention(out, d["query"], big_k[:NB], big_v[:NB], 2, inp["scale"], bt, d["seq_lens"],
+                                    d["query_start_loc"], inp["max_query_len"], 16, None, 0, 0.0, "auto")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
