@@ -214,3 +214,13 @@ def test_mfma32_block_numbers_beyond_the_stated_extent_are_clamped_not_followed(
         outs.append(out)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("block_size", [16, 32])
+def test_mfma32_contexts_longer_than_one_block_number_chunk(ops, block_size):
+    """The body keeps the block numbers of 64 tiles (4 096 keys) in a register and reloads it every 64 tiles: a chunk
+    over a context of more than 64 tiles has to pick up the second chunk's numbers."""
+    inp = make_prefill_inputs(8, 2, 128, block_size, [4500, 8300], [130, 70], dtype=torch.bfloat16, seed=51)
+    out = run_hip(ops, inp)
+    assert torch.isfinite(out).all()
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
