@@ -1,4 +1,4 @@
-// Causal varlen attention of LONG prompt chunks over the paged cache: the 32x32x16-MFMA body
+// Causal varlen attention of prompt chunks of 64+ query tokens over the paged cache: the 32x32x16-MFMA body
 // (prefill_mfma.h is the 16x16x32 body and the owner of every other case: fp8 caches, ALiBi,
 // soft cap, sliding windows, head sizes other than 64 / 128, short chunks).
 //
@@ -11,7 +11,7 @@
 //     copies cost their wave 60-185 issue cycles per KiB among MFMAs and were 22 % of the time;
 //   * S^T = K.Q^T with v_mfma_f32_32x32x16: a lane holds 32 keys of ONE column, so the column maximum is
 //     in-lane v_max's plus one half-swap, and an MFMA holds the vector issue port for 8 of its 32 cycles
-//     (16x16x32: 8 of 16) -- the softmax of a wave fits in the gaps of its own MFMAs;
+//     (16x16x32: 8 of 16), which leaves the other wave of the SIMD room for its vector work;
 //   * the paged layouts stay MFMA operands: a K fragment (32 keys x 16 d) is one 16-byte chunk per lane of
 //     the [D/8][BS][8] block, a V^T fragment (32 d x 16 keys) 8 consecutive tokens of a [D][BS] row.  The
 //     LDS images are the blocks' head slices, K verbatim, V with the lanes of each copy permuted so that a
