@@ -41,6 +41,9 @@
 // exponentials, 4 = no barriers, 8 = no maximum / rescale, 16 = no LDS reads (fragments = registers)
 #define LVLLM_PREFILL32_DIAG 0
 #endif
+#ifndef LVLLM_PREFILL32_LAZYMAX
+#define LVLLM_PREFILL32_LAZYMAX 1  // 0: the column maximum is computed for every tile
+#endif
 #ifndef LVLLM_PREFILL32_GROW
 #define LVLLM_PREFILL32_GROW 6  // log2 of the growth of a column maximum that forces a rescale
 #endif
@@ -321,37 +324,52 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
         }
     };
     exps(m_run * kf);
+    auto sum_all = [&]() __attribute__((always_inline)) -> f32x2_t {
+      f32x2_t acc2 = {0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) acc2 += f32x2_t{e[kh][r], e[kh][r + 1]};
+      return acc2;
+    };
+    f32x2_t psum2 = sum_all();
     if constexpr (!(LVLLM_PREFILL32_DIAG & 8)) {
-      float m4[4];
+      // The new maximum is not computed on the way: a probability above 2^kGrow shows in the lane's sum (all
+      // terms are >= 0), and only then (wave-uniform, rare after the first tiles; NaN-proof: the test is "not <=")
+      // the exact maximum is taken and the usual criterion decides per column -- both lanes of a column see the
+      // same maximum, so they decide alike.  Below the limit every probability is <= 32 * 2^kGrow: fine for fp32 sums
+      // and for the bf16 / f16 rounding of P.
+      constexpr float kSumLimit = 32.f * (float)(1 << LVLLM_PREFILL32_GROW);
+      const bool suspicious = LVLLM_PREFILL32_LAZYMAX ? !(psum2.x + psum2.y <= kSumLimit) : true;
+      if (__builtin_amdgcn_ballot_w64(suspicious) != 0) {
+        float m4[4];
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        m4[c4] = fmaxf(y[0][4 * c4], y[1][4 * c4]);
+        for (int c4 = 0; c4 < 4; ++c4) {
+          m4[c4] = fmaxf(y[0][4 * c4], y[1][4 * c4]);
 #pragma unroll
-        for (int r = 1; r < 4; ++r) m4[c4] = fmaxf(m4[c4], fmaxf(y[0][4 * c4 + r], y[1][4 * c4 + r]));
-      }
-      const float m_loc = half_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
-      // ---- some column outgrew the maximum in use by 2^kGrow (wave-uniform branch): rescale, and redo the
-      // exponentials.  The new maximum is taken per column, so a column's arithmetic never depends on its
-      // neighbours. ----
-      const bool grew = (m_loc - m_run) * kf > kGrow;
-      if (__builtin_amdgcn_ballot_w64(grew) != 0) {
-        const float m_new = grew ? fmaxf(m_run, m_loc) : m_run;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kf);
-        l_run *= alpha;
+          for (int r = 1; r < 4; ++r) m4[c4] = fmaxf(m4[c4], fmaxf(y[0][4 * c4 + r], y[1][4 * c4 + r]));
+        }
+        const float m_loc = half_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+        // ---- some column outgrew the maximum in use by 2^kGrow: rescale, and redo the exponentials.  The new
+        // maximum is taken per column, so a column's arithmetic never depends on its neighbours. ----
+        const bool grew = (m_loc - m_run) * kf > kGrow;
+        if (__builtin_amdgcn_ballot_w64(grew) != 0) {
+          const float m_new = grew ? fmaxf(m_run, m_loc) : m_run;
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kf);
+          l_run *= alpha;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+          for (int db = 0; db < NDB; ++db)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
-        m_run = m_new;
-        exps(m_run * kf);
+            for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
+          m_run = m_new;
+          exps(m_run * kf);
+          psum2 = sum_all();
+        }
       }
     }
-    // ---- row sums, packing, and the move to the B-operand layout ----
-    f32x2_t psum2 = {0.f, 0.f};
+    // ---- packing, and the move to the B-operand layout ----
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) psum2 += f32x2_t{e[kh][r], e[kh][r + 1]};
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int r0 = 8 * g2;

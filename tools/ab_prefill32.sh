@@ -3,7 +3,7 @@
 # container: tools/ab_prefill32.sh build) and times them on the GPU box (tools/ab_prefill32.sh run).
 # Diagnosis builds (LVLLM_PREFILL32_DIAG) compute WRONG results; they only price a part of the loop.
 cd "$(dirname "$0")/.."
-VARIANTS=${VARIANTS:-"base: ppprio:-DLVLLM_PREFILL32_PINGPONG=1;-DLVLLM_PREFILL32_PRIO=1 kwin12:-DLVLLM_PREFILL32_KWIN=12 kwin16:-DLVLLM_PREFILL32_KWIN=16 grow20:-DLVLLM_PREFILL32_GROW=20"}
+VARIANTS=${VARIANTS:-"lazy: exact:-DLVLLM_PREFILL32_LAZYMAX=0"}
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; flags=${v#*:}
