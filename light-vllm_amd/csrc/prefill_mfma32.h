@@ -324,13 +324,17 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
         }
     };
     exps(m_run * kf);
-    auto sum_all = [&]() __attribute__((always_inline)) -> f32x2_t {
-      f32x2_t acc2 = {0.f, 0.f};
+    auto sum_all = [&]() __attribute__((always_inline)) -> f32x2_t {  // (four chains: a packed add waits for the one before)
+      f32x2_t part[4];
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) acc2 += f32x2_t{e[kh][r], e[kh][r + 1]};
-      return acc2;
+        for (int r = 0; r < 16; r += 2) {
+          const int c4 = (r >> 1) & 3;
+          const f32x2_t v = {e[kh][r], e[kh][r + 1]};
+          part[c4] = (kh == 0 && r < 8) ? v : part[c4] + v;
+        }
+      return (part[0] + part[1]) + (part[2] + part[3]);
     };
     f32x2_t psum2 = sum_all();
     if constexpr (!(LVLLM_PREFILL32_DIAG & 8)) {
