@@ -216,6 +216,86 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   const bool in_a = BS != 8 || c < 8;    // K: this lane's token lies in the tile's first block
   const bool vin_a = BS != 8 || g < 2;   // V: this lane's 4 tokens lie in the tile's first block
 
+  // Physical block number of this wave's j-th tile.  The index is wave-uniform, so
+  // this is a scalar load; callers request it one rotation before it is needed.
+  // The index is clamped by the table width (a kernel argument), not by the sequence length,
+  // so the first block-table loads do not wait for the seq_lens load.
+  const int last_block = p.max_num_blocks_per_seq - 1;
+  // (BS == 8: two numbers per tile, packed low | high)
+  auto block_number = [&](const int j) __attribute__((always_inline)) -> int64_t {
+    const int blk = ((tile0 + wave + j * NWAVES) << 4) / BS;
+    const uint32_t a = min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
+    if constexpr (BS == 8) {
+      const uint32_t b = min((uint32_t)block_table[min(blk + 1, last_block)], (uint32_t)p.max_block);
+      return (int64_t)(((uint64_t)b << 32) | a);
+    }
+    return (int64_t)a;
+  };
+
+  auto load_tile = [&](u32x4_t (&k)[NKL], vraw_t (&v)[NDT], const int j, const int64_t bnp)
+                       __attribute__((always_inline)) {
+    const int lt = wave + j * NWAVES;
+    const bool valid = j < nmy;
+    const int64_t bn = (int64_t)(uint32_t)bnp;
+    const int tok_base = (tile0 + lt) << 4;
+    const int off = (BS == 32) ? (tok_base & 16) : 0;  // second half of a 32-token block
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+    // chunks past the head size and rows with d >= D fall outside kHeadBytes -> zeros
+    // (a chunk is 16 bytes of one token in both cache types: 8 T or 16 fp8)
+    if constexpr (BS == 8) {
+      const int64_t bn2 = (int64_t)((uint64_t)bnp >> 32);
+      __amdgpu_buffer_rsrc_t kr2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(kbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+      __amdgpu_buffer_rsrc_t vr2 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(vbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
+      const int ka = in_a ? koff : kOut, kb = in_a ? kOut : koff;
+      const int va = vin_a ? voff : kOut, vb = vin_a ? kOut : voff;
+#pragma unroll
+      for (int jj = 0; jj < NKL; ++jj) {
+        const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(kr, ka + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
+        const u32x4_t y = __builtin_amdgcn_raw_buffer_load_b128(kr2, kb + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
+        k[jj] = x | y;
+      }
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(vr, va + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
+        const u32x2_t y = __builtin_amdgcn_raw_buffer_load_b64(vr2, vb + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
+        v[t] = x | y;
+      }
+      return;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NKL; ++jj)
+      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      if constexpr (KV8)
+        v[t] = __builtin_amdgcn_raw_buffer_load_b32(vr, voff + t * (16 * BS), off, LVLLM_ATTN_AUX);
+      else
+        v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
+    }
+  };
+
+  // ---- ROPE: the first K/V tiles are requested before anything else: the block-table read and the HBM round trip
+  // of tile 0 (and 1) then overlap the position -> cos / sin -> rotation -> cache-write prologue and its barrier
+  // instead of following them (the tile that ends with the new token takes that token from the LDS stash, never
+  // from the bytes this launch is writing) ----
+  u32x4_t k0[NKL], k1[NKL], k2[NKL];
+  vraw_t v0[NDT], v1[NDT], v2[NDT];
+  int64_t bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
+  auto first_loads = [&]() __attribute__((always_inline)) {
+    load_tile(k0, v0, 0, bn0);
+    bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
+    if constexpr (NBUF == 3) {
+      load_tile(k1, v1, 1, bn1);
+      bn1 = block_number(4);
+    }
+  };
+  if constexpr (ROPE) first_loads();  // (without the prologue the Q loads go first, as before: 25.0 against 25.4 us)
+
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
   u32x4_t qf[NSQ];
   {
@@ -346,75 +426,12 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   const bool k_scaled = KV8 && p.k_scale != 1.f, v_scaled = KV8 && p.v_scale != 1.f;
   const float alibi = (p.alibi_slopes != nullptr && c < nh) ? p.alibi_slopes[head0 + c] : 0.f;
 
-  // Physical block number of this wave's j-th tile.  The index is wave-uniform, so
-  // this is a scalar load; callers request it one rotation before it is needed.
-  // The index is clamped by the table width (a kernel argument), not by the sequence length,
-  // so the first block-table loads do not wait for the seq_lens load.
-  const int last_block = p.max_num_blocks_per_seq - 1;
-  // (BS == 8: two numbers per tile, packed low | high)
-  auto block_number = [&](const int j) __attribute__((always_inline)) -> int64_t {
-    const int blk = ((tile0 + wave + j * NWAVES) << 4) / BS;
-    const uint32_t a = min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
-    if constexpr (BS == 8) {
-      const uint32_t b = min((uint32_t)block_table[min(blk + 1, last_block)], (uint32_t)p.max_block);
-      return (int64_t)(((uint64_t)b << 32) | a);
-    }
-    return (int64_t)a;
-  };
-
   // running softmax state of this wave: column c of lanes (g, c) is head head0 + c
   float m_run = -FLT_MAX;
   float l_run = 0.f;  // per-lane partial sum over its own tokens
   f32x4_t acc[NDT];
 #pragma unroll
   for (int t = 0; t < NDT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto load_tile = [&](u32x4_t (&k)[NKL], vraw_t (&v)[NDT], const int j, const int64_t bnp)
-                       __attribute__((always_inline)) {
-    const int lt = wave + j * NWAVES;
-    const bool valid = j < nmy;
-    const int64_t bn = (int64_t)(uint32_t)bnp;
-    const int tok_base = (tile0 + lt) << 4;
-    const int off = (BS == 32) ? (tok_base & 16) : 0;  // second half of a 32-token block
-    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(kbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(vbytes + bn * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-    // chunks past the head size and rows with d >= D fall outside kHeadBytes -> zeros
-    // (a chunk is 16 bytes of one token in both cache types: 8 T or 16 fp8)
-    if constexpr (BS == 8) {
-      const int64_t bn2 = (int64_t)((uint64_t)bnp >> 32);
-      __amdgpu_buffer_rsrc_t kr2 = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(kbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-      __amdgpu_buffer_rsrc_t vr2 = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(vbytes + bn2 * bsb), 0, valid ? kHeadBytes : 0, kSrdFlags);
-      const int ka = in_a ? koff : kOut, kb = in_a ? kOut : koff;
-      const int va = vin_a ? voff : kOut, vb = vin_a ? kOut : voff;
-#pragma unroll
-      for (int jj = 0; jj < NKL; ++jj) {
-        const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(kr, ka + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
-        const u32x4_t y = __builtin_amdgcn_raw_buffer_load_b128(kr2, kb + jj * (4 * BS * 16), 0, LVLLM_ATTN_AUX);
-        k[jj] = x | y;
-      }
-#pragma unroll
-      for (int t = 0; t < NDT; ++t) {
-        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(vr, va + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
-        const u32x2_t y = __builtin_amdgcn_raw_buffer_load_b64(vr2, vb + t * (16 * BS * 2), 0, LVLLM_ATTN_AUX);
-        v[t] = x | y;
-      }
-      return;
-    }
-#pragma unroll
-    for (int jj = 0; jj < NKL; ++jj)
-      k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
-#pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-      if constexpr (KV8)
-        v[t] = __builtin_amdgcn_raw_buffer_load_b32(vr, voff + t * (16 * BS), off, LVLLM_ATTN_AUX);
-      else
-        v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
-    }
-  };
 
   // One tile: S = K.Q^T (NS MFMAs), online softmax, O^T += V^T.P^T (NDT MFMAs).
   auto compute_tile = [&](u32x4_t (&kraw)[NKL], vraw_t (&v)[NDT], const int j)
@@ -519,14 +536,8 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 
   // ---- main loop: NBUF register sets rotate; NBUF-1 tiles stay in flight ----
   {
-    u32x4_t k0[NKL], k1[NKL], k2[NKL];
-    vraw_t v0[NDT], v1[NDT], v2[NDT];
-    int64_t bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
-    load_tile(k0, v0, 0, bn0);
-    bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
+    if constexpr (!ROPE) first_loads();
     if constexpr (NBUF == 3) {
-      load_tile(k1, v1, 1, bn1);
-      bn1 = block_number(4);
       for (int j = 0; j < nmy; j += 3) {
         load_tile(k2, v2, j + 2, bn2);
         bn2 = block_number(j + 5);
