@@ -65,3 +65,35 @@ def test_cpu_tensors_are_rejected_not_silently_computed(ops):
     x = torch.randn(2, 64)
     with pytest.raises((RuntimeError, NotImplementedError)):
         ops.rms_norm(torch.empty_like(x), x, torch.ones(64), 1e-6)
+
+
+def test_tuning_knobs_round_trip_through_the_abi():
+    """lvllm_set_tuning / lvllm_get_tuning: every documented key reads back what was set, the shipped defaults are
+    the documented ones, unknown keys and out-of-range values are errors (no GPU needed: host state only)."""
+    from light_vllm_amd import _native
+    lib = _native.load_hip_library()
+    lib.lvllm_set_tuning.restype = ctypes.c_int
+    lib.lvllm_get_tuning.restype = ctypes.c_int
+
+    def get(key):
+        v = ctypes.c_int(-12345)
+        assert lib.lvllm_get_tuning(key, ctypes.byref(v)) == 0, lib.lvllm_last_error()
+        return v.value
+
+    defaults = {b"gemm_workgroups": 256, b"attn_waves": 8, b"attn_splits": 0, b"swap_kernel_min_runs": 3,
+                b"cache_tile_min_tokens": 384, b"prefill_lds": 1, b"prefill_mfma32_min_query": 64,
+                b"gemm_partials_ksplit": 0}
+    for key, want in defaults.items():
+        if os.environ.get("LVLLM_" + key.decode().upper()) is None:
+            assert get(key) == want, key
+    for key, val in ((b"prefill_mfma32_min_query", 512), (b"cache_tile_min_tokens", 64), (b"attn_splits", -1),
+                     (b"gemm_workgroups", 128)):
+        old = get(key)
+        assert lib.lvllm_set_tuning(key, ctypes.c_int(val)) == 0
+        assert get(key) == val
+        assert lib.lvllm_set_tuning(key, ctypes.c_int(old)) == 0
+    assert lib.lvllm_set_tuning(b"no_such_knob", ctypes.c_int(1)) != 0 and b"unknown tuning key" in lib.lvllm_last_error()
+    assert lib.lvllm_get_tuning(b"no_such_knob", ctypes.byref(ctypes.c_int())) != 0
+    assert lib.lvllm_set_tuning(b"attn_waves", ctypes.c_int(5)) != 0
+    assert lib.lvllm_set_tuning(b"prefill_mfma32_min_query", ctypes.c_int(-1)) != 0
+    assert lib.lvllm_get_tuning(b"attn_waves", None) != 0
