@@ -16,8 +16,9 @@
 //     the [D/8][BS][8] block, a V^T fragment (32 d x 16 keys) 8 consecutive tokens of a [D][BS] row.  The
 //     LDS images are the blocks' head slices, K verbatim, V with the lanes of each copy permuted so that a
 //     fragment read (ds_read_b128) is 32 consecutive chunks: no bank conflicts, no padding;
-//   * P moves from the S^T accumulator layout (keys 4hi..4hi+3 of every 8) to the B-operand layout (keys
-//     8hi..8hi+7 of every 16) by v_permlane32_swap of the packed words, one swap per 4 probabilities;
+//   * P never moves between lanes: the K fragment of MFMA row i holds a PERMUTED key (groups 4..7 and 8..11 of
+//     every 16 trade places -- only a lane's LDS read address changes), so that the S^T accumulator registers of
+//     a lane are the consecutive keys 8hi..8hi+7 of every 16, the B-operand layout of P.V;
 //   * accumulators are rescaled only when some column's maximum grew by more than 2^kGrow over the value
 //     the exponentials use (probabilities stay below 2^kGrow; fp32 sums and the bf16/f16 rounding of P are
 //     relative, so nothing is lost).
@@ -217,10 +218,15 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 
   // ---- fragment addresses inside a stage ----
   // K fragment (half kh, k-step ks): key 32 kh + col, chunk d8 = 2 ks + hi
+  // MFMA row i of a half does NOT hold key i: within every 16 keys the groups 4..7 and 8..11 trade places, so that
+  // the accumulator registers of a lane -- rows {0..3, 8..11} + 4 hi of every 16 -- are the CONSECUTIVE keys
+  // 8 hi .. 8 hi + 7: exactly the B-operand layout P.V wants.  The probabilities are packed where they are; no
+  // cross-lane move.  (Register r of half kh of lane (col, hi) is key 32 kh + 16 (r >> 3) + 8 hi + (r & 7).)
+  const int krow = (col & ~0xc) | ((col & 4) << 1) | ((col & 8) >> 1);  // key (inside the half) held by MFMA row col
   int koff[2];
 #pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
-    const int key = 32 * kh + col;
+    const int key = 32 * kh + krow;
     koff[kh] = (key / BS) * kSlice + hi * (BS * 16) + (key % BS) * 16;
   }
   constexpr int kKStep = 2 * BS * 16;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     const int base = j * KT;
     // ---- column maximum (the logits leave the accumulator tuples as scalars and never go back) ----
     float y[2][16];
-    const int rel = vlast - base - 4 * hi;  // register r of half kh is key base + 4 hi + (32 kh + (r & 3) + 8 (r >> 2))
+    const int rel = vlast - base - 8 * hi;  // register r of half kh is key base + 8 hi + (32 kh + 16 (r >> 3) + (r & 7))
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[kh][r] = 32 * kh + (r & 3) + 8 * (r >> 2) <= rel ? y[kh][r] : kMasked;
+        for (int r = 0; r < 16; ++r) y[kh][r] = 32 * kh + 16 * (r >> 3) + (r & 7) <= rel ? y[kh][r] : kMasked;
     }
     // ---- probabilities against the maximum in use, issued before the new maximum is known: the maximum is a
     // dependent chain (4 short ones here) ending in a branch, and the exponentials need not wait for it ----
@@ -377,11 +383,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int r0 = 8 * g2;
-        uint32_t w0 = pack2<T>(e[kh][r0 + 0], e[kh][r0 + 1]), w1 = pack2<T>(e[kh][r0 + 2], e[kh][r0 + 3]);
-        uint32_t w2 = pack2<T>(e[kh][r0 + 4], e[kh][r0 + 5]), w3 = pack2<T>(e[kh][r0 + 6], e[kh][r0 + 7]);
-        half_swap(w0, w2);
-        half_swap(w1, w3);
-        pb[2 * kh + g2] = u32x4_t{w0, w1, w2, w3};
+        pb[2 * kh + g2] = u32x4_t{pack2<T>(e[kh][r0 + 0], e[kh][r0 + 1]), pack2<T>(e[kh][r0 + 2], e[kh][r0 + 3]),
+                                  pack2<T>(e[kh][r0 + 4], e[kh][r0 + 5]), pack2<T>(e[kh][r0 + 6], e[kh][r0 + 7])};
       }
     }
     l_run += psum2.x + psum2.y;
