@@ -50,7 +50,8 @@
 #endif
 
 #ifndef LVLLM_PREFILL32_STAMPS
-#define LVLLM_PREFILL32_STAMPS 0  // diagnosis build: s_memtime at the phase boundaries of one workgroup (tools/stamps_prefill32.py)
+#define LVLLM_PREFILL32_STAMPS 0  // diagnosis builds: 1 = s_memtime at the phase boundaries of one workgroup (tools/stamps_prefill32.py);
+                                  // 2 = also start / first barrier / loop end / exit of EVERY workgroup (tools/wg_timeline_prefill32.py)
 #endif
 
 namespace lvllm {
@@ -59,6 +60,10 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #if LVLLM_PREFILL32_STAMPS
 constexpr int kStampTiles = 24, kStampPerTile = 8;
 __device__ unsigned long long g_prefill32_stamps[8 * kStampTiles * kStampPerTile];
+// per workgroup (LVLLM_PREFILL32_STAMPS == 2, tools/wg_timeline_prefill32.py): 100 MHz wall clock at kernel entry,
+// first barrier passed, loop end, exit (wave 0); tiles walked; hardware id (XCC, SE, CU)
+constexpr int kWgRecords = 4096, kWgFields = 6;
+__device__ unsigned long long g_prefill32_wg[kWgRecords * kWgFields];
 #endif
 
 template <typename T>
@@ -109,6 +114,10 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, hi = lane >> 5;
+#if LVLLM_PREFILL32_STAMPS == 2
+  const unsigned long long wg_t0 = wall_clock64();
+  const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
 
   const int GP = 1 << p.gp_shift;    // heads per query token among the 32 columns (group size rounded up)
   const int TQW = 32 >> p.gp_shift;  // query tokens per wave
@@ -435,6 +444,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
       stamp(j, 6);
       if constexpr (!(LVLLM_PREFILL32_DIAG & 4)) __builtin_amdgcn_s_barrier();
       stamp(j, 7);
+#if LVLLM_PREFILL32_STAMPS == 2
+      if (j == 0 && threadIdx.x == 0 && wg_id < kWgRecords) g_prefill32_wg[wg_id * kWgFields + 1] = wall_clock64();
+#endif
       if constexpr (!(LVLLM_PREFILL32_DIAG & 1)) {
         if (((j + 1) & 63) == 0) load_block_chunk((j + 1) >> 6, ld_blk);
         fetch(j + 1, block_of_tile(j + 1));
@@ -488,6 +500,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     else run(std::false_type{});
     __builtin_amdgcn_s_waitcnt(0);  // no copy may still be landing when the workgroup's LDS is released
   }
+#if LVLLM_PREFILL32_STAMPS == 2
+  const unsigned long long wg_t2 = wall_clock64();
+#endif
 
   // ---- normalise and store: register r of block db is d = 32 db + 8 (r >> 2) + 4 hi + (r & 3) ----
   {
@@ -508,6 +523,19 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
         }
     }
   }
+#if LVLLM_PREFILL32_STAMPS == 2
+  __builtin_amdgcn_s_waitcnt(0);
+  if (threadIdx.x == 0 && wg_id < kWgRecords) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_prefill32_wg[wg_id * kWgFields + 0] = wg_t0;
+    g_prefill32_wg[wg_id * kWgFields + 2] = wg_t2;
+    g_prefill32_wg[wg_id * kWgFields + 3] = wall_clock64();
+    g_prefill32_wg[wg_id * kWgFields + 4] = (unsigned long long)ntiles;
+    g_prefill32_wg[wg_id * kWgFields + 5] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 // 0 = launched; -1 = not this kernel's case (the caller falls back to prefill_mfma.h)
@@ -525,6 +553,23 @@ static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+#if LVLLM_PREFILL32_STAMPS == 2
+  if (getenv("LVLLM_PREFILL32_WG_FILE")) {
+    static unsigned long long hostw[kWgRecords * kWgFields];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(hostw, HIP_SYMBOL(g_prefill32_wg), sizeof(hostw));
+    FILE* f = fopen(getenv("LVLLM_PREFILL32_WG_FILE"), "w");
+    if (f) {
+      const int n = (int)(grid.x * grid.y * grid.z);
+      for (int w = 0; w < n && w < kWgRecords; ++w) {
+        fprintf(f, "%d", w);
+        for (int k = 0; k < kWgFields; ++k) fprintf(f, " %llu", hostw[w * kWgFields + k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
 #if LVLLM_PREFILL32_STAMPS
   if (getenv("LVLLM_PREFILL32_STAMP_FILE")) {
     static unsigned long long host[8 * kStampTiles * kStampPerTile];
