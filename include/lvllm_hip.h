@@ -60,8 +60,9 @@ const char* lvllm_version(void);
  * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4), "attn_splits" (paged_attention_v2:
  * 0 = shares chosen per call, n >= 1 = n shares, -1 = the reference's 512-token partitions),
  * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used),
- * "prefill_mfma32_min_query" (paged_prefill_attention: plain chunks of at least this many query tokens, head size
- * 64 or 128, 16-bit cache, take the 32x32-MFMA body; 0 = never).  lvllm_get_tuning reads a knob back. */
+ * "prefill_mfma32_min_query" (paged_prefill_attention: plain launches -- head size 64 or 128, 16-bit cache -- whose
+ * longest chunk has at least this many query tokens take the 32x32-MFMA body, and so do launches with chunks of 16+
+ * tokens whose grid fits the CUs at once; 0 = never).  lvllm_get_tuning reads a knob back. */
 int lvllm_set_tuning(const char* key, int value);
 int lvllm_get_tuning(const char* key, int* value);
 

@@ -38,7 +38,8 @@ struct Tuning {
                                     // slots cost the tiled kernel 17 us at any small size)
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
   int prefill_mfma32_min_query = 64;  // launches whose longest chunk has at least this many query tokens take the
-                                      // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache); 0 = never
+                                      // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache) --
+                                      // and launches with chunks of 16+ tokens whose grid fits the CUs at once; 0 = never
 };
 Tuning& tuning();
 

@@ -561,8 +561,25 @@ static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_quer
   constexpr int NB = D > 128 ? 1 : LVLLM_PREFILL_NB;  // accumulators: NB * D/4 VGPRs per lane
   if constexpr (D == 64 || D == 128) {
     const int min_query = tuning().prefill_mfma32_min_query;
-    if (min_query > 0 && max_query_len >= min_query && !p0.kv_fp8 && p0.alibi_slopes == nullptr &&
-        p0.softcap <= 0.f && p0.sliding_window <= 0)
+    // Shorter chunks (16 tokens up) take it too when its whole grid fits the CUs at once: the launch then lasts as
+    // long as its slowest workgroup, and the 64-key tile walk is the faster one whatever the number of live
+    // columns (1 x (32 over 4 096): 74 against 139 us; profiles/r02_prefill_threshold_ab.txt).  Larger launches
+    // with short chunks are typically mixed steps full of one-token sequences: the 128-column body's case.
+    bool take32 = min_query > 0 && max_query_len >= min_query;
+    if (!take32 && min_query > 0 && max_query_len >= 16) {
+      static const int num_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+      }();
+      const int G_ = p0.num_heads / p0.num_kv_heads;
+      const int cols_per_token = G_ == 1 ? 1 : G_ == 2 ? 2 : G_ <= 4 ? 4 : G_ <= 8 ? 8 : G_ <= 16 ? 16 : 32;
+      const int tqwg = 256 / cols_per_token;
+      const int64_t wgs = (int64_t)p0.num_kv_heads * ((G_ + 31) / 32) * num_seqs * ((max_query_len + tqwg - 1) / tqwg);
+      take32 = wgs <= num_cus;
+    }
+    if (take32 && !p0.kv_fp8 && p0.alibi_slopes == nullptr && p0.softcap <= 0.f && p0.sliding_window <= 0)
       return launch_prefill_mfma32<T, D, BS>(p0, num_seqs, max_query_len, stream);
   }
   PrefillParams p = p0;

@@ -222,14 +222,19 @@ def test_prefill_non_causal_sees_the_whole_context(ops, block_size):
 
 
 def test_prefill_dispatch_default_threshold(ops):
-    """As shipped: a launch whose longest chunk has >= 64 query tokens takes the 32x32-MFMA body, shorter ones the
-    first body; both meet the bar, and a launch is bit-identical to the body it is documented to take."""
+    """As shipped: a launch whose longest chunk has >= 64 query tokens takes the 32x32-MFMA body, and so does one with
+    chunks of 16+ tokens whose grid fits the CUs at once; the others the first body.  Both meet the bar, and a launch
+    is bit-identical to the body it is documented to take."""
     assert int(torch.ops._C_amd.get_tuning("prefill_mfma32_min_query")) == 64
-    for seq, ql in (([300, 90, 17], [300, 10, 1]), ([300, 90, 17], [63, 10, 1]), ([64], [64])):
+    # (chunk lengths, takes the 32x32 body): >= 64 tokens always; 16..63 when the grid fits the CUs (2 kv heads x 3
+    # sequences here: it does); below 16 never; 16..63 in a launch of many sequences (2 x 200 workgroups) not either
+    cases = [([300, 90, 17], [300, 10, 1], True), ([300, 90, 17], [63, 10, 1], True), ([64], [64], True),
+             ([300, 90, 17], [15, 10, 1], False), ([40] * 200, [20] * 200, False)]
+    for seq, ql, new_body in cases:
         inp = make_prefill_inputs(8, 2, 128, 16, seq, ql, dtype=torch.bfloat16, seed=31)
         out = run_hip(ops, inp)
         check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
-        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 1 if max(ql) >= 64 else 0)
+        torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 1 if new_body else 0)
         same = run_hip(ops, inp)
         torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 64)
         assert torch.equal(out.view(torch.int16), same.view(torch.int16))
