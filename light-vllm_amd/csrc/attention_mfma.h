@@ -135,15 +135,29 @@ constexpr int kSrdFlags = 0x00020000;
 #ifndef LVLLM_ATTN_MIN_WAVES_PER_SIMD
 #define LVLLM_ATTN_MIN_WAVES_PER_SIMD 2
 #endif
-// 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale)
+// 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale).
+// scale == 1 (`scaled` false, the common case): gfx950 converts two fp8 straight to two bf16 / f16 in ONE instruction
+// (v_cvt_scalef32_pk_{bf16,f16}_fp8 with a scale of 1.0) -- exact, every e4m3 value is a bf16 and an f16 value -- half
+// the vector instructions of the fp8 -> f32 -> T route, which the fp8 attention kernels are bound by.
+template <typename T>
+__device__ __forceinline__ uint32_t fp8x2_to_T(uint32_t w, bool upper);
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_T<BF16>(uint32_t w, bool upper) {
+  return upper ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+               : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+}
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_T<F16>(uint32_t w, bool upper) {
+  return upper ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true))
+               : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false));
+}
 template <typename T>
 __device__ __forceinline__ u32x2_t dequant4(uint32_t w, float scale, bool scaled) {
+  if (!scaled) return u32x2_t{fp8x2_to_T<T>(w, false), fp8x2_to_T<T>(w, true)};
   f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
   f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
-  if (scaled) {
-    lo *= scale;
-    hi *= scale;
-  }
+  lo *= scale;
+  hi *= scale;
   return u32x2_t{pack2<T>(lo.x, lo.y), pack2<T>(hi.x, hi.y)};
 }
 
