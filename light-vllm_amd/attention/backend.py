@@ -390,14 +390,17 @@ class PagedAttnImpl:
 
     def unified_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                           block_tables: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
-                          max_query_len: int) -> torch.Tensor:
+                          max_query_len: int, output: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Every sequence of a mixed step as a chunk of query_len >= 1 tokens over its paged context
         (a decode token is a chunk of one): one launch of the prefill kernel with device-side
         metadata only, so a mixed step can be captured into a HIP graph.  K/V of all tokens must
-        already be in the cache."""
+        already be in the cache.  `output`: a [num_tokens, hidden] buffer whose padding rows (tokens of no
+        sequence, never written here) the caller keeps finite -- the model zeroes ONE buffer per step and hands it to
+        every layer instead of paying a fill launch per layer."""
         num_tokens, hidden_size = query.shape
         q = query.view(-1, self.num_heads, self.head_size)
-        out = torch.zeros_like(q)  # rows of padding tokens belong to no sequence: keep them finite
+        # rows of padding tokens belong to no sequence: keep them finite
+        out = torch.zeros_like(q) if output is None else output.view(-1, self.num_heads, self.head_size)
         alibi = self.alibi_slopes
         if alibi is not None and alibi.device != q.device:
             alibi = self.alibi_slopes = alibi.to(q.device)

@@ -199,6 +199,7 @@ class DecoderModel:
             attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
         slot_mapping = unified[4] if unified is not None else getattr(attn_metadata, "slot_mapping", None)
         residual = None
+        unified_out = None
         for i, lw in enumerate(self.layers):
             if residual is None:  # qwen2.py:203-208
                 residual = hidden
@@ -225,8 +226,10 @@ class DecoderModel:
                 pass
             elif unified is not None:
                 assert fused, "a captured mixed step needs the fused rope + cache write"
+                if unified_out is None:  # one zeroed buffer per step (its padding rows stay zero), not one per layer
+                    unified_out = torch.zeros(T, self.q_size, dtype=q.dtype, device=q.device)
                 attn_out = self.attn.unified_attention(q, key_cache, value_cache, unified[0], unified[1],
-                                                       unified[2], unified[3])
+                                                       unified[2], unified[3], output=unified_out)
             elif fused:
                 attn_out = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata)
             else:
