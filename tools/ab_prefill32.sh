@@ -3,7 +3,7 @@
 # container: tools/ab_prefill32.sh build) and times them on the GPU box (tools/ab_prefill32.sh run).
 # Diagnosis builds (LVLLM_PREFILL32_DIAG) compute WRONG results; they only price a part of the loop.
 cd "$(dirname "$0")/.."
-VARIANTS=${VARIANTS:-"base: exact:-DLVLLM_PREFILL32_LAZYMAX=0 pp:-DLVLLM_PREFILL32_PINGPONG=1 nolds:-DLVLLM_PREFILL32_DIAG=16 nocopy:-DLVLLM_PREFILL32_DIAG=1 mfmaonly:-DLVLLM_PREFILL32_DIAG=31"}
+VARIANTS=${VARIANTS:-"base: pp:-DLVLLM_PREFILL32_PINGPONG=1 ppprio:-DLVLLM_PREFILL32_PINGPONG=1;-DLVLLM_PREFILL32_PRIO=1 nolds:-DLVLLM_PREFILL32_DIAG=16 nocopy:-DLVLLM_PREFILL32_DIAG=1 noexp:-DLVLLM_PREFILL32_DIAG=2 mfmaonly:-DLVLLM_PREFILL32_DIAG=31"}
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; flags=${v#*:}
