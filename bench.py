@@ -505,14 +505,21 @@ def main():
         engine.scheduler_config.num_scheduler_steps = burst  # lookahead slots stay at k_max - 1
         engine.scheduler_config.max_num_on_the_fly = in_flight
         n = n_model_steps // burst
-        produced = 0
+        # tokens are COUNTED, not inferred: what the engine appended to its sequences, cross-checked against the
+        # sequences' own output lengths; and every engine step of the region must have been a burst of `burst`
+        # model steps (a step that fell back to the general path would otherwise be credited `burst` tokens)
+        tok0, steps0 = engine.stat_tokens_appended, engine.stat_model_steps
+        len0 = sum(s.get_output_len() for grp in engine.groups.values() for s in grp.seqs)
         for i in range(n):
             if a.scheduling != "sync":
-                outs = engine.async_step(schedule_more=i < n - (in_flight - 1))
+                engine.async_step(schedule_more=i < n - (in_flight - 1))
             else:
-                outs = engine.step()
-            produced += len(outs) * burst
+                engine.step()
         assert engine.num_on_the_fly == 0
+        produced = engine.stat_tokens_appended - tok0
+        len1 = sum(s.get_output_len() for grp in engine.groups.values() for s in grp.seqs)
+        assert len1 - len0 == produced, (len1 - len0, produced)
+        assert engine.stat_model_steps - steps0 == n_model_steps, (engine.stat_model_steps - steps0, n_model_steps, burst)
         return produced
 
     if a.warmup > 0:

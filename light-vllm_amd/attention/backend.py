@@ -377,6 +377,12 @@ class PagedAttnImpl:
         # prologue and its barrier cost more than the launch they save
         if self.alibi_slopes is not None or self.decode_version == "v1" or self.kv_cache_dtype != "auto":
             return None
+        # Sliding windows: the fused kernel takes the step's new token for logical position seq_len - 1 of the
+        # table it is handed.  The v1 manager's circular table (block_manager/v1.py, block_manager_v1.py:279-295)
+        # with seq_len clipped to the window puts it at offset (L - 1) % block_size of some OTHER entry once the
+        # sequence has outgrown the window: separate launches there (they read everything from the cache).
+        if self.sliding_window is not None:
+            return None
         num_tokens, hidden_size = query.shape
         md = attn_metadata.decode_metadata
         max_len = md.max_decode_seq_len

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   static_assert(BS == 8 || BS == 16 || BS == 32, "a 16-token tile is one block, half a block, or two 8-token blocks");
   static_assert(BS != 8 || (!KV8 && !ROPE), "8-token blocks: 16-bit caches, separate rope / cache-write launches");
   static_assert(!(ROPE && KV8) || D % 128 == 0, "fused rotation over an fp8 cache: Q fragment j pairs with j + NSQ/2");
-  static_assert(NBUF >= 1 && NBUF <= 3, "register sets per wave");
+  static_assert(NBUF >= 2 && NBUF <= 6, "register sets per wave");
   constexpr int NS = (D + 31) / 32;   // k-slices of the QK product
   constexpr int NDT = (D + 15) / 16;  // 16-row d-tiles of the PV product
   constexpr int DPAD = NDT * 16;
@@ -297,15 +297,17 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   // of tile 0 (and 1) then overlap the position -> cos / sin -> rotation -> cache-write prologue and its barrier
   // instead of following them (the tile that ends with the new token takes that token from the LDS stash, never
   // from the bytes this launch is writing) ----
-  u32x4_t k0[NKL], k1[NKL], k2[NKL];
-  vraw_t v0[NDT], v1[NDT], v2[NDT];
-  int64_t bn0 = block_number(0), bn1 = block_number(1), bn2 = block_number(2);
+  // NBUF register sets: set s holds tile s, s + NBUF, ...; bnr[s] the block number of the set's NEXT tile
+  u32x4_t kset[NBUF][NKL];
+  vraw_t vset[NBUF][NDT];
+  int64_t bnr[NBUF];
+#pragma unroll
+  for (int s = 0; s < NBUF; ++s) bnr[s] = block_number(s);
   auto first_loads = [&]() __attribute__((always_inline)) {
-    load_tile(k0, v0, 0, bn0);
-    bn0 = block_number(NBUF == 1 ? 1 : NBUF == 2 ? 2 : 3);
-    if constexpr (NBUF == 3) {
-      load_tile(k1, v1, 1, bn1);
-      bn1 = block_number(4);
+#pragma unroll
+    for (int s = 0; s + 1 < NBUF; ++s) {
+      load_tile(kset[s], vset[s], s, bnr[s]);
+      bnr[s] = block_number(s + NBUF);
     }
   };
   if constexpr (ROPE) first_loads();  // (without the prologue the Q loads go first, as before: 25.0 against 25.4 us)
@@ -549,36 +551,19 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   };
 
   // ---- main loop: NBUF register sets rotate; NBUF-1 tiles stay in flight ----
+  // Before tile j + u (set u) is multiplied, the loads of tile j + u + NBUF - 1 go into the set tile j + u - 1 has
+  // just left.  Tiles past the wave's last one load nothing (zero-size descriptors) and multiply zeros against
+  // masked logits: the running maximum, sum and accumulators are unchanged by them.
   {
     if constexpr (!ROPE) first_loads();
-    if constexpr (NBUF == 3) {
-      for (int j = 0; j < nmy; j += 3) {
-        load_tile(k2, v2, j + 2, bn2);
-        bn2 = block_number(j + 5);
-        compute_tile(k0, v0, j);
-        load_tile(k0, v0, j + 3, bn0);
-        bn0 = block_number(j + 6);
-        compute_tile(k1, v1, j + 1);
-        load_tile(k1, v1, j + 4, bn1);
-        bn1 = block_number(j + 7);
-        compute_tile(k2, v2, j + 2);
-      }
-    } else if constexpr (NBUF == 1) {
-      (void)bn1; (void)bn2;
-      for (int j = 0; j < nmy; ++j) {
-        compute_tile(k0, v0, j);
-        load_tile(k0, v0, j + 1, bn0);
-        bn0 = block_number(j + 2);
-      }
-    } else {
-      (void)bn2;
-      for (int j = 0; j < nmy; j += 2) {
-        load_tile(k1, v1, j + 1, bn1);
-        bn1 = block_number(j + 3);
-        compute_tile(k0, v0, j);
-        load_tile(k0, v0, j + 2, bn0);
-        bn0 = block_number(j + 4);
-        compute_tile(k1, v1, j + 1);
+    for (int j = 0; j < nmy; j += NBUF) {
+#pragma unroll
+      for (int u = 0; u < NBUF; ++u) {
+        constexpr int kSets = NBUF;
+        const int s = (u + kSets - 1) % kSets;
+        load_tile(kset[s], vset[s], j + u + NBUF - 1, bnr[s]);
+        bnr[s] = block_number(j + u + 2 * NBUF - 1);
+        compute_tile(kset[u], vset[u], j + u);
       }
     }
   }
@@ -630,6 +615,11 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 #ifndef LVLLM_ATTN_NBUF
 #define LVLLM_ATTN_NBUF 2  // measured: 2 sets beat 3 by 13 % at bs32/seq1024 (profiles/r01_tuning.md)
 #endif
+// fp8 caches: a register set is half the size (and half the bytes in flight), so the fp8 instantiations take their
+// own count (profiles/r03_tuning.md section 1)
+#ifndef LVLLM_ATTN_NBUF_KV8
+#define LVLLM_ATTN_NBUF_KV8 2
+#endif
 
 template <typename T, int D, int BS, int NWAVES>
 static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStream_t stream) {
@@ -648,7 +638,7 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   };
   if constexpr (D % 128 == 0 && BS != 8) {
     if (p.positions != nullptr && p.kv_fp8) {  // fused rotation + quantised cache write (host checked the envelope)
-      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true, true>);
+      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true, true>);
       return;
     }
   }
@@ -660,11 +650,43 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   }
   if constexpr (D % 16 == 0 && BS != 8) {
     if (p.kv_fp8) {
-      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, true>);
+      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true>);
       return;
     }
   }
   launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false>);
+}
+
+// fp8 caches, 16 waves per workgroup: the fp8 kernel needs under 128 registers with two sets, so four waves fit a
+// SIMD -- twice the loads in flight per CU of the 8-wave launch (tuning value attn_waves_fp8; section 1 of
+// profiles/r03_tuning.md)
+template <typename T, int D, int BS>
+static bool launch_mfma_fp8_16waves(const AttnParams& p, int num_seqs, int num_parts, hipStream_t stream) {
+  if constexpr (D % 16 == 0 && BS != 8 && D <= 128) {
+    constexpr int NW = 16;
+    const int G = p.num_heads / p.num_kv_heads;
+    const int HG = (G + 15) / 16;
+    const int nh_lds = G < 16 ? G : 16;
+    constexpr int DPAD = ((D + 15) / 16) * 16;
+    const size_t smem = (size_t)NW * 16 * 2 * sizeof(float) + (size_t)NW * nh_lds * DPAD * sizeof(float) +
+                        (p.positions != nullptr ? (size_t)2 * D * 2 : 0);
+    if (smem > 160 * 1024) return false;
+    auto launch = [&](auto kern) {
+      if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NW * 64), smem, stream, p);
+    };
+    if (p.positions != nullptr) {
+      if constexpr (D % 128 == 0) {
+        launch(paged_attn_mfma_kernel<T, D, BS, NW, 2, true, true>);
+        return true;
+      }
+      return false;
+    }
+    launch(paged_attn_mfma_kernel<T, D, BS, NW, 2, true>);
+    return true;
+  }
+  return false;
 }
 
 template <typename T, int D, int BS>
@@ -673,6 +695,9 @@ static void launch_mfma_waves(const AttnParams& p, int num_seqs, int num_parts,
   // 16-token tiles per workgroup decide how many waves can be kept busy
   const int tiles = (max_tokens_per_wg + 15) / 16;
   const int G = p.num_heads / p.num_kv_heads;
+  if (p.kv_fp8 && tiles >= 32 && tuning().attn_waves_fp8 == 16 &&
+      launch_mfma_fp8_16waves<T, D, BS>(p, num_seqs, num_parts, stream))
+    return;
   const bool lds8_ok =
       (size_t)8 * (G < 16 ? G : 16) * (((D + 15) / 16) * 16) * 4 + 1024 <= 160 * 1024;
 #ifndef LVLLM_ATTN_NWAVES_LONG

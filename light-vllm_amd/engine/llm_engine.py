@@ -359,6 +359,10 @@ class LLMEngine:
         self._fence: Optional[torch.cuda.Event] = None                # latest block-moving step (see _launch)
         self.step_timeout_s = 300.0
         self.step_returns_outputs = True
+        # counters a benchmark reads instead of inferring its work: model steps the processed results covered
+        # (a burst of k counts k) and tokens actually appended to sequences
+        self.stat_model_steps = 0
+        self.stat_tokens_appended = 0
 
     def capture_decode_graphs(self, batch_size: int) -> None:
         """Set-up: capture every slot's HIP graph of a decode step of `batch_size` sequences now rather than
@@ -395,6 +399,7 @@ class LLMEngine:
         finished is dropped (its KV went into lookahead slots that are freed with the sequence)."""
         rows = out.sampled.t().tolist()  # [n][k]
         tok_of = dict(zip(out.sample_seq_ids, rows))
+        self.stat_model_steps += out.num_steps
         results: List[RequestOutput] = []
         max_model_len = self.scheduler_config.max_model_len
         eos = self.eos_token_id
@@ -404,6 +409,7 @@ class LLMEngine:
             for tok in tok_of[seq.seq_id]:
                 seq.data.update_num_computed_tokens(1)
                 seq.append_token_id(tok, 0.0)
+                self.stat_tokens_appended += 1
                 sp = g.sampling_params
                 if (eos is not None and tok == eos and not (sp is not None and sp.ignore_eos)) or \
                         (sp is not None and tok in sp.stop_token_ids):
@@ -440,6 +446,8 @@ class LLMEngine:
             return self._process_burst(sched, out)
         sampled = out.sampled.tolist() if out.sampled is not None else []
         tok_of = dict(zip(out.sample_seq_ids, sampled))
+        self.stat_model_steps += 1 if sched.scheduled_seq_groups else 0
+        self.stat_tokens_appended += len(sampled)
         results: List[RequestOutput] = []
         max_model_len = self.scheduler_config.max_model_len
         for s in sched.scheduled_seq_groups:

@@ -35,19 +35,118 @@ class ModelInput:
         return self
 
 
+class PrefillOnlyWorker:
+    """The model on its GPU, the per-step input building and the step itself
+    (prefill_only/worker/gpu_worker.py + runner/model_runner.py of the reference).  `pooling`: "cls" (bge-m3's dense
+    embedding: first token, L2-normalised, fp32), "mean", or "last_hidden_states" (the whole [len, hidden] block per
+    request)."""
+
+    def __init__(self, model_config: EncoderConfig, device: str = "cuda:0", pooling: str = "cls", seed: int = 0):
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.model_config = model_config
+        self.model = EncoderModel(model_config, device, seed)
+        self.builder = self.model.backend.make_metadata_builder()
+        assert pooling in ("cls", "mean", "last_hidden_states")
+        self.pooling = pooling
+
+    def build(self, token_ids: torch.Tensor, seq_lens: List[int]) -> ModelInput:
+        """prefill_only/processor/model_input_builder.py:17-52: the scheduled prompts back to back, positions
+        restarting at every prompt, the attention metadata from the lengths."""
+        pos = torch.cat([torch.arange(n, dtype=torch.long) for n in seq_lens]) if seq_lens else token_ids.new_empty(0)
+        if torch.cuda.is_available():
+            token_ids, pos = token_ids.pin_memory(), pos.pin_memory()
+        return ModelInput(token_ids, pos, self.builder(seq_lens=list(seq_lens)), list(seq_lens))
+
+    @torch.inference_mode()
+    def execute(self, mi: ModelInput) -> torch.Tensor:
+        """On the current stream: H2D, forward, pooling, D2H into pinned memory (not yet complete)."""
+        mi.to(self.device)
+        hidden = self.model.forward(mi.input_ids, mi.positions, mi.attn_metadata)
+        if self.pooling == "last_hidden_states":
+            out = hidden
+        else:
+            start = mi.attn_metadata.seq_start_loc[:-1].long()
+            if self.pooling == "cls":
+                pooled = hidden[start].float()
+            else:
+                csum = torch.cat([hidden.new_zeros(1, hidden.shape[1], dtype=torch.float32),
+                                  hidden.float().cumsum(0)])
+                end = mi.attn_metadata.seq_start_loc[1:].long()
+                pooled = (csum[end] - csum[start]) / (end - start).unsqueeze(1)
+            out = torch.nn.functional.normalize(pooled, dim=-1)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        return host
+
+
+class PrefillOnlyStepExecutor:
+    """A worker's execute loop over queues it shares with other workers (the data-parallel front end,
+    dp_executor.py; reference: Executor.async_execute_loop, prefill_only/executor/gpu_executor.py:109-262).  `slots`
+    steps are in flight on their own streams: one step's copies run beside another's kernels.  A slot is taken
+    BEFORE an item is taken off the shared queue, so a worker never holds a step it cannot start."""
+
+    def __init__(self, worker: PrefillOnlyWorker, slots: int = 2):
+        self.worker = worker
+        self.slots = max(1, slots)
+        self.streams = [torch.cuda.Stream(worker.device) for _ in range(self.slots)]
+
+    def execute_loop(self, executor_in, executor_out, rank: int = 0) -> None:
+        from .dp_executor import ExecuteOutput
+        torch.cuda.set_device(self.worker.device)
+        free: "queue.Queue" = queue.Queue()
+        for i in range(self.slots):
+            free.put(i)
+        done_q: "queue.Queue" = queue.Queue()
+
+        def done_loop():
+            torch.cuda.set_device(self.worker.device)
+            while True:
+                item = done_q.get()
+                if item is None:
+                    return
+                slot, ev, step_id, host, t0 = item
+                try:
+                    ev.synchronize()
+                    out = ExecuteOutput(step_id, rank, host, execute_begin_ts=t0, execute_end_ts=time.time())
+                except Exception as e:
+                    out = ExecuteOutput(step_id, rank, None, error=repr(e))
+                free.put(slot)
+                executor_out.put(out)
+
+        waiter = threading.Thread(target=done_loop, daemon=True)
+        waiter.start()
+        while True:
+            slot = free.get()
+            item = executor_in.get()
+            if item is None:
+                free.put(slot)
+                break
+            t0 = time.time()
+            try:
+                with torch.cuda.stream(self.streams[slot]):
+                    host = self.worker.execute(self.worker.build(item.token_ids, item.seq_lens))
+                    ev = torch.cuda.Event()
+                    ev.record(self.streams[slot])
+                done_q.put((slot, ev, item.step_id, host, t0))
+            except Exception as e:
+                free.put(slot)
+                executor_out.put(ExecuteOutput(item.step_id, rank, None, error=repr(e)))
+        done_q.put(None)
+        waiter.join(timeout=30)
+
+
 class PrefillOnlyEngine:
-    """`pooling`: "cls" (bge-m3's dense embedding: first token, L2-normalised, fp32), "mean", or
-    "last_hidden_states" (the whole [len, hidden] block per request)."""
+    """One engine = one GPU: scheduler + worker in one process (`dp_executor.DataParallelEncodeEngine` puts N worker
+    processes behind one scheduler).  `pooling`: see PrefillOnlyWorker."""
 
     def __init__(self, model_config: EncoderConfig, scheduler_config: PrefillOnlySchedulerConfig,
                  device: str = "cuda:0", pooling: str = "cls", seed: int = 0):
-        self.device = torch.device(device)
-        torch.cuda.set_device(self.device)
+        self.worker = PrefillOnlyWorker(model_config, device, pooling, seed)
+        self.device = self.worker.device
         self.model_config, self.scheduler_config = model_config, scheduler_config
-        self.model = EncoderModel(model_config, device, seed)
+        self.model = self.worker.model
         self.scheduler = PrefillOnlyScheduler(scheduler_config)
-        self.builder = self.model.backend.make_metadata_builder()
-        assert pooling in ("cls", "mean", "last_hidden_states")
         self.pooling = pooling
         self.num_slots = (max(1, scheduler_config.max_num_on_the_fly)
                           if scheduler_config.scheduling in ("async", "double_buffer") else 1)
@@ -73,40 +172,11 @@ class PrefillOnlyEngine:
 
     # ---- one step ----
     def _build(self, sched: PrefillOnlySchedulerOutput) -> ModelInput:
-        pin = torch.cuda.is_available()
-        toks: List[int] = []
-        pos: List[int] = []
-        lens: List[int] = []
-        for r in sched.scheduled_requests:
-            toks.extend(r.prompt_token_ids)
-            pos.extend(range(r.num_new_tokens))
-            lens.append(r.num_new_tokens)
-        ids = torch.tensor(toks, dtype=torch.long)
-        p = torch.tensor(pos, dtype=torch.long)
-        if pin:
-            ids, p = ids.pin_memory(), p.pin_memory()
-        return ModelInput(ids, p, self.builder(seq_lens=lens), lens)
+        toks = torch.tensor([t for r in sched.scheduled_requests for t in r.prompt_token_ids], dtype=torch.long)
+        return self.worker.build(toks, [r.num_new_tokens for r in sched.scheduled_requests])
 
-    @torch.inference_mode()
     def _execute(self, mi: ModelInput) -> torch.Tensor:
-        """On the current stream: H2D, forward, pooling, D2H into pinned memory (not yet complete)."""
-        mi.to(self.device)
-        hidden = self.model.forward(mi.input_ids, mi.positions, mi.attn_metadata)
-        if self.pooling == "last_hidden_states":
-            out = hidden
-        else:
-            start = mi.attn_metadata.seq_start_loc[:-1].long()
-            if self.pooling == "cls":
-                pooled = hidden[start].float()
-            else:
-                csum = torch.cat([hidden.new_zeros(1, hidden.shape[1], dtype=torch.float32),
-                                  hidden.float().cumsum(0)])
-                end = mi.attn_metadata.seq_start_loc[1:].long()
-                pooled = (csum[end] - csum[start]) / (end - start).unsqueeze(1)
-            out = torch.nn.functional.normalize(pooled, dim=-1)
-        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-        host.copy_(out, non_blocking=True)
-        return host
+        return self.worker.execute(mi)
 
     def _process(self, sched: PrefillOnlySchedulerOutput, host: Optional[torch.Tensor], lens: List[int]):
         outs: List[PrefillOnlyRequestOutput] = []

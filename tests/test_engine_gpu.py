@@ -53,16 +53,19 @@ def dense_reference_logits(model, token_ids):
 
 def make_engine(graph, scheduling="sync", num_blocks=256, max_seqs=8, chunked=False, budget=2048,
                 cache_dtype="auto", quantization=None, v2=False, prefix_caching=False, preemption_mode=None,
-                num_scheduler_steps=1, max_model_len=512, stream_gemm_max_rows=None):
+                num_scheduler_steps=1, max_model_len=512, stream_gemm_max_rows=None, sliding_window=None,
+                rope_in_attention=True):
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
     from light_vllm_amd.engine.llm_engine import LLMEngine
     cfg = ModelConfig.tiny()
     cfg.quantization = quantization
+    cfg.rope_in_attention = rope_in_attention
     if stream_gemm_max_rows is not None:
         cfg.stream_gemm_max_rows = stream_gemm_max_rows
     return LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=num_blocks, num_cpu_blocks=32,
-                                      cache_dtype=cache_dtype, enable_prefix_caching=prefix_caching),
+                                      cache_dtype=cache_dtype, enable_prefix_caching=prefix_caching,
+                                      sliding_window=sliding_window),
                      SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=max_model_len,
                                      scheduling=scheduling, max_num_on_the_fly=2,
                                      chunked_prefill_enabled=chunked, use_v2_block_manager=v2,
@@ -162,6 +165,27 @@ def test_preemption_under_memory_pressure_keeps_results():
     assert same >= len(ref) - 2, (same, len(ref))
     for a, b in zip(got, ref):
         assert a[:4] == b[:4]
+
+
+@pytest.mark.parametrize("v2", [False, True])
+def test_sliding_window_decode_does_not_take_the_fused_rope_attention_launch(v2):
+    """CacheConfig.sliding_window shorter than the generated length: the v1 manager hands over a circular block
+    table with seq_len clipped to the window (block_manager_v1.py:279-295), where the step's new token is NOT
+    logical position seq_len - 1 -- the one assumption of the rope + cache + attention launch.  The backend must
+    route such steps to the separate launches: tokens with rope_in_attention on and off are identical, eager and
+    captured, and the fused entry answers None."""
+    runs = {}
+    for rope in (True, False):
+        for graph in (False, True):
+            e = make_engine(graph=graph, v2=v2, sliding_window=32, rope_in_attention=rope)
+            assert e.worker.attn_impl.sliding_window == 32
+            runs[(rope, graph)] = run_to_completion(e, max_tokens=60)
+    assert all(len(t) == 60 for t in runs[(False, False)])
+    assert runs[(True, False)] == runs[(False, False)]
+    assert runs[(True, True)] == runs[(False, True)]
+    e = make_engine(graph=False, v2=v2, sliding_window=32)
+    assert e.worker.attn_impl.rope_cache_decode_attention(None, torch.zeros(1, 256), None, None, None, None, None,
+                                                          None) is None
 
 
 def collect_logits(engine, max_tokens=4):

@@ -73,8 +73,24 @@ def main():
         torch.cuda.synchronize()
         ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
         med, mn = ts[len(ts) // 2], ts[0]
+        # trains of 32 back-to-back launches between one event pair (what bench.py's roofline object times):
+        # the per-launch figure carries the kernel and its launch gap, not the cost of two events per kernel
+        tr = []
+        k = 0
+        for _ in range(max(2, a.iters // 32)):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(32):
+                fn(k)
+                k += 1
+            e_.record()
+            torch.cuda.synchronize()
+            tr.append(s_.elapsed_time(e_) * 1e3 / 32)
+        tavg = sum(tr) / len(tr)
         print(f"{name}: median {med:.1f} us  min {mn:.1f} us  -> {algo_bytes / med / 1e6:.2f} TB/s median "
-              f"({algo_bytes / med / 1e6 / 8 * 100:.1f}% of 8 TB/s), algorithmic bytes {algo_bytes}")
+              f"({algo_bytes / med / 1e6 / 8 * 100:.1f}% of 8 TB/s); trains of 32: {tavg:.2f} us per launch "
+              f"(min {min(tr):.2f}) -> {algo_bytes / tavg / 1e6:.2f} TB/s = {algo_bytes / tavg / 1e6 / 8:.3f} of 8 TB/s; "
+              f"algorithmic bytes {algo_bytes}")
 
 
 if __name__ == "__main__":
