@@ -76,6 +76,9 @@ def parse():
                     help="workgroups per decode GEMM launch (default: 256 for one stream, 128 for several)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-ops-baseline", action="store_true", help="no per-op GPU / CPU timings of the small operators")
+    ap.add_argument("--skip-other-configs", action="store_true",
+                    help="no other_settings entries for BASELINE configs 3 (chunked prefill), 4 (encode-only) and 5 (fp8 "
+                         "weights + fp8 KV cache); each builds its own engine after the headline region")
     ap.add_argument("--skip-prefill-roofline", action="store_true",
                     help="no roofline_prefill object (one 16k-token prompt through the prefill kernel)")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
@@ -177,11 +180,13 @@ def gemm_leg(engine, B):
     """The other HBM stream of a decode step: the four weight-streaming projections of a layer
     (csrc/skinny_gemm.hip), timed on the engine's own packed weights -- trains of one launch per layer
     (32 different weight matrices per train, >> the Infinity Cache) with HIP events on the launch
-    stream, at the workgroup count a lone step would use (256).  Returns None when the engine's
-    weights are not the packed 16-bit ones (library GEMM, fp8)."""
+    stream, at the workgroup count a lone step would use (256).  W8A8 engines (`--quantization fp8`) time
+    lvllm_skinny_gemm_w8a8 on the packed fp8 weights (one byte per weight).  Returns None when the engine's
+    weights are not packed (library GEMM)."""
     model = engine.worker.model
     layers = model.layers
-    if any(l.qkv.packed is None for l in layers):
+    w8 = all(l.qkv.w8_packed is not None for l in layers)
+    if not w8 and any(l.qkv.packed is None for l in layers):
         return None
     dev = engine.device
     cfg = engine.model_config
@@ -192,22 +197,28 @@ def gemm_leg(engine, B):
             ws = [getattr(l, name) for l in layers]
             N, K = ws[0].N, ws[0].K
             x = (torch.randn(B, K, device=dev) * 0.5).to(cfg.dtype)
+
+            def call(w):
+                if w8:
+                    torch.ops._C_amd.skinny_linear_w8a8(x, w.w8_packed, w.w_scale, w.x_scale, N, K, None)
+                else:
+                    torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
             for w in ws[:4]:
-                torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
+                call(w)
             torch.cuda.synchronize(dev)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
             for a, b in evs:
                 a.record()
                 for w in ws:
-                    torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
+                    call(w)
                 b.record()
             torch.cuda.synchronize(dev)
             t = min(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(ws)
-            by = N * K * 2 + B * K * 2 + B * N * 2  # weights once + activations in + result out
+            by = N * K * (1 if w8 else 2) + B * K * 2 + B * N * 2  # weights once + activations in + result out
             per_shape[name] = {"us": round(t * 1e6, 2), "GB/s": round(by / t / 1e9, 1)}
             tot_bytes += by
             tot_s += t
-        return dict(per_shape=per_shape, bytes_per_layer=tot_bytes, s_per_layer=tot_s)
+        return dict(per_shape=per_shape, bytes_per_layer=tot_bytes, s_per_layer=tot_s, w8=w8)
     finally:
         torch.ops._C_amd.set_tuning("gemm_workgroups", engine.gemm_workgroups)
 
@@ -407,6 +418,180 @@ def prefill_leg(engine, qlen=16384, iters=12):
             "avg_launch_us": round(avg * 1e6, 1), "min_launch_us": round(min(ts) * 1e6, 1)}
 
 
+def decode_region(engine, B, steps, burst, in_flight, sync=False):
+    """`steps` model steps of the decode engine as bursts of `burst`, `in_flight` engine steps in flight, the
+    pipeline empty on both sides; returns (tokens appended -- counted by the engine, not inferred --, seconds)."""
+    engine.scheduler_config.num_scheduler_steps = burst
+    engine.scheduler_config.max_num_on_the_fly = in_flight
+    n = steps // burst
+    tok0, st0 = engine.stat_tokens_appended, engine.stat_model_steps
+    torch.cuda.synchronize(engine.device)
+    t0 = time.perf_counter()
+    for i in range(n):
+        if sync:
+            engine.step()
+        else:
+            engine.async_step(schedule_more=i < n - (in_flight - 1))
+    torch.cuda.synchronize(engine.device)
+    el = time.perf_counter() - t0
+    assert engine.num_on_the_fly == 0
+    assert engine.stat_model_steps - st0 == steps, (engine.stat_model_steps - st0, steps)
+    return engine.stat_tokens_appended - tok0, el
+
+
+def fp8_config_leg(a, dev, B, ctx, steps=32):
+    """BASELINE config 5 beside the headline: the same decode workload with fp8 (e4m3) W8A8 projections
+    (csrc/quantization fp8 -> CDNA4 fp8 MFMA) AND an fp8 KV cache, two engine steps in flight, bursts of 8.  Its own
+    engine (own weights); returns the other_settings entry with tokens/s, ms/step, algorithmic bytes / time against
+    8 TB/s, and the rooflines of its two HBM streams (fp8 attention launch, W8A8 projections)."""
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+    cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    cfg.quantization = "fp8"
+    k = largest_divisor_at_most(steps, 8)
+    fly = 2
+    max_len = ctx + steps // fly + 6 * k + 8
+    bs = 16
+    blocks = B * fly * ((max_len + bs - 1) // bs + 1) + 64
+    eng = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype="fp8"),
+                    SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
+                                    max_model_len=(max_len + 511) // 512 * 512, scheduling="async", max_num_on_the_fly=fly,
+                                    use_v2_block_manager=True, num_scheduler_steps=k), device=dev, seed=7)
+    eng.step_returns_outputs = False
+    g = torch.Generator().manual_seed(99)
+    for i in range(B * fly):
+        eng.add_request(str(i), torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist(), max_tokens=4 * steps + 100)
+    eng.prefill_synthetic(seed=7)
+    eng.capture_decode_graphs(B)
+    decode_region(eng, B, k * fly, k, fly)  # warm-up: one burst per slot
+    toks, el = decode_region(eng, B, steps, k, fly)
+    assert toks == steps * B, (toks, steps, B)
+    kl = kernel_leg(eng, B, 96, seq_len=ctx)
+    gm = gemm_leg(eng, B) if B <= 64 else None
+    L = cfg.num_hidden_layers
+    kv_step = 2 * B * ctx * cfg.num_key_value_heads * cfg.head_dim * 1 * L
+    step_bytes = eng.worker.model.weight_bytes() + kv_step
+    eng.shutdown()
+    out = {"value": round(toks / el, 1), "unit": "tokens/s", "ms_per_step": round(el / steps * 1e3, 4),
+           "steps": steps, "config": f"BASELINE config 5: fp8 e4m3 W8A8 projections + fp8 KV cache, decode bs={B} ctx={ctx}, "
+                                     f"{fly} in flight, {k} model steps per engine step",
+           "algorithmic_bytes_per_step": step_bytes,
+           "hbm": {"achieved": round(step_bytes / (el / steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(step_bytes / (el / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+           "roofline_attention": {"bound": "hbm", "kernel": "paged_attn_mfma_kernel<KV8> (fp8 cache), single pass",
+                                  "achieved": round(kl["algo_bytes"] / kl["avg_s"] / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(kl["algo_bytes"] / kl["avg_s"] / 1e9 / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes_per_launch": kl["algo_bytes"],
+                                  "avg_launch_us": round(kl["avg_s"] * 1e6, 2)}}
+    if gm is not None:
+        ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
+        out["roofline_projections"] = {"bound": "hbm", "kernel": f"skinny_gemm_w8a8_kernel (qkv, o, gate_up, down of one layer, M = {B})",
+                                       "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
+                                       "us_per_layer": round(gm["s_per_layer"] * 1e6, 2), "per_shape": gm["per_shape"]}
+    del eng
+    return out
+
+
+def chunked_prefill_leg(a, dev, num_prompts=96, input_len=512, output_len=512, budget=64):
+    """BASELINE config 3 beside the headline: the reference's benchmarks/benchmark_chunked_prefill_throughput.py
+    workload (:176-201: 512-token prompts, 512 output tokens, chunked prefill, max_num_batched_tokens = max_num_seqs
+    = 64; fewer prompts: a short region) on its own bf16 engine, async, every mixed step a captured graph.  tokens/s
+    counts prompt and output tokens like the reference script.  Algorithmic bytes of a step: every weight once (<= 64
+    rows) + the K/V of every sequence in the step up to its current length, tallied from the scheduler's metadata."""
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+    cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    if a.tiny:
+        num_prompts, input_len, output_len = 12, 96, 24
+    max_len = input_len + output_len + 16
+    bs = 16
+    blocks = (budget + 8) * ((max_len + bs - 1) // bs + 1) + 64
+    eng = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0),
+                    SchedulerConfig(max_num_batched_tokens=budget, max_num_seqs=budget,
+                                    max_model_len=(max_len + 511) // 512 * 512, scheduling="async", max_num_on_the_fly=2,
+                                    chunked_prefill_enabled=True), device=dev, seed=3)
+    eng.step_returns_outputs = False
+    kv_tok = 2 * cfg.num_key_value_heads * cfg.head_dim * 2 * cfg.num_hidden_layers  # bytes of K+V per token, all layers
+    tally = {"kv": 0, "steps": 0}
+    real = eng._execute
+
+    def counting(sched, slot):
+        for m in sched.seq_group_metadata_list:
+            for d in m.seq_data.values():
+                n = d.get_len() if not m.is_prompt else min(d.get_len(), d.get_num_computed_tokens() + m.token_chunk_size)
+                tally["kv"] += n * kv_tok
+        tally["steps"] += 1
+        return real(sched, slot)
+    eng._execute = counting
+    g = torch.Generator().manual_seed(0)
+    for i in range(num_prompts):
+        eng.add_request(str(i), torch.randint(0, cfg.vocab_size, (input_len,), generator=g).tolist(), max_tokens=output_len)
+    done = 0
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while eng.has_unfinished_requests() or eng.num_on_the_fly > 0:
+        for o in eng.async_step():
+            done += o.finished
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    assert done == num_prompts and eng.stat_tokens_appended == num_prompts * output_len
+    by = tally["steps"] * eng.worker.model.weight_bytes() + tally["kv"]
+    eng.shutdown()
+    total = num_prompts * (input_len + output_len)
+    out = {"value": round(total / el, 1), "unit": "tokens/s", "requests_per_s": round(num_prompts / el, 2),
+           "ms_per_step": round(el / tally["steps"] * 1e3, 4), "steps": tally["steps"],
+           "config": f"BASELINE config 3: chunked prefill, {num_prompts} prompts x ({input_len} in + {output_len} out), "
+                     f"max_num_batched_tokens = max_num_seqs = {budget}, async (2 in flight), bf16; tokens/s counts prompt + output tokens",
+           "algorithmic_bytes": by,
+           "hbm": {"achieved": round(by / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(by / el / 1e9 / HBM_PEAK_GBS, 4)}}
+    del eng
+    return out
+
+
+def encode_only_leg(a, dev, num_prompts=512, length=512, max_num_seqs=32):
+    """BASELINE config 4 beside the headline: bge-m3 shapes (XLM-RoBERTa-large: 24 layers, hidden 1024, 16 heads of
+    64) through the prefill-only engine (light_vllm.encode_only workflow: varlen bidirectional attention + the fused
+    add + LayerNorm / GELU kernels, library GEMMs), two steps in flight, dense (CLS) embeddings out.  MFMA-bound:
+    FLOPs = tokens x (2 x layer weights + 4 x length x hidden per layer)."""
+    from light_vllm_amd.prefill_only import PrefillOnlySchedulerConfig
+    from light_vllm_amd.prefill_only.engine import PrefillOnlyEngine
+    from light_vllm_amd.prefill_only.model import EncoderConfig
+    cfg = EncoderConfig.tiny() if a.tiny else EncoderConfig.bge_m3()
+    if a.tiny:
+        num_prompts, length, max_num_seqs = 24, 64, 4
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(2, cfg.vocab_size, (length,), generator=g).tolist() for _ in range(num_prompts)]
+    eng = PrefillOnlyEngine(cfg, PrefillOnlySchedulerConfig(max_model_len=max(length, 8), max_num_seqs=max_num_seqs,
+                                                            scheduling="async"), device=dev)
+    eng.encode(prompts[: 2 * max_num_seqs])  # warm up
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    res = eng.encode(prompts)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    eng.shutdown()
+    assert len(res) == num_prompts
+    hid, inter, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    ntok = num_prompts * length
+    flops = ntok * L * (2.0 * (4 * hid * hid + 2 * hid * inter) + 4.0 * length * hid)
+    steps = (num_prompts + max_num_seqs - 1) // max_num_seqs
+    by = steps * L * (4 * hid * hid + 2 * hid * inter) * 2 + ntok * hid * 2 * L * 12  # weights per step + ~12 activation passes
+    out = {"value": round(num_prompts / el, 1), "unit": "sequences/s", "tokens_per_s": round(ntok / el, 1),
+           "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+           "config": f"BASELINE config 4: encode-only, bge-m3 shapes (L{L} hidden {hid} heads {cfg.num_attention_heads}), "
+                     f"{num_prompts} prompts x {length} tokens, {max_num_seqs} per step, async (2 in flight), bf16, CLS pooling",
+           "mfma": {"achieved": round(flops / el / 1e12, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(flops / el / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4)},
+           "algorithmic_bytes": by,
+           "hbm": {"achieved": round(by / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(by / el / 1e9 / HBM_PEAK_GBS, 4)}}
+    del eng
+    return out
+
+
 def largest_divisor_at_most(n, k):
     """Largest d <= k with n % d == 0 (>= 1)."""
     for d in range(max(1, min(k, n)), 0, -1):
@@ -577,6 +762,19 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     engine.shutdown()
+    # BASELINE configs 3, 4, 5 beside the headline (never as `value`): each on its own engine, after this one is gone
+    if rank == 0 and world == 1 and not a.skip_other_configs and not (a.quantization or a.kv_cache_dtype != "auto"):
+        import gc
+        engine.worker.graph_pools = None
+        del engine
+        gc.collect()
+        torch.cuda.empty_cache()
+        for key, leg in (("config3_chunked_prefill", lambda: chunked_prefill_leg(a, dev)),
+                         ("config5_fp8_weights_fp8_kv", lambda: fp8_config_leg(a, dev, B, ctx)),
+                         ("config4_encode_only", lambda: encode_only_leg(a, dev))):
+            other[key] = leg()
+            gc.collect()
+            torch.cuda.empty_cache()
     if rank == 0:
         achieved = kl["algo_bytes"] / kl["avg_s"] / 1e9
         line = {
@@ -621,13 +819,13 @@ def main():
             try:  # PMC passes of the same kernels at the same shapes (tools/pmc_gemm.py), M = 32 only
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")) as f:
                     pm = json.load(f)
-                if B == pm["M"] and not a.tiny:
+                if B == pm["M"] and not a.tiny and not gm["w8"]:
                     gm_traffic = sum(v["hbm_bytes_per_launch"] for v in pm["shapes"].values())
             except (OSError, KeyError, ValueError):
                 pass
             line["roofline_projections"] = {
-                "bound": "hbm", "kernel": "skinny_gemm_kernel (qkv, o, gate_up + SwiGLU input, down of one layer, M = "
-                                          f"{B}, 256 workgroups)",
+                "bound": "hbm", "kernel": ("skinny_gemm_w8a8_kernel" if gm["w8"] else "skinny_gemm_kernel") +
+                                          f" (qkv, o, gate_up + SwiGLU input, down of one layer, M = {B}, 256 workgroups)",
                 "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_ach / HBM_PEAK_GBS, 4),
                 "traffic": gm_traffic, "traffic_source": "profiles/r01_pmc_gemm.json (2*FETCH_SIZE + WRITE_SIZE per launch, "
                                                          "the four shapes summed; M = 32)",

@@ -363,6 +363,34 @@ int lvllm_advance_step_ex(int num_seqs, int num_queries, int block_size, int64_t
                           int64_t block_tables_stride, int64_t* token_log, int skip_empty_rows,
                           void* stream);
 
+/* ---- device-side sampler (replaces the torch sequence of light_vllm/decoding/backends/sampler.py:90-200:
+ * _apply_min_tokens_penalty :238-277, _apply_penalties :281-301, _apply_top_k_top_p :304-330, _apply_min_p :333-347,
+ * _greedy_sample / _multinomial :350-454) ----
+ * One launch per step: tokens_out[row] int64 <- the token drawn for row `row` of `logits` [num_rows, vocab]
+ * (row stride logits_stride elements, element type `logits_dtype` = enum lvllm_dtype).
+ * state_slot (nullable) int32 [num_rows]: the request's slot in the device-resident sampler state, or < 0 for a
+ * plain greedy row (arg-max of the logits, ties to the smaller index -- torch.argmax).  A slot is
+ *   params + slot * LVLLM_SAMPLER_PARAMS_BYTES : { float temperature, top_p, min_p, presence_penalty,
+ *       frequency_penalty, repetition_penalty; int32 top_k (<= 0 or >= vocab: off); int32 min_tokens; uint64 seed;
+ *       int32 output_len; int32 num_banned; int32 banned[20] }   (stop tokens banned while output_len < min_tokens)
+ *   counts + slot * counts_stride : int32 [vocab], bit 31 = token occurs in the prompt, bits 0..30 = occurrences in
+ *       the output so far (lvllm_sampler_init_row fills it from the histories).
+ * update_state != 0: the drawn token is added to the slot's counts and output_len += 1 on the device, so the model
+ * steps of a multi-step burst need no host round trip.  scratch: float [num_rows, scratch_stride >= vocab] working
+ * copy of the rows (needed when state_slot is given).  processed_out (nullable) float [num_rows, processed_stride]:
+ * the logits as they stand before the draw (-inf = filtered out), for tests.  temperature < 1e-5 = greedy on the
+ * penalised logits.  Random numbers: Philox4x32-10, key = seed, counter = (vocabulary index / 4, output_len).
+ * Deterministic: integer histograms and 2^-40 fixed-point mass sums, no floating-point atomics. */
+#define LVLLM_SAMPLER_PARAMS_BYTES 128
+int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_t logits_stride, int logits_dtype,
+                      int num_rows, int vocab, const int32_t* state_slot, void* params, int32_t* counts,
+                      int64_t counts_stride, int num_slots, float* scratch, int64_t scratch_stride,
+                      float* processed_out, int64_t processed_stride, int update_state, void* stream);
+/* counts_row int32 [vocab] <- 0, then bit 31 for every prompt token and +1 for every output token (ids outside
+ * [0, vocab) -- padding -- are ignored).  Token lists are device (or device-visible pinned) int64 arrays. */
+int lvllm_sampler_init_row(int32_t* counts_row, int vocab, const int64_t* prompt_tokens, int n_prompt,
+                           const int64_t* output_tokens, int n_output, void* stream);
+
 /* convert_fp8: csrc/cache_kernels.cu:334-410, torch_bindings.cpp:261-264 ("only for testing" there).
  * to_fp8 != 0: dst (bytes) = fp8(float(src) / scale); else dst = T(float(fp8 src) * scale).  `dtype` is the
  * element type of the non-fp8 side; contiguous buffers of num_elems elements. */

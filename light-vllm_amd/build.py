@@ -34,6 +34,7 @@ HIP_SOURCES = [
     "prefill_attention.hip",
     "prepare_inputs.hip",
     "fp8_quant.hip",
+    "sampler.hip",
 ]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

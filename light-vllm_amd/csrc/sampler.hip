@@ -1,0 +1,391 @@
+// Device-side sampler: everything between the lm_head's logits and the next token ids of a decode step, in ONE
+// launch, so that a step with sampled (non-greedy) requests stays inside the captured graph and the multi-step burst.
+//
+// WHAT (reference: light_vllm/decoding/backends/sampler.py:90-200 forward; :238-277 _apply_min_tokens_penalty;
+// :281-301 _apply_penalties; :304-330 _apply_top_k_top_p; :333-347 _apply_min_p; :434-454 _multinomial):
+//   per row: stop tokens banned while fewer than min_tokens outputs exist -> repetition / frequency / presence
+//   penalties from the prompt and output token histories -> division by the temperature -> top-k (keep everything
+//   >= the k-th largest value) -> top-p (sorted ascending, drop the prefix whose probability mass is <= 1 - p, never
+//   the largest) -> min-p (drop what is less likely than min_p x the most likely) -> an exponential-race multinomial
+//   draw (arg-max of p_i / q_i, q_i ~ Exp(1)); greedy rows (temperature < 1e-5) take the arg-max of the penalised
+//   logits.  The reference runs these as ~25 torch launches (two full sorts among them) on the [rows, vocab] matrix.
+//
+// HOW: one workgroup of 1024 threads per row.  The row's fp32 working copy lives in a caller-provided scratch (it
+// stays in the XCD's L2 between passes).  Nothing is sorted: the k-th largest value and the top-p cut are found by a
+// three-level radix descent (11 + 11 + 10 bits of the order-preserving integer image of the float) over LDS
+// histograms -- counts for top-k, probability mass for top-p.  Mass is accumulated in 2^-40 fixed point with integer
+// atomics, so the result does not depend on the order in which the adds arrive: the kernel is deterministic.
+// Per-request state lives on the device in `state slots` (SamplerParams + one int32 per vocabulary entry: bit 31 =
+// seen in the prompt, bits 0..30 = occurrences in the output); the kernel appends the token it drew to that state, so
+// the k model steps of a burst need no host round trip.  Random numbers: Philox4x32-10 keyed by the request's seed,
+// counter = (vocabulary index / 4, number of tokens the request has drawn so far): a request's stream depends on
+// nothing but its seed and its own step count.
+//
+// Differences from the reference, stated: arithmetic is fp32 on the model-dtype logits (the reference's live code
+// keeps the model dtype through penalties and filters, its golden vectors here were recorded in fp32); exact ties at
+// the top-p cut are kept as a group (the reference keeps whichever of them its unstable sort happened to put last);
+// the random stream is Philox, not torch's generator -- seeded requests repeat themselves, they do not repeat torch.
+#include <float.h>
+
+#include "common.h"
+
+namespace lvllm {
+
+struct SamplerParams {  // one per state slot; 128 bytes; the host writes it, the kernel advances output_len
+  float temperature, top_p, min_p, presence, frequency, repetition;
+  int32_t top_k;       // <= 0 or >= vocab: off
+  int32_t min_tokens;  // stop tokens are banned while output_len < min_tokens
+  uint64_t seed;
+  int32_t output_len;  // tokens drawn so far (device-updated)
+  int32_t num_banned;
+  int32_t banned[20];
+};
+static_assert(sizeof(SamplerParams) == LVLLM_SAMPLER_PARAMS_BYTES, "include/lvllm_hip.h states the size");
+
+constexpr int kSamplerThreads = 1024;
+constexpr float kSamplingEps = 1e-5f;  // sampling_params.py:14 (_SAMPLING_EPS)
+
+__device__ __forceinline__ uint32_t order_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
+  const uint32_t b = __builtin_bit_cast(uint32_t, x);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+  uint32_t c2 = 0, c3 = 0;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename LT>
+__device__ __forceinline__ float logit_to_float(LT v);
+template <>
+__device__ __forceinline__ float logit_to_float<float>(float v) { return v; }
+struct BF16Bits { uint16_t v; };
+struct F16Bits { uint16_t v; };
+template <>
+__device__ __forceinline__ float logit_to_float<BF16Bits>(BF16Bits v) { return BF16::to_float(v.v); }
+template <>
+__device__ __forceinline__ float logit_to_float<F16Bits>(F16Bits v) { return F16::to_float(v.v); }
+
+// (value, index) arg-max of the block, ties to the smaller index; result in every thread
+__device__ inline void block_argmax(float& v, int& i, float* sv, int* si) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(v, m);
+    const int oi = __shfl_xor(i, m);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sv[wave] = v; si[wave] = i; }
+  __syncthreads();
+  float rv = lane < kSamplerThreads / 64 ? sv[lane] : -INFINITY;
+  int ri = lane < kSamplerThreads / 64 ? si[lane] : 0x7fffffff;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(rv, m);
+    const int oi = __shfl_xor(ri, m);
+    if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+  }
+  v = __shfl(rv, 0);
+  i = __shfl(ri, 0);
+}
+
+__device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t* red) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  uint64_t r = lane < kSamplerThreads / 64 ? red[lane] : 0;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) r += __shfl_xor(r, m);
+  return __shfl(r, 0);
+}
+
+// Histogram search by wave 0.  `from_top`: first bin b (walking down from the last) whose running total reaches
+// `target` (counts: the k-th largest lies in b); else first bin (walking up) whose running total EXCEEDS `target`
+// (mass: the cut lies in b).  Writes the bin and the total accumulated before it; bin = -1 when no bin qualifies.
+template <int NBINS, bool FROM_TOP>
+__device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_out, uint64_t* before_out) {
+  if (threadIdx.x < 64) {
+    constexpr int PER = NBINS / 64;
+    const int lane = threadIdx.x;
+    const int base = FROM_TOP ? NBINS - 1 - lane * PER : lane * PER;
+    uint64_t mine = 0;
+#pragma unroll 4
+    for (int j = 0; j < PER; ++j) mine += hist[FROM_TOP ? base - j : base + j];
+    uint64_t incl = mine;  // inclusive scan over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    const uint64_t excl = incl - mine;
+    const bool hit = FROM_TOP ? (excl < target && incl >= target) : (excl <= target && incl > target);
+    const uint64_t ballot = __ballot(hit);
+    if (ballot == 0) {
+      if (lane == 0) { *bin_out = -1; *before_out = 0; }
+    } else if (lane == __ffsll((long long)ballot) - 1) {
+      uint64_t run = excl;
+      int b = -1;
+      for (int j = 0; j < PER; ++j) {
+        const int idx = FROM_TOP ? base - j : base + j;
+        const uint64_t h = hist[idx];
+        const bool here = FROM_TOP ? (run + h >= target) : (run + h > target);
+        if (here) { b = idx; break; }
+        run += h;
+      }
+      *bin_out = b;
+      *before_out = run;
+    }
+  }
+  __syncthreads();
+}
+
+template <typename LT>
+__global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
+    int64_t* __restrict__ tokens_out, const LT* __restrict__ logits, const int64_t logits_stride, const int vocab,
+    const int32_t* __restrict__ state_slot, SamplerParams* __restrict__ params, int32_t* __restrict__ counts,
+    const int64_t counts_stride, const int num_slots, float* __restrict__ scratch, const int64_t scratch_stride,
+    float* __restrict__ processed_out, const int64_t processed_stride, const int update_state) {
+  __shared__ uint64_t hist[2048];
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  __shared__ uint64_t red[16];
+  __shared__ int s_bin;
+  __shared__ uint64_t s_before;
+
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const LT* lrow = logits + (int64_t)row * logits_stride;
+  const int sid = state_slot != nullptr ? state_slot[row] : -1;
+
+  if (sid < 0 || sid >= num_slots) {  // plain greedy row: arg-max of the logits as they are
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < vocab; i += kSamplerThreads) {
+      const float x = logit_to_float<LT>(lrow[i]);
+      if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+    }
+    block_argmax(bv, bi, sv, si);
+    if (processed_out != nullptr)
+      for (int i = tid; i < vocab; i += kSamplerThreads)
+        processed_out[(int64_t)row * processed_stride + i] = logit_to_float<LT>(lrow[i]);
+    if (tid == 0) tokens_out[row] = bi;
+    return;
+  }
+
+  __shared__ SamplerParams P;  // one copy per workgroup (its banned[] list is indexed dynamically)
+  if (tid < (int)(sizeof(SamplerParams) / 4)) ((uint32_t*)&P)[tid] = ((const uint32_t*)&params[sid])[tid];
+  __syncthreads();
+  int32_t* crow = counts + (int64_t)sid * counts_stride;
+  float* x_row = scratch + (int64_t)row * scratch_stride;
+  const bool greedy = P.temperature < kSamplingEps;
+  const bool do_pen = P.presence != 0.f || P.frequency != 0.f || P.repetition != 1.f;
+  const int nban = P.output_len < P.min_tokens ? min(P.num_banned, 20) : 0;
+  const float temp = greedy ? 1.f : P.temperature;  // sampling_metadata.py: greedy rows divide by 1
+
+  // ---- pass A: ban, penalties, temperature; the row's maximum ----
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < vocab; i += kSamplerThreads) {
+    float x = logit_to_float<LT>(lrow[i]);
+    for (int b = 0; b < nban; ++b)
+      if (P.banned[b] == i) x = -INFINITY;
+    if (do_pen) {
+      const uint32_t c = (uint32_t)crow[i];
+      if (c != 0) x = x > 0.f ? x / P.repetition : x * P.repetition;
+      const float oc = (float)(c & 0x7fffffffu);
+      x -= P.frequency * oc;
+      x -= P.presence * (oc > 0.f ? 1.f : 0.f);
+    }
+    x = x / temp;
+    x_row[i] = x;
+    if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+  }
+  block_argmax(bv, bi, sv, si);
+  const float m = bv;
+  int token = bi;
+
+  if (!greedy) {
+    // ---- top-k: the key of the k-th largest value (counts, from the top) ----
+    uint32_t kth_key = 0;  // everything is >= key 0
+    if (P.top_k > 0 && P.top_k < vocab) {
+      uint64_t want = (uint64_t)P.top_k;
+      uint32_t prefix = 0;
+#pragma unroll 1
+      for (int level = 0; level < 3; ++level) {
+        const int shift = level == 0 ? 21 : level == 1 ? 10 : 0;
+        const int nb = level == 2 ? 1024 : 2048;
+        for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < vocab; i += kSamplerThreads) {
+          const uint32_t key = order_key(x_row[i]);
+          const bool in = level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix);
+          if (in) atomicAdd((unsigned long long*)&hist[(key >> shift) & (nb - 1)], 1ull);
+        }
+        __syncthreads();
+        if (level == 2) find_bin<1024, true>(hist, want, &s_bin, &s_before);
+        else find_bin<2048, true>(hist, want, &s_bin, &s_before);
+        const int b = s_bin;
+        want -= s_before;
+        prefix = level == 0 ? (uint32_t)b : level == 1 ? ((prefix << 11) | (uint32_t)b) : ((prefix << 10) | (uint32_t)b);
+        __syncthreads();
+      }
+      kth_key = prefix;
+    }
+    // ---- top-p: the smallest key whose mass from the bottom (inside the top-k set) exceeds (1 - p) Z ----
+    uint32_t cut_key = kth_key;
+    if (P.top_p < 1.f) {
+      uint64_t z = 0;
+      for (int i = tid; i < vocab; i += kSamplerThreads) {
+        const float x = x_row[i];
+        if (order_key(x) >= kth_key) z += (uint64_t)(expf(x - m) * 1099511627776.f);  // 2^40
+      }
+      z = block_sum_u64(z, red);
+      uint64_t target = (uint64_t)((double)(1.f - P.top_p) * (double)z);
+      uint32_t prefix = 0;
+      bool found = true;
+#pragma unroll 1
+      for (int level = 0; level < 3 && found; ++level) {
+        const int shift = level == 0 ? 21 : level == 1 ? 10 : 0;
+        const int nb = level == 2 ? 1024 : 2048;
+        for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < vocab; i += kSamplerThreads) {
+          const float x = x_row[i];
+          const uint32_t key = order_key(x);
+          const bool in = key >= kth_key &&
+                          (level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix));
+          if (in)
+            atomicAdd((unsigned long long*)&hist[(key >> shift) & (nb - 1)],
+                      (unsigned long long)(expf(x - m) * 1099511627776.f));
+        }
+        __syncthreads();
+        if (level == 2) find_bin<1024, false>(hist, target, &s_bin, &s_before);
+        else find_bin<2048, false>(hist, target, &s_bin, &s_before);
+        const int b = s_bin;
+        if (b < 0) {
+          found = false;  // the whole mass is <= the target (p -> 0): only the largest survives ("at least one")
+        } else {
+          target -= s_before;
+          prefix = level == 0 ? (uint32_t)b : level == 1 ? ((prefix << 11) | (uint32_t)b) : ((prefix << 10) | (uint32_t)b);
+        }
+        __syncthreads();
+      }
+      const uint32_t max_key = order_key(m);
+      cut_key = found ? prefix : max_key;
+      if (cut_key > max_key) cut_key = max_key;
+      if (cut_key < kth_key) cut_key = kth_key;
+    }
+    // ---- min-p + the draw: arg-max over the kept tokens of (x - m) - log(q), q ~ Exp(1) ----
+    const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+    const uint32_t step = (uint32_t)P.output_len;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i4 = tid; i4 * 4 < vocab; i4 += kSamplerThreads) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)i4, step, k0, k1, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i4 * 4 + e;
+        if (i >= vocab) break;
+        float x = x_row[i];
+        bool keep = order_key(x) >= cut_key && x > -INFINITY;
+        if (keep && P.min_p > 0.f) keep = !(expf(x - m) < P.min_p);
+        if (!keep) x = -INFINITY;
+        if (processed_out != nullptr) processed_out[(int64_t)row * processed_stride + i] = x;
+        if (keep) {
+          const float u = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
+          const float q = -logf(u);
+          const float s = (x - m) - logf(q);
+          if (s > best || (s == best && i < besti)) { best = s; besti = i; }
+        }
+      }
+    }
+    block_argmax(best, besti, sv, si);
+    token = besti != 0x7fffffff ? besti : bi;
+  } else if (processed_out != nullptr) {
+    for (int i = tid; i < vocab; i += kSamplerThreads) processed_out[(int64_t)row * processed_stride + i] = x_row[i];
+  }
+
+  if (tid == 0) {
+    tokens_out[row] = token;
+    if (update_state) {  // the drawn token joins the request's output history
+      crow[token] += 1;
+      params[sid].output_len = P.output_len + 1;
+    }
+  }
+}
+
+// A state slot's vocabulary row from the request's histories: bit 31 = in the prompt, low bits = output occurrences.
+__global__ void sampler_init_row_kernel(int32_t* __restrict__ crow, const int vocab, const int64_t* __restrict__ prompt,
+                                        const int n_prompt, const int64_t* __restrict__ output, const int n_output) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_prompt) {
+    const int64_t t = prompt[i];
+    if (t >= 0 && t < vocab) atomicOr((unsigned int*)&crow[t], 0x80000000u);
+  } else if (i < n_prompt + n_output) {
+    const int64_t t = output[i - n_prompt];
+    if (t >= 0 && t < vocab) atomicAdd((unsigned int*)&crow[t], 1u);
+  }
+}
+
+}  // namespace lvllm
+
+using namespace lvllm;
+
+extern "C" int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_t logits_stride, int logits_dtype,
+                                 int num_rows, int vocab, const int32_t* state_slot, void* params, int32_t* counts,
+                                 int64_t counts_stride, int num_slots, float* scratch, int64_t scratch_stride,
+                                 float* processed_out, int64_t processed_stride, int update_state, void* stream) {
+  LV_CHECK(num_rows >= 0 && vocab > 0, "bad shape");
+  if (num_rows == 0) return 0;
+  LV_CHECK(tokens_out != nullptr && logits != nullptr, "null tokens_out / logits");
+  LV_CHECK(state_slot == nullptr || (params != nullptr && counts != nullptr && scratch != nullptr && num_slots > 0),
+           "rows with state need params, counts and scratch");
+  LV_CHECK(scratch == nullptr || scratch_stride >= vocab, "scratch rows shorter than the vocabulary");
+  LV_CHECK(counts == nullptr || counts_stride >= vocab, "count rows shorter than the vocabulary");
+  hipStream_t s = (hipStream_t)stream;
+  auto* pp = (SamplerParams*)params;
+#define LV_SAMPLE(LT)                                                                                              \
+  hipLaunchKernelGGL(sampler_kernel<LT>, dim3(num_rows), dim3(kSamplerThreads), 0, s, tokens_out, (const LT*)logits, \
+                     logits_stride, vocab, state_slot, pp, counts, counts_stride, num_slots, scratch, scratch_stride, \
+                     processed_out, processed_stride, update_state)
+  switch (logits_dtype) {
+    case LVLLM_F32: LV_SAMPLE(float); break;
+    case LVLLM_F16: LV_SAMPLE(F16Bits); break;
+    case LVLLM_BF16: LV_SAMPLE(BF16Bits); break;
+    default: LV_CHECK(false, "unsupported logits dtype");
+  }
+#undef LV_SAMPLE
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int lvllm_sampler_init_row(int32_t* counts_row, int vocab, const int64_t* prompt_tokens, int n_prompt,
+                                      const int64_t* output_tokens, int n_output, void* stream) {
+  LV_CHECK(counts_row != nullptr && vocab > 0 && n_prompt >= 0 && n_output >= 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(counts_row, 0, (size_t)vocab * 4, s) != hipSuccess) {
+    set_error("lvllm_sampler_init_row: memset failed");
+    return 2;
+  }
+  const int n = n_prompt + n_output;
+  if (n > 0) {
+    hipLaunchKernelGGL(sampler_init_row_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counts_row, vocab, prompt_tokens,
+                       n_prompt, output_tokens, n_output);
+    LV_LAUNCH_CHECK();
+  }
+  return 0;
+}

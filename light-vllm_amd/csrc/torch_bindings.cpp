@@ -649,6 +649,67 @@ void advance_step_logged(int64_t block_size, torch::Tensor& input_tokens, const 
                               token_log.data_ptr<int64_t>(), 1, current_stream(input_tokens)));
 }
 
+// Device-side sampler (include/lvllm_hip.h: lvllm_sample_rows).  `params` uint8 [num_slots, 128], `counts` int32
+// [num_slots, vocab], `scratch` float [rows, >= vocab]; all three absent = every row plain greedy.
+void sample_rows(torch::Tensor& tokens_out, const torch::Tensor& logits, const std::optional<torch::Tensor>& state_slot,
+                 const std::optional<torch::Tensor>& params, const std::optional<torch::Tensor>& counts,
+                 const std::optional<torch::Tensor>& scratch, const std::optional<torch::Tensor>& processed_out,
+                 bool update_state) {
+  LV_CHECK_DEVICE(logits);
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "sample_rows: logits [rows, vocab], unit inner stride");
+  const int64_t rows = logits.size(0), vocab = logits.size(1);
+  TORCH_CHECK(tokens_out.is_cuda() && tokens_out.scalar_type() == at::kLong && tokens_out.is_contiguous() &&
+              tokens_out.numel() >= rows, "sample_rows: tokens_out int64 [rows]");
+  const int32_t* slot = nullptr;
+  void* pp = nullptr;
+  int32_t* cc = nullptr;
+  float* sc = nullptr;
+  float* po = nullptr;
+  int64_t cstride = 0, sstride = 0, pstride = 0, nslots = 0;
+  if (state_slot.has_value()) {
+    TORCH_CHECK(params.has_value() && counts.has_value() && scratch.has_value(),
+                "sample_rows: state_slot needs params, counts and scratch");
+    TORCH_CHECK(state_slot->is_cuda() && state_slot->scalar_type() == at::kInt && state_slot->is_contiguous() &&
+                state_slot->numel() >= rows, "sample_rows: state_slot int32 [rows]");
+    TORCH_CHECK(params->is_cuda() && params->scalar_type() == at::kByte && params->is_contiguous() && params->dim() == 2 &&
+                params->size(1) == LVLLM_SAMPLER_PARAMS_BYTES, "sample_rows: params uint8 [slots, 128]");
+    TORCH_CHECK(counts->is_cuda() && counts->scalar_type() == at::kInt && counts->dim() == 2 && counts->stride(1) == 1 &&
+                counts->size(0) == params->size(0) && counts->size(1) >= vocab, "sample_rows: counts int32 [slots, vocab]");
+    TORCH_CHECK(scratch->is_cuda() && scratch->scalar_type() == at::kFloat && scratch->dim() == 2 &&
+                scratch->stride(1) == 1 && scratch->size(0) >= rows && scratch->size(1) >= vocab,
+                "sample_rows: scratch float [rows, >= vocab]");
+    slot = state_slot->data_ptr<int32_t>();
+    pp = params->data_ptr();
+    cc = counts->data_ptr<int32_t>();
+    sc = scratch->data_ptr<float>();
+    cstride = counts->stride(0);
+    sstride = scratch->stride(0);
+    nslots = params->size(0);
+  }
+  if (processed_out.has_value()) {
+    TORCH_CHECK(processed_out->is_cuda() && processed_out->scalar_type() == at::kFloat && processed_out->dim() == 2 &&
+                processed_out->stride(1) == 1 && processed_out->size(0) >= rows && processed_out->size(1) >= vocab,
+                "sample_rows: processed_out float [rows, >= vocab]");
+    po = processed_out->data_ptr<float>();
+    pstride = processed_out->stride(0);
+  }
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(logits));
+  check(lvllm_sample_rows(tokens_out.data_ptr<int64_t>(), logits.data_ptr(), logits.stride(0),
+                          dtype_code(logits, "sample_rows"), (int)rows, (int)vocab, slot, pp, cc, cstride, (int)nslots, sc,
+                          sstride, po, pstride, update_state ? 1 : 0, current_stream(logits)));
+}
+
+void sampler_init_row(torch::Tensor& counts_row, const torch::Tensor& prompt_tokens, const torch::Tensor& output_tokens) {
+  LV_CHECK_DEVICE(counts_row);
+  TORCH_CHECK(counts_row.scalar_type() == at::kInt && counts_row.dim() == 1 && counts_row.stride(0) == 1);
+  TORCH_CHECK(prompt_tokens.is_cuda() && prompt_tokens.scalar_type() == at::kLong && prompt_tokens.is_contiguous());
+  TORCH_CHECK(output_tokens.is_cuda() && output_tokens.scalar_type() == at::kLong && output_tokens.is_contiguous());
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(counts_row));
+  check(lvllm_sampler_init_row(counts_row.data_ptr<int32_t>(), (int)counts_row.size(0), prompt_tokens.data_ptr<int64_t>(),
+                               (int)prompt_tokens.numel(), output_tokens.data_ptr<int64_t>(), (int)output_tokens.numel(),
+                               current_stream(counts_row)));
+}
+
 // csrc/cache_kernels.cu:352-410
 void convert_fp8(torch::Tensor& dst_cache, torch::Tensor& src_cache, const double scale,
                  const std::string& kv_cache_dtype) {
@@ -952,6 +1013,11 @@ TORCH_LIBRARY(_C_amd, amd) {
           "Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables, "
           "Tensor! token_log) -> ()");
   amd.impl("advance_step_logged", torch::kCUDA, &advance_step_logged);
+  amd.def("sample_rows(Tensor! tokens_out, Tensor logits, Tensor? state_slot, Tensor(a!)? params, Tensor(b!)? counts, "
+          "Tensor(c!)? scratch, Tensor(d!)? processed_out, bool update_state) -> ()");
+  amd.impl("sample_rows", torch::kCUDA, &sample_rows);
+  amd.def("sampler_init_row(Tensor! counts_row, Tensor prompt_tokens, Tensor output_tokens) -> ()");
+  amd.impl("sampler_init_row", torch::kCUDA, &sampler_init_row);
   amd.def("set_tuning(str key, int value) -> ()", [](const std::string& key, int64_t value) {
     check(lvllm_set_tuning(key.c_str(), (int)value));
   });

@@ -21,8 +21,12 @@ from .input_builder import DecodeStepArrays, MixedStepArrays
 
 class DecodeGraph:
     def __init__(self, model, kv_caches: List[torch.Tensor], batch_size: int,
-                 max_blocks_per_seq: int, block_size: int, device):
+                 max_blocks_per_seq: int, block_size: int, device, sampler=None):
+        """`sampler` (device_sampler.DeviceSampler): the captured step ends with the lm_head's logits and the sampling
+        kernel (rows with a state slot are sampled, the others take the arg-max); None: the lm_head's arg-max
+        epilogue, no logits tensor (every row plain greedy)."""
         self.model = model
+        self.sampler = sampler
         self.kv_caches = kv_caches
         self.batch_size = batch_size
         self.max_blocks_per_seq = max_blocks_per_seq
@@ -31,14 +35,16 @@ class DecodeGraph:
         # the five static inputs are views of one device buffer, mirrored by one pinned staging
         # buffer on the host: a step's inputs arrive with a single copy (DecodeStepArrays)
         B, W = batch_size, max_blocks_per_seq
-        o_ids, o_pos, o_slot, o_len, o_bt, total = DecodeStepArrays.layout(B, W)
+        o_ids, o_pos, o_slot, o_len, o_bt, o_state, total = DecodeStepArrays.layout(B, W)
         self.packed = torch.zeros(total, dtype=torch.uint8, device=dev)
         self.input_ids = self.packed[o_ids:o_pos].view(torch.int64)
         self.positions = self.packed[o_pos:o_slot].view(torch.int64)
         self.slot_mapping = self.packed[o_slot:o_len].view(torch.int64)
         self.seq_lens = self.packed[o_len:o_bt].view(torch.int32)
-        self.block_tables = self.packed[o_bt:].view(torch.int32).view(B, W)
+        self.block_tables = self.packed[o_bt:o_state].view(torch.int32).view(B, W)
+        self.state_slots = self.packed[o_state:].view(torch.int32)
         self.slot_mapping.fill_(-1)
+        self.state_slots.fill_(-1)
         self.host = torch.zeros(total, dtype=torch.uint8, pin_memory=dev.type == "cuda")
         self.staging = DecodeStepArrays(B, W, block_size, self.host.numpy())
         # pinned landing buffers of the sampled tokens: a result is read by the host right after its step
@@ -94,6 +100,8 @@ class DecodeGraph:
 
     def _step(self):
         hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, self._metadata())
+        if self.sampler is not None:  # logits -> one sampling launch, still inside the captured step
+            return hidden, self.sampler.sample(self.model.compute_logits(hidden), self.state_slots)
         return hidden, self.model.greedy_tokens(hidden)  # greedy sampling stays on the device
 
     def capture(self, stream: Optional[torch.cuda.Stream] = None) -> None:
@@ -111,9 +119,12 @@ class DecodeGraph:
             self.hidden, self.next_tokens = self._step()
         torch.cuda.synchronize()
 
-    def load(self, input_ids, positions, slot_mapping, block_tables, seq_lens) -> None:
+    def load(self, input_ids, positions, slot_mapping, block_tables, seq_lens, state_slots=None) -> None:
         """Copy one step's inputs (device or pinned-host tensors) into the static buffers."""
         n = input_ids.shape[0]
+        self.state_slots.fill_(-1)
+        if state_slots is not None:
+            self.state_slots[:n].copy_(state_slots, non_blocking=True)
         self.input_ids[:n].copy_(input_ids, non_blocking=True)
         self.positions[:n].copy_(positions, non_blocking=True)
         self.slot_mapping[:n].copy_(slot_mapping, non_blocking=True)
@@ -230,6 +241,7 @@ class DecodeGraphPool:
         self.model, self.kv_caches = model, kv_caches
         self.max_blocks_per_seq, self.block_size, self.device = max_blocks_per_seq, block_size, device
         self.graphs: Dict[int, DecodeGraph] = {}
+        self.sampler_graphs: Dict[int, DecodeGraph] = {}  # the flavour that ends with the sampling kernel
         self.mixed: Optional[MixedGraph] = None
 
     @staticmethod
@@ -265,14 +277,18 @@ class DecodeGraphPool:
             self.mixed = self._off_default_stream(build)
         return self.mixed
 
-    def get(self, batch_size: int) -> DecodeGraph:
+    def get(self, batch_size: int, sampler=None) -> DecodeGraph:
+        """`sampler` (DeviceSampler): the graph flavour whose step ends with logits + the sampling kernel, captured
+        the first time a step with a non-greedy request comes by."""
         p = self.padded(batch_size)
-        g = self.graphs.get(p)
+        pool = self.graphs if sampler is None else self.sampler_graphs
+        g = pool.get(p)
         if g is None:
             def build():
-                g = DecodeGraph(self.model, self.kv_caches, p, self.max_blocks_per_seq, self.block_size, self.device)
+                g = DecodeGraph(self.model, self.kv_caches, p, self.max_blocks_per_seq, self.block_size, self.device,
+                                sampler=sampler)
                 g.capture()
                 return g
             g = self._off_default_stream(build)
-            self.graphs[p] = g
+            pool[p] = g
         return g

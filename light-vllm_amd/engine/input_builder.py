@@ -207,22 +207,25 @@ class DecodeStepArrays:
         self.nbytes = self.layout(B, W)[-1]
         buf = np.zeros(self.nbytes, dtype=np.uint8) if buffer is None else buffer
         assert buf.dtype == np.uint8 and buf.size == self.nbytes
-        o_ids, o_pos, o_slot, o_len, o_bt, _ = self.layout(B, W)
+        o_ids, o_pos, o_slot, o_len, o_bt, o_state, _ = self.layout(B, W)
         self.buffer = buf
         self.input_ids = buf[o_ids:o_pos].view(np.int64)
         self.positions = buf[o_pos:o_slot].view(np.int64)
         self.slot_mapping = buf[o_slot:o_len].view(np.int64)
         self.seq_lens = buf[o_len:o_bt].view(np.int32)
-        self.block_tables = buf[o_bt:].view(np.int32).reshape(B, W)
+        self.block_tables = buf[o_bt:o_state].view(np.int32).reshape(B, W)
+        # sampler state slot of each row (device_sampler.py): -1 = plain greedy; read by the sampling kernel only
+        self.state_slots = buf[o_state:].view(np.int32)
         self.slot_mapping[:] = -1
+        self.state_slots[:] = -1
         self._rows: List[Optional[List[int]]] = [None] * B  # the table each row holds
         self._arange = np.arange(B)
 
     @staticmethod
     def layout(B: int, W: int):
         """Byte offsets of (input_ids i64[B], positions i64[B], slot_mapping i64[B], seq_lens i32[B],
-        block_tables i32[B, W]) and the total size."""
-        return 0, 8 * B, 16 * B, 24 * B, 28 * B, 28 * B + 4 * B * W
+        block_tables i32[B, W], sampler state slots i32[B]) and the total size."""
+        return 0, 8 * B, 16 * B, 24 * B, 28 * B, 28 * B + 4 * B * W, 32 * B + 4 * B * W
 
     @staticmethod
     def eligible(metas, worker_lists_empty: bool, sliding_window) -> bool:
@@ -233,10 +236,11 @@ class DecodeStepArrays:
                 return False
         return True
 
-    def fill(self, metas) -> Optional[List[int]]:
+    def fill(self, metas, state_slots: Optional[List[int]] = None) -> Optional[List[int]]:
         """Writes the step into the staging arrays (rows past len(metas) become padding: slot -1,
         length 0) and returns the sequence ids in row order; None when a block table is wider than
-        the arrays (the caller then takes the general path)."""
+        the arrays (the caller then takes the general path).  `state_slots`: the rows' sampler state slots
+        (None: every row plain greedy)."""
         n = len(metas)
         assert n <= self.batch_size
         seq_ids: List[int] = []
@@ -270,6 +274,9 @@ class DecodeStepArrays:
         if n < self.batch_size:
             self.slot_mapping[n:] = -1
             self.seq_lens[n:] = 0
+        self.state_slots[:] = -1
+        if state_slots is not None:
+            self.state_slots[:n] = state_slots
         return seq_ids
 
 

@@ -73,6 +73,9 @@ class Worker:
         # > 0: mixed (chunked-prefill) steps of at most this many tokens / sequences replay one graph
         self.mixed_graph_tokens, self.mixed_graph_seqs = mixed_graph_tokens, mixed_graph_seqs
         self.graph_pools: Optional[List[DecodeGraphPool]] = None
+        # device-resident sampler state (device_sampler.DeviceSampler), created by the engine with the first request
+        # that is not plain greedy; None: every step ends with the arg-max epilogue
+        self.sampler = None
         # tests: keep the logits of the sampled rows of the last eager step
         self.capture_logits = False
         self.last_logits: Optional[torch.Tensor] = None
@@ -185,10 +188,15 @@ class Worker:
                                                 self.cache_config.block_size, self.device)
                                 for _ in range(self.num_slots)]
 
+    def _slots_tensor(self, slots: List[int]) -> torch.Tensor:
+        t = torch.tensor(slots, dtype=torch.int32)
+        return (t.pin_memory() if self.device.type == "cuda" else t).to(self.device, non_blocking=True)
+
     @torch.inference_mode()
-    def execute(self, execute_input: ExecuteInput, slot: int = 0, sampling=None) -> ExecuteOutput:
-        """`sampling`: a callable (sample_seq_ids) -> SamplingBatch for steps in which some request is not
-        plain greedy: the logits of the sampled rows then go through the sampler's front half."""
+    def execute(self, execute_input: ExecuteInput, slot: int = 0, state_slots=None) -> ExecuteOutput:
+        """`state_slots`: {seq id: sampler state slot} for a step in which some request is not plain greedy (None:
+        all plain greedy): the step's logits then go through the device sampler (one launch: penalties, temperature,
+        top-k / top-p / min-p, the draw; rows without a slot take the arg-max)."""
         wi, mi = execute_input.worker_input, execute_input.model_input
         ce = self.cache_engine
         if wi.blocks_to_swap_in.numel() > 0:
@@ -201,19 +209,21 @@ class Worker:
             return ExecuteOutput(None, [])
         md = mi.attn_metadata
         graphs = self.graph_pools[slot] if self.graph_pools is not None else None
+        row_slots = None if state_slots is None else [state_slots.get(sid, -1) for sid in mi.sample_seq_ids]
         if graphs is not None and mi.decode_only and md.block_tables.shape[1] <= graphs.max_blocks_per_seq:
-            g = graphs.get(mi.input_tokens.shape[0])
-            g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor)
-            tokens = g.replay()[:mi.input_tokens.shape[0]]
-            rows = None
-            if len(mi.sample_indices) != mi.input_tokens.shape[0]:
-                rows = torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)
-                tokens = tokens[rows]
-            if sampling is not None:  # the captured step's hidden states -> logits -> sampler
-                hidden = g.hidden[:mi.input_tokens.shape[0]]
-                logits = self.model.compute_logits(hidden if rows is None else hidden[rows])
-                tokens = sampling(mi.sample_seq_ids).sample(logits)
-        elif (graphs is not None and self.mixed_graph_tokens > 0 and not self.capture_logits and sampling is None
+            n = mi.input_tokens.shape[0]
+            g = graphs.get(n, sampler=self.sampler if row_slots is not None else None)
+            per_row = None
+            if row_slots is not None:  # one slot per ROW of the step (rows that do not sample: -1)
+                full = [-1] * n
+                for r, sl in zip(mi.sample_indices, row_slots):
+                    full[r] = sl
+                per_row = self._slots_tensor(full)
+            g.load(mi.input_tokens, mi.input_positions, md.slot_mapping, md.block_tables, md.seq_lens_tensor, per_row)
+            tokens = g.replay()[:n]
+            if len(mi.sample_indices) != n:
+                tokens = tokens[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
+        elif (graphs is not None and self.mixed_graph_tokens > 0 and not self.capture_logits and row_slots is None
               and mi.input_tokens.shape[0] <= self.mixed_graph_tokens
               and md.seq_lens_tensor.shape[0] <= self.mixed_graph_seqs
               and md.block_tables.shape[0] == md.seq_lens_tensor.shape[0]
@@ -230,14 +240,17 @@ class Worker:
             logits = self.model.compute_logits(hidden)
             if self.capture_logits:
                 self.last_logits = logits.float().cpu()
-            tokens = torch.argmax(logits, dim=-1) if sampling is None else sampling(mi.sample_seq_ids).sample(logits)
+            if row_slots is None or logits.shape[0] == 0:
+                tokens = torch.argmax(logits, dim=-1)
+            else:
+                tokens = self.sampler.sample(logits, self._slots_tensor(row_slots))
         out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, mi.sample_seq_ids)
 
 
     @torch.inference_mode()
-    def execute_decode(self, metas, slot: int = 0, num_steps: int = 1) -> Optional[ExecuteOutput]:
+    def execute_decode(self, metas, slot: int = 0, num_steps: int = 1, state_slots=None) -> Optional[ExecuteOutput]:
         """A step of decode tokens only, taken straight from the scheduler's metadata to the captured
         graph's staging buffer (DecodeStepArrays): same inputs as `execute(input_builder(...))`, a
         fraction of the host time.  None when the step does not fit the captured shapes.
@@ -247,8 +260,11 @@ class Worker:
         if graphs is None or self.capture_logits:
             return None
         n = len(metas)
-        g = graphs.get(n)
-        seq_ids = g.staging.fill(metas)
+        row_slots = None
+        if state_slots is not None:  # {seq id: sampler state slot}: the graph flavour that ends with the sampling kernel
+            row_slots = [state_slots.get(next(iter(m.seq_data)), -1) for m in metas]
+        g = graphs.get(n, sampler=self.sampler if row_slots is not None else None)
+        seq_ids = g.staging.fill(metas, row_slots)
         if seq_ids is None:  # a block table wider than the captured step
             return None
         g.load_staged()
@@ -353,7 +369,8 @@ class LLMEngine:
         # the engine thread polls the steps' events instead of being woken by a waiter thread (+2 % tokens/s;
         # SchedulerConfig.poll_completion = False brings the per-slot waiter threads back)
         self.poll_completion = scheduler_config.poll_completion
-        self._sampler_generator = torch.Generator(device=self.device).manual_seed(seed)
+        self.device_sampler = None  # device_sampler.DeviceSampler, created with the first request that needs it
+        self._sampler_seed = seed
         self._pending: List[Tuple[int, torch.cuda.Event, SchedulerOutput, ExecuteOutput]] = []
         self._last_event: Dict[int, Optional[torch.cuda.Event]] = {}  # latest step of each slot
         self._fence: Optional[torch.cuda.Event] = None                # latest block-moving step (see _launch)
@@ -436,6 +453,8 @@ class LLMEngine:
                     if g is not None:
                         for seq in g.seqs:
                             self.seq_to_group.pop(seq.seq_id, None)
+                            if self.device_sampler is not None:
+                                self.device_sampler.release(seq.seq_id)
         else:
             for s in sched.scheduled_seq_groups:
                 s.seq_group.busy = False
@@ -508,6 +527,8 @@ class LLMEngine:
                     if g is not None:
                         for seq in g.seqs:
                             self.seq_to_group.pop(seq.seq_id, None)
+                            if self.device_sampler is not None:
+                                self.device_sampler.release(seq.seq_id)
         else:  # nobody left: free_finished_request would only clear the busy flags of this step's groups
             for s in sched.scheduled_seq_groups:
                 s.seq_group.busy = False
@@ -528,44 +549,49 @@ class LLMEngine:
     # ---- asynchronous step (core/llm_engine.py:132-176) ----
     def _execute(self, sched: SchedulerOutput, slot: int) -> ExecuteOutput:
         """Decode-only steps go from the scheduler's metadata to the captured graph directly; every
-        other step through the general input builder."""
-        sampling = self._sampling_for(sched)
-        if sampling is not None:
-            return self.worker.execute(self.input_builder(sched), slot, sampling=sampling)
+        other step through the general input builder.  Steps with requests that are not plain greedy carry their
+        sampler state slots along and stay on the same paths (fast decode inputs, multi-step bursts included)."""
+        state_slots = self._sampler_slots(sched)
         if self.fast_decode_inputs:
             from .input_builder import DecodeStepArrays, MixedStepArrays
             plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
             metas = sched.seq_group_metadata_list
             if DecodeStepArrays.eligible(metas, plain, self.cache_config.sliding_window):
-                out = self.worker.execute_decode(metas, slot, self._burst_steps(sched))
+                out = self.worker.execute_decode(metas, slot, self._burst_steps(sched), state_slots)
                 if out is not None:
                     return out
-            elif self.worker.mixed_graph_tokens > 0 and MixedStepArrays.eligible(metas, plain,
-                                                                                 self.cache_config.sliding_window):
+            elif (state_slots is None and self.worker.mixed_graph_tokens > 0
+                  and MixedStepArrays.eligible(metas, plain, self.cache_config.sliding_window)):
                 out = self.worker.execute_mixed(metas, slot)
                 if out is not None:
                     return out
-        return self.worker.execute(self.input_builder(sched), slot)
+        return self.worker.execute(self.input_builder(sched), slot, state_slots=state_slots)
 
-    def _sampling_for(self, sched: SchedulerOutput):
-        """None when every request of the step is plain greedy (the captured arg-max serves it); otherwise a
-        factory of the step's SamplingBatch, called by the worker with the sequence ids of the sampled rows."""
-        if not any(s.seq_group.sampling_params is not None and not s.seq_group.sampling_params.plain_greedy
-                   for s in sched.scheduled_seq_groups):
+    def _sampler_slots(self, sched: SchedulerOutput) -> Optional[Dict[int, int]]:
+        """None when every request of the step is plain greedy (the captured arg-max serves it); otherwise
+        {seq id: state slot on the device} for the step's requests that are not, their state built on the current
+        stream where it does not exist yet (new request, or evicted while it waited)."""
+        groups = [s.seq_group for s in sched.scheduled_seq_groups
+                  if s.seq_group.sampling_params is not None and not s.seq_group.sampling_params.plain_greedy]
+        if not groups:
             return None
-        from ..sampling import SamplingBatch
+        if self.device_sampler is None:
+            from ..device_sampler import DeviceSampler
+            n = max(64, self.scheduler_config.max_num_seqs * (self.num_slots + 1))
+            self.device_sampler = self.worker.sampler = DeviceSampler(self.model_config.vocab_size, self.device, n,
+                                                                      seed=self._sampler_seed)
 
-        def make(sample_seq_ids):
-            rows = []
-            for sid in sample_seq_ids:
-                g = self.seq_to_group[sid]
-                seq = g.seqs_dict[sid]
-                rows.append(dict(params=g.sampling_params, prompt=seq.prompt_token_ids,
-                                 output=seq.get_output_token_ids(), eos=self.eos_token_id))
-            batch = SamplingBatch(rows, self.model_config.vocab_size, self.device, self._sampler_generator)
-            batch._steps = [len(r["output"]) for r in rows]
-            return batch
-        return make
+        def pinned():  # sequences of steps in flight and of this step keep their slots
+            keep = {seq.seq_id for g in self.groups.values() if g.busy for seq in g.seqs}
+            keep.update(seq.seq_id for g in groups for seq in g.seqs)
+            return keep
+        out: Dict[int, int] = {}
+        for g in groups:
+            for seq in g.seqs:
+                if seq.status == SequenceStatus.RUNNING:
+                    out[seq.seq_id] = self.device_sampler.ensure(seq.seq_id, g.sampling_params, seq.prompt_token_ids,
+                                                                 seq.get_output_token_ids(), self.eos_token_id, pinned)
+        return out or None
 
     def _burst_steps(self, sched: SchedulerOutput) -> int:
         """Model steps a decode-only step runs on the device before it returns to the host: the configured

@@ -118,6 +118,22 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
         assert line["config"]["max_num_on_the_fly"] == 2
         o = line["other_settings"]["max_num_on_the_fly=3"]
         assert o["value"] > 0 and o["sequences_resident"] == 24
+    if not extra:  # BASELINE configs 3, 4, 5 beside the headline, each with its rate, ms/step and bytes (or FLOPs) / time
+        o = line["other_settings"]
+        for key, unit in (("config3_chunked_prefill", "tokens/s"), ("config5_fp8_weights_fp8_kv", "tokens/s"),
+                          ("config4_encode_only", "sequences/s")):
+            e = o[key]
+            assert e["value"] > 0 and e["unit"] == unit and e["ms_per_step"] > 0 and e["steps"] > 0 and "BASELINE config" in e["config"]
+            h = e["hbm"]
+            assert h["peak"] == 8000.0 and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-3
+        assert o["config3_chunked_prefill"]["requests_per_s"] > 0
+        f8 = o["config5_fp8_weights_fp8_kv"]
+        assert f8["roofline_attention"]["bound"] == "hbm" and f8["roofline_attention"]["avg_launch_us"] > 0
+        assert set(f8["roofline_projections"]["per_shape"]) == {"qkv", "o", "gate_up", "down"}
+        m = o["config4_encode_only"]["mfma"]
+        assert m["peak"] == 2500.0 and m["unit"] == "TFLOP/s" and 0 < m["frac"] < 1
+    else:
+        assert not any(k.startswith("config") for k in line.get("other_settings", {}))
     assert line["cpu_baseline"]["value"] > 0
     ops = line["ops_baseline"]["ops"]
     assert set(ops) == {"reshape_and_cache", "rms_norm", "fused_add_rms_norm", "rotary_embedding", "silu_and_mul"}

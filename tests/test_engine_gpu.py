@@ -609,3 +609,83 @@ def test_engine_sampling_params_drive_the_sampler():
     mt = [SamplingParams(temperature=0.0, max_tokens=12, min_tokens=8) for _ in ps]
     out = run(mt, eos=eos)
     assert all(eos not in t[:8] for t in out)
+
+
+def test_sampled_requests_stay_in_the_captured_step_and_the_burst():
+    """The device-side sampler: a step with sampled requests replays a captured graph (the flavour that ends with the
+    lm_head's logits and ONE sampling launch), takes the staged fast path and runs multi-step bursts like a greedy
+    step -- the general `Worker.execute` path is never taken for a decode step -- and the tokens of k-step bursts are
+    those of single steps (the request state the kernel keeps on the device advances exactly as the host's would)."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    ps = prompts()
+
+    def params():
+        return [SamplingParams(temperature=0.9, top_k=20, top_p=0.95, seed=100 + i, max_tokens=21) if i % 2 == 0 else
+                (SamplingParams(temperature=0.0, repetition_penalty=1.3, frequency_penalty=0.4, max_tokens=21) if i == 1 else None)
+                for i in range(len(ps))]
+
+    def run(k, use_async=False, **kw):
+        e = make_engine(graph=True, v2=True, num_scheduler_steps=k, **kw)
+        general_decode_steps = []
+        real = e.worker.execute
+
+        def spy(execute_input, slot=0, state_slots=None):
+            if execute_input.model_input.decode_only:
+                general_decode_steps.append(1)
+            return real(execute_input, slot, state_slots=state_slots)
+        e.worker.execute = spy
+        for i, p in enumerate(ps):
+            e.add_request(str(i), p, max_tokens=21, sampling_params=params()[i])
+        final, bursts = {}, []
+        step = e.async_step if use_async else e.step
+        for _ in range(1000):
+            for out in step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not e.has_unfinished_requests() and e.num_on_the_fly == 0:
+                break
+        e.shutdown()
+        assert not general_decode_steps, "a decode step with sampled requests fell back to the general path"
+        assert e.worker.graph_pools[0].sampler_graphs, "the sampler graph flavour was never captured"
+        assert e.device_sampler is not None and not e.device_sampler._slot_of  # every slot released at the end
+        return [final[str(i)] for i in range(len(ps))], e
+
+    single, _ = run(1)
+    assert all(len(t) == 21 for t in single)
+    for k in (4, 8):
+        burst, e = run(k)
+        assert burst == single, k
+        assert e.stat_model_steps > 0
+    asyn, _ = run(4, use_async=True, scheduling="async", max_seqs=3)
+    assert asyn == single
+    greedy = run_to_completion(make_engine(graph=True, v2=True), max_tokens=21)
+    for i in (3, 5):  # plain greedy requests inside sampled steps keep their greedy tokens
+        assert single[i] == greedy[i]
+    assert single[0] != greedy[0] and single[1] != greedy[1]
+
+
+def test_sampler_state_is_rebuilt_after_eviction():
+    """More sampled requests alive than state slots: slots of waiting sequences are evicted and rebuilt from the host's
+    histories; tokens equal a run with room for everybody."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    g = torch.Generator().manual_seed(9)
+    reqs = [torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (5, 9, 17, 3, 30, 12, 8, 21, 6, 14)]
+
+    def run(num_slots):
+        e = make_engine(graph=True, max_seqs=3, num_blocks=7)  # 7 blocks: sequences are preempted and wait with a slot
+        from light_vllm_amd.device_sampler import DeviceSampler
+        e.device_sampler = e.worker.sampler = DeviceSampler(e.model_config.vocab_size, DEV, num_slots, seed=0)
+        for i, p in enumerate(reqs):
+            e.add_request(str(i), p, sampling_params=SamplingParams(temperature=0.8, top_p=0.9, seed=i, frequency_penalty=0.3,
+                                                                    max_tokens=10))
+        final = {}
+        while e.has_unfinished_requests():
+            for out in e.step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+        return [final[str(i)] for i in range(len(reqs))], e.device_sampler.evictions
+
+    tight, evicted = run(3)
+    roomy, none = run(64)
+    assert tight == roomy and none == 0
+    print("sampler slots evicted:", evicted)
