@@ -763,7 +763,8 @@ def main():
         pass
     engine.shutdown()
     # BASELINE configs 3, 4, 5 beside the headline (never as `value`): each on its own engine, after this one is gone
-    if rank == 0 and world == 1 and not a.skip_other_configs and not (a.quantization or a.kv_cache_dtype != "auto"):
+    if (rank == 0 and world == 1 and not a.skip_other_configs and a.scheduling == "async"
+            and not (a.quantization or a.kv_cache_dtype != "auto")):
         import gc
         engine.worker.graph_pools = None
         del engine

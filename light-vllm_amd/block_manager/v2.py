@@ -207,7 +207,10 @@ class _Pool:
             return
         assert len(tokens) <= blk.num_empty_slots
         blk.tokens.extend(tokens)
-        blk.num_tokens_total += len(tokens)
+        # recomputed from the predecessor's CURRENT total, as the reference does at every append
+        # (prefix_caching_block.py _update_num_tokens_total): a lookahead block is created while its predecessor is
+        # still filling up, and the evictor breaks last-access ties on this number
+        blk.num_tokens_total = (blk.prev.num_tokens_total if blk.prev is not None else 0) + len(blk.tokens)
         if blk.block_id is not None and self.ref[blk.block_id] > 1:
             src = blk.block_id
             # the hash is not known yet for a block that is being written: hashless release

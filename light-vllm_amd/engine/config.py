@@ -95,6 +95,11 @@ class SchedulerConfig:
         if self.num_lookahead_slots > 0 and not self.use_v2_block_manager:
             raise ValueError("lookahead slots (multi-step decode) need use_v2_block_manager=True: "
                              "BlockSpaceManagerV1 does not support lookahead allocation")
+        if self.num_lookahead_slots > 0 and self.preemption_mode == "swap":
+            # the reference's own swap_out raises on a table that ends in reserved, still empty lookahead blocks
+            # (block/common.py:207 via naive_block.py:335; tests/bm_driver.py): no trace to replay, so no claim
+            raise ValueError("lookahead slots (multi-step decode) with preemption_mode='swap' are not supported: "
+                             "preempted sequences are recomputed")
         if self.max_num_on_the_fly is None:
             self.max_num_on_the_fly = 3 if self.scheduling == "double_buffer" else 2
         if self.max_num_on_the_fly < 1:  # the reference insists on >= 2 (:190-193); one step in flight is

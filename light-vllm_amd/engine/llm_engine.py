@@ -307,9 +307,8 @@ class LLMEngine:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.attn_backend = PagedAttnBackend()
-        if scheduler_config.num_lookahead_slots > 0 and cache_config.enable_prefix_caching:
-            # the reference's v2 prefix-caching allocator under lookahead is not among the replayed traces
-            raise ValueError("multi-step decode (lookahead slots) with prefix caching is not supported")
+        # (multi-step decode over the prefix-caching allocator: the reference's v2 manager under lookahead is replayed
+        # bit for bit -- tests/golden/block_manager_v2_cached_lookahead*.json, scheduler_lookahead_prefix_cache_v2.json)
         # steps in flight run on separate streams (a stream per task, core/executor.py:62-93), so
         # each needs its own graph static buffers
         # ("simple_async": the reference's executor runs the queued steps one after the other,

@@ -402,7 +402,10 @@ def make_scheduler_traces():
             return log
         return finish
 
+    only = os.environ.get("GOLDEN_ONLY")  # e.g. GOLDEN_ONLY=lookahead_prefix: record just the matching programs
     for name, cfg in sched_driver.CONFIGS:
+        if only and only not in name:
+            continue
         hook = recording_hook if cfg["version"] == "v1" else None
         with contextlib.redirect_stdout(io.StringIO()):  # the reference's _schedule_prefills prints its token counts
             trace = sched_driver.run_program(make, adapter, cfg, free_hook=hook)

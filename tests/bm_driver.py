@@ -265,4 +265,10 @@ V2_CONFIGS = [
                                  sliding_window=None, enable_caching=False, no_fork=True, lookahead=3), 16, 500),
     ("v2_naive_lookahead7_fork", dict(version="v2", block_size=16, num_gpu_blocks=96, num_cpu_blocks=0, watermark=0.01,
                                       sliding_window=None, enable_caching=False, lookahead=7), 17, 400),
+    # multi-step decode over the prefix-caching allocator (block_manager_v2.py:199-237 with
+    # PrefixCachingBlockAllocator): lookahead blocks are mutable, content hashes appear as blocks fill up
+    ("v2_cached_lookahead3", dict(version="v2", block_size=8, num_gpu_blocks=64, num_cpu_blocks=0, watermark=0.02,
+                                  sliding_window=None, enable_caching=True, no_fork=True, lookahead=3), 18, 600),
+    ("v2_cached_lookahead7_tight", dict(version="v2", block_size=4, num_gpu_blocks=48, num_cpu_blocks=0, watermark=0.0,
+                                        sliding_window=None, enable_caching=True, no_fork=True, lookahead=7), 19, 600),
 ]

@@ -48,6 +48,10 @@ CONFIGS = [
     ("lookahead_v2", dict(version="v2", block_size=8, num_gpu_blocks=64, num_cpu_blocks=0, max_num_seqs=6,
                           max_num_batched_tokens=128, max_model_len=128, chunked=False, preemption_mode=None,
                           enable_caching=False, n_requests=40, seed=8, lookahead=3)),
+    # multi-step decode over the prefix-caching allocator of the v2 manager (block_manager_v2.py:199-237)
+    ("lookahead_prefix_cache_v2", dict(version="v2", block_size=8, num_gpu_blocks=40, num_cpu_blocks=0, max_num_seqs=6,
+                                       max_num_batched_tokens=128, max_model_len=128, chunked=False, preemption_mode=None,
+                                       enable_caching=True, n_requests=50, seed=10, lookahead=3, max_out=40)),
 ]
 
 

@@ -488,6 +488,35 @@ def test_multi_step_decode_gives_the_tokens_of_single_steps(k):
     assert short == short_ref and len(short[3]) == 30
 
 
+def test_multi_step_decode_with_prefix_caching_gives_the_tokens_of_single_steps():
+    """num_scheduler_steps = 4 over the v2 manager's prefix-caching allocator (block_manager_v2.py:199-237: lookahead
+    blocks are mutable, full blocks are hashed and shared): requests sharing a 48-token prefix, sync and two bursts in
+    flight, tokens identical to single steps with the same cache."""
+    g = torch.Generator().manual_seed(21)
+    shared = torch.randint(0, 512, (48,), generator=g).tolist()
+    reqs = [shared + torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (3, 20, 9, 33, 1, 17)]
+
+    def run(k, use_async=False, **kw):
+        e = make_engine(graph=True, v2=True, prefix_caching=True, num_scheduler_steps=k, **kw)
+        for i, p in enumerate(reqs):
+            e.add_request(str(i), p, max_tokens=19)
+        final = {}
+        step = e.async_step if use_async else e.step
+        for _ in range(2000):
+            for out in step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not e.has_unfinished_requests() and e.num_on_the_fly == 0:
+                break
+        e.shutdown()
+        return [final[str(i)] for i in range(len(reqs))]
+
+    ref = run(1)
+    assert all(len(t) == 19 for t in ref)
+    assert run(4) == ref
+    assert run(4, use_async=True, scheduling="async", max_seqs=3) == ref
+
+
 def test_multi_step_decode_stops_at_eos_inside_a_burst():
     """A sequence that samples EOS in the middle of a burst ends there: what the device generated for it
     afterwards is dropped, every other sequence is unaffected."""
@@ -508,6 +537,8 @@ def test_multi_step_needs_the_v2_block_manager():
     from light_vllm_amd.engine.config import SchedulerConfig
     with pytest.raises(ValueError):
         SchedulerConfig(num_scheduler_steps=4)
+    with pytest.raises(ValueError):  # the reference's swap_out cannot move a table with empty lookahead blocks
+        SchedulerConfig(num_scheduler_steps=4, use_v2_block_manager=True, preemption_mode="swap")
     assert SchedulerConfig(num_scheduler_steps=4, use_v2_block_manager=True).num_lookahead_slots == 3
 
 
