@@ -265,8 +265,10 @@ class PagedAttnImpl:
                  logits_soft_cap: Optional[float] = None, decode_version: Optional[str] = None) -> None:
         if blocksparse_params is not None:
             raise ValueError("PagedAttn (HIP) does not support block-sparse attention.")
-        if logits_soft_cap:
-            raise ValueError("PagedAttn (HIP) decode does not support logits soft cap.")
+        # Soft cap (cap * tanh(logits / cap); the reference's live decode hands it to flash_attn_with_kvcache,
+        # flash_attn.py:554): paged_attention_v1/v2 have no such argument (csrc/ops.h:8-27), so with a cap decode
+        # tokens go through the prefill kernel as chunks of one token (`_decode_as_chunks`), which has it.
+        self.logits_soft_cap = float(logits_soft_cap) if logits_soft_cap else 0.0
         if head_size not in PagedAttention.get_supported_head_sizes():
             raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
                              f"Supported head sizes are: {PagedAttention.get_supported_head_sizes()}.")
@@ -326,7 +328,9 @@ class PagedAttnImpl:
         if prefill_meta := attn_metadata.prefill_metadata:
             self._prefill(query[:npt], key[:npt], value[:npt], key_cache, value_cache, prefill_meta,
                           output[:npt])
-        if decode_meta := attn_metadata.decode_metadata:
+        if (decode_meta := attn_metadata.decode_metadata) and self.logits_soft_cap > 0.0:
+            self._decode_as_chunks(query[npt:], key_cache, value_cache, decode_meta, output[npt:])
+        elif decode_meta:
             dq = query[npt:]
             max_len = decode_meta.max_decode_seq_len
             force = self.decode_version
@@ -346,12 +350,27 @@ class PagedAttnImpl:
     def split_kv_cache(self, kv_cache: torch.Tensor):
         return PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
 
+    def _decode_as_chunks(self, dq: torch.Tensor, key_cache, value_cache, md: PagedAttnMetadata, out: torch.Tensor) -> None:
+        """Decode tokens as chunks of ONE query token over their paged contexts (the prefill kernel: soft cap)."""
+        n = dq.shape[0]
+        qsl = torch.arange(n + 1, dtype=torch.int32, device=dq.device)
+        alibi = self.alibi_slopes
+        if alibi is not None and alibi.device != dq.device:
+            alibi = self.alibi_slopes = alibi.to(dq.device)
+        PagedAttention.forward_prefix(dq, None, None, key_cache, value_cache, md.block_tables, qsl, md.seq_lens_tensor,
+                                      None, 1, alibi, None, scale=self.scale, softcap=self.logits_soft_cap,
+                                      kv_cache_dtype=self.kv_cache_dtype, output=out)
+
     def decode_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                          attn_metadata: PagedAttnMetadata) -> torch.Tensor:
         """Decode attention only (all tokens are decode tokens, K/V already in the cache)."""
         num_tokens, hidden_size = query.shape
         dq = query.view(-1, self.num_heads, self.head_size)
         md = attn_metadata.decode_metadata
+        if self.logits_soft_cap > 0.0:
+            out = torch.empty(dq.shape, dtype=dq.dtype, device=dq.device)
+            self._decode_as_chunks(dq, key_cache, value_cache, md, out)
+            return out.view(num_tokens, hidden_size)
         max_len = md.max_decode_seq_len
         force = self.decode_version
         use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads,
@@ -381,7 +400,7 @@ class PagedAttnImpl:
         # table it is handed.  The v1 manager's circular table (block_manager/v1.py, block_manager_v1.py:279-295)
         # with seq_len clipped to the window puts it at offset (L - 1) % block_size of some OTHER entry once the
         # sequence has outgrown the window: separate launches there (they read everything from the cache).
-        if self.sliding_window is not None:
+        if self.sliding_window is not None or self.logits_soft_cap > 0.0:
             return None
         num_tokens, hidden_size = query.shape
         md = attn_metadata.decode_metadata
@@ -412,7 +431,7 @@ class PagedAttnImpl:
             alibi = self.alibi_slopes = alibi.to(q.device)
         PagedAttention.forward_prefix(q, None, None, key_cache, value_cache, block_tables, query_start_loc,
                                       seq_lens, None, max_query_len, alibi, None, scale=self.scale,
-                                      kv_cache_dtype=self.kv_cache_dtype, output=out)
+                                      softcap=self.logits_soft_cap, kv_cache_dtype=self.kv_cache_dtype, output=out)
         return out.view(num_tokens, hidden_size)
 
     # ---- prompt attention ----
@@ -431,9 +450,12 @@ class PagedAttnImpl:
             PagedAttention.forward_prefix(q, k, v, key_cache, value_cache, meta.block_tables,
                                           meta.query_start_loc, meta.seq_lens_tensor,
                                           meta.context_lens_tensor, meta.max_query_len, alibi,
-                                          self.sliding_window, scale=self.scale,
+                                          self.sliding_window, scale=self.scale, softcap=self.logits_soft_cap,
                                           kv_cache_dtype=self.kv_cache_dtype, output=out)
             return
+        if self.logits_soft_cap > 0.0 and key_cache is not None:
+            raise NotImplementedError("logits_soft_cap needs the HIP prefill kernel (16-bit model dtype, block size 16 / 32, "
+                                      "no sliding window)")
         qs = 0
         G = self.num_queries_per_kv
         for i in range(meta.num_prefills):

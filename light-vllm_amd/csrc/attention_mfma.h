@@ -169,7 +169,7 @@ __device__ __forceinline__ u32x2_t dequant4(uint32_t w, float scale, bool scaled
 // + v_cvt_pk_{bf16,f16}_f32: ~100 vector instructions per tile against ~7 us of HBM time per tile
 // and wave at full bandwidth -- free.
 // ROPE: see AttnParams (rotation of q and the new k, cache write of the new k and v, inside this launch).
-template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8, bool ROPE = false>
+template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8, bool ROPE = false, bool SCALED = false>
 __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
     const AttnParams p) {
   using S = typename T::store_t;
@@ -281,9 +281,14 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       }
       return;
     }
+    // vmcnt retires in issue order and K is needed first, so K is requested first -- pinned: left alone, the
+    // scheduler put the V requests in front, and the wait for K in front of K.Q^T became a wait for everything
+    // (found in the ISA, round 3: -5 % on the fp8 launch, -3 % on the 16-bit one)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = 0; jj < NKL; ++jj)
       k[jj] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff + jj * (4 * BS * 16), off * 16, LVLLM_ATTN_AUX);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NDT; ++t) {
       if constexpr (KV8)
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       else
         v[t] = __builtin_amdgcn_raw_buffer_load_b64(vr, voff + t * (16 * BS * 2), off * 2, LVLLM_ATTN_AUX);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- ROPE: the first K/V tiles are requested before anything else: the block-table read and the HBM round trip
@@ -439,7 +445,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
     }
     __syncthreads();  // the stash is visible to the wave that owns the last tile
   }
-  const bool k_scaled = KV8 && p.k_scale != 1.f, v_scaled = KV8 && p.v_scale != 1.f;
+  // fp8 caches: scales other than 1 take their own instantiation (SCALED).  As a run-time flag the choice became a
+  // branch around EVERY conversion of the unrolled loop -- two arms with an s_waitcnt vmcnt(0) in each, 32 branches
+  // per tile (found in the ISA, round 3: profiles/r03_tuning.md section 1)
+  constexpr bool k_scaled = KV8 && SCALED, v_scaled = KV8 && SCALED;
   const float alibi = (p.alibi_slopes != nullptr && c < nh) ? p.alibi_slopes[head0 + c] : 0.f;
 
   // running softmax state of this wave: column c of lanes (g, c) is head head0 + c
@@ -615,8 +624,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 #ifndef LVLLM_ATTN_NBUF
 #define LVLLM_ATTN_NBUF 2  // measured: 2 sets beat 3 by 13 % at bs32/seq1024 (profiles/r01_tuning.md)
 #endif
-// fp8 caches: a register set is half the size (and half the bytes in flight), so the fp8 instantiations take their
-// own count (profiles/r03_tuning.md section 1)
+// fp8 caches take their own count.  Measured, round 3 (profiles/r03_tuning.md section 1): EVERY added set made the fp8
+// launch slower (2 / 3 / 4 sets: 15.3 / 17.4 / 17.8 us), so did 16 waves per workgroup and two-tile softmax steps with
+// two or three pairs in flight (16.7 / 22.4 us): about 64 KiB in flight per CU cover the HBM latency, more backs up
+// the memory pipeline, and a wave that cannot issue its next request cannot issue the arithmetic behind it either.
 #ifndef LVLLM_ATTN_NBUF_KV8
 #define LVLLM_ATTN_NBUF_KV8 2
 #endif
@@ -638,7 +649,10 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   };
   if constexpr (D % 128 == 0 && BS != 8) {
     if (p.positions != nullptr && p.kv_fp8) {  // fused rotation + quantised cache write (host checked the envelope)
-      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true, true>);
+      if (p.k_scale != 1.f || p.v_scale != 1.f)
+        launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true, true, true>);
+      else
+        launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true, true>);
       return;
     }
   }
@@ -650,43 +664,14 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   }
   if constexpr (D % 16 == 0 && BS != 8) {
     if (p.kv_fp8) {
-      launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true>);
+      if (p.k_scale != 1.f || p.v_scale != 1.f)
+        launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true, false, true>);
+      else
+        launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF_KV8, true>);
       return;
     }
   }
   launch(paged_attn_mfma_kernel<T, D, BS, NWAVES, LVLLM_ATTN_NBUF, false>);
-}
-
-// fp8 caches, 16 waves per workgroup: the fp8 kernel needs under 128 registers with two sets, so four waves fit a
-// SIMD -- twice the loads in flight per CU of the 8-wave launch (tuning value attn_waves_fp8; section 1 of
-// profiles/r03_tuning.md)
-template <typename T, int D, int BS>
-static bool launch_mfma_fp8_16waves(const AttnParams& p, int num_seqs, int num_parts, hipStream_t stream) {
-  if constexpr (D % 16 == 0 && BS != 8 && D <= 128) {
-    constexpr int NW = 16;
-    const int G = p.num_heads / p.num_kv_heads;
-    const int HG = (G + 15) / 16;
-    const int nh_lds = G < 16 ? G : 16;
-    constexpr int DPAD = ((D + 15) / 16) * 16;
-    const size_t smem = (size_t)NW * 16 * 2 * sizeof(float) + (size_t)NW * nh_lds * DPAD * sizeof(float) +
-                        (p.positions != nullptr ? (size_t)2 * D * 2 : 0);
-    if (smem > 160 * 1024) return false;
-    auto launch = [&](auto kern) {
-      if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NW * 64), smem, stream, p);
-    };
-    if (p.positions != nullptr) {
-      if constexpr (D % 128 == 0) {
-        launch(paged_attn_mfma_kernel<T, D, BS, NW, 2, true, true>);
-        return true;
-      }
-      return false;
-    }
-    launch(paged_attn_mfma_kernel<T, D, BS, NW, 2, true>);
-    return true;
-  }
-  return false;
 }
 
 template <typename T, int D, int BS>
@@ -695,9 +680,6 @@ static void launch_mfma_waves(const AttnParams& p, int num_seqs, int num_parts,
   // 16-token tiles per workgroup decide how many waves can be kept busy
   const int tiles = (max_tokens_per_wg + 15) / 16;
   const int G = p.num_heads / p.num_kv_heads;
-  if (p.kv_fp8 && tiles >= 32 && tuning().attn_waves_fp8 == 16 &&
-      launch_mfma_fp8_16waves<T, D, BS>(p, num_seqs, num_parts, stream))
-    return;
   const bool lds8_ok =
       (size_t)8 * (G < 16 ? G : 16) * (((D + 15) / 16) * 16) * 4 + 1024 <= 160 * 1024;
 #ifndef LVLLM_ATTN_NWAVES_LONG

@@ -13,7 +13,6 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_GEMM_CUS_WIDE")) v.gemm_workgroups_wide = atoi(e);
     if (const char* e = getenv("LVLLM_GEMM_WIDE_MIN_TILES")) v.gemm_wide_min_tiles = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
-    if (const char* e = getenv("LVLLM_ATTN_WAVES_FP8")) v.attn_waves_fp8 = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     if (const char* e = getenv("LVLLM_PREFILL_MFMA32_MIN_QUERY")) v.prefill_mfma32_min_query = atoi(e);
@@ -42,9 +41,6 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
-  } else if (k == "attn_waves_fp8") {
-    LV_CHECK(value == 8 || value == 16, "attn_waves_fp8 must be 8 or 16");
-    lvllm::tuning().attn_waves_fp8 = value;
   } else if (k == "attn_splits") {
     LV_CHECK(value >= -1, "attn_splits must be -1 (512-token partitions), 0 (automatic) or a share count");
     lvllm::tuning().attn_splits = value;
@@ -74,7 +70,6 @@ extern "C" int lvllm_get_tuning(const char* key, int* value) {
   else if (k == "gemm_wide_min_tiles") *value = t.gemm_wide_min_tiles;
   else if (k == "gemm_partials_ksplit") *value = t.gemm_partials_ksplit;
   else if (k == "attn_waves") *value = t.attn_waves;
-  else if (k == "attn_waves_fp8") *value = t.attn_waves_fp8;
   else if (k == "attn_splits") *value = t.attn_splits;
   else if (k == "swap_kernel_min_runs") *value = t.swap_kernel_min_runs;
   else if (k == "cache_tile_min_tokens") *value = t.cache_tile_min_tokens;

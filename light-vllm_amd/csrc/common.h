@@ -31,7 +31,6 @@ struct Tuning {
   int gemm_wide_min_tiles = 1024;  // 1024: gate_up and lm_head of an 8B model; 4096: lm_head only
   int gemm_partials_ksplit = 0;  // > 0: a projection that leaves split-K partials splits K at least this many ways
   int attn_waves = 8;
-  int attn_waves_fp8 = 8;  // 16: fp8-cache launches with >= 32 tiles per workgroup run 16 waves (four per SIMD)
   int attn_splits = 0;  // paged_attention_v2: 0 = shares chosen per call; n >= 1 = n shares; -1 = 512-token partitions
   int swap_kernel_min_runs = 3;  // swap_blocks: more contiguous runs than this (and a pinned host side) -> one kernel
   int cache_tile_min_tokens = 384;  // reshape_and_cache: >= this many tokens take the LDS-tiled kernel (consecutive

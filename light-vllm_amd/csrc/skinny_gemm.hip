@@ -376,6 +376,38 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
       load_unit(a1, 0, 1);
 #endif
       char* xs = reinterpret_cast<char*>(stage + (size_t)stage_tiles * MT * 64) + wave * (16 * NCH * 16);
+#ifdef LVLLM_GEMM_FAKE_NORM
+      // Diagnosis build only (tools/diag_fake_norm.py; WRONG results): prices a [add + norm -> projection] fusion.
+      // The SwiGLU projection normalises its own activations in the prologue -- T(T(x * s_row) * w[k]) on every
+      // 16-byte chunk this wave holds, the norm weight read like the real one would be (16 bytes per lane at the
+      // chunk's k) -- with the weight stream already requested, while the add + norm launch in front of it is skipped
+      // by the caller.  What a real fusion would add on top (row statistics from the producer's partial sums) is not
+      // included: the figure is an upper bound of the gain.
+      if (glu) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+              const int r = i * RPI + b, q = pos ^ r;
+              const int ks = h * HALF + (q >> 2), m = mt * 16 + r;
+              const unsigned woff = ks < nvalid ? (unsigned)(((int64_t)(step0 + ks) * 32 + (q & 3) * 8) * 2) : kOutOfRange;
+              const g_u32x4_t wv = __builtin_amdgcn_raw_buffer_load_b128(xr, woff, 0, 0);  // stand-in for the norm weight
+              const float srow = 1.0f + 1e-6f * (float)m;
+              g_u32x4_t v = xf[mt][h * HALF + i];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a0f = T::to_float((S)(v[e] & 0xffffu)), a1f = T::to_float((S)(v[e] >> 16));
+                const float w0f = T::to_float((S)(wv[e] & 0xffffu)), w1f = T::to_float((S)(wv[e] >> 16));
+                const S n0 = T::from_float(a0f * srow), n1 = T::from_float(a1f * srow);
+                const S o0 = T::from_float(T::to_float(n0) * w0f), o1 = T::from_float(T::to_float(n1) * w1f);
+                v[e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+              }
+              xf[mt][h * HALF + i] = v;
+            }
+      }
+#endif
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

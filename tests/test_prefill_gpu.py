@@ -139,6 +139,33 @@ def test_prefill_single_token_chunks_match_decode(ops):
     check_attention(out, dec.cpu(), None, tol=5e-3)
 
 
+def test_decode_with_a_logits_soft_cap_goes_through_one_token_chunks(ops):
+    """PagedAttnImpl(logits_soft_cap=...) (the reference's live decode passes the cap to flash_attn_with_kvcache,
+    flash_attn.py:554; paged_attention_v1/v2 have no such argument): decode tokens run as chunks of one token through
+    the prefill kernel -- forward(), decode_attention() and the refusal of the fused rope + attention launch --
+    against the oracle and fp64 with the cap, and visibly different from the run without it."""
+    from light_vllm_amd.attention.backend import PagedAttnImpl, PagedAttnMetadata
+    lens = [100, 257, 16, 1, 513]
+    inp = make_prefill_inputs(32, 8, 128, 16, lens, [1] * len(lens), dtype=torch.bfloat16, seed=18)
+    inp["query"] = inp["query"] * 4  # logits large enough for the cap to bite
+    cap = 1.5
+    want_o, want_64 = run_oracle(inp, softcap=cap), dense_prefill_fp64(inp, None, 0, cap)
+    d = to_dev(inp)
+    n = len(lens)
+    impl = PagedAttnImpl(32, 128, inp["scale"], 8, None, None, "auto", None, cap)
+    md = PagedAttnMetadata(num_prefills=0, num_prefill_tokens=0, num_decode_tokens=n,
+                           slot_mapping=torch.full((n,), -1, dtype=torch.int64, device=DEV), seq_lens=None,
+                           seq_lens_tensor=d["seq_lens"], max_query_len=1, max_prefill_seq_len=0, max_decode_seq_len=max(lens),
+                           query_start_loc=None, seq_start_loc=None, context_lens_tensor=None, block_tables=d["block_tables"])
+    q2 = d["query"].reshape(n, 32 * 128)
+    got = impl.decode_attention(q2, d["key_cache"], d["value_cache"], md).view(n, 32, 128)
+    torch.cuda.synchronize()
+    check_attention(got.cpu(), want_o, want_64)
+    assert impl.rope_cache_decode_attention(None, q2, None, None, None, d["key_cache"], d["value_cache"], md) is None
+    plain = PagedAttnImpl(32, 128, inp["scale"], 8, None, None, "auto").decode_attention(q2, d["key_cache"], d["value_cache"], md)
+    assert float((plain.view(n, 32, 128).cpu().float() - want_o.float()).abs().max()) > 0.05  # the cap changes the result
+
+
 def test_prefill_strided_query_and_output(ops):
     """query as a view of the fused qkv projection, output into a slice of a wider buffer."""
     H, KVH, D = 8, 2, 128

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv", default="auto", choices=["auto", "fp8"])
+    ap.add_argument("--rope", action="store_true",
+                    help="also time the ROPE instantiation (rotary_embedding + reshape_and_cache + attention in one launch: "
+                         "what a decode step of the engine launches); the new token is the context's last")
     a = ap.parse_args()
     dev = "cuda:0"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
@@ -61,7 +64,25 @@ def main():
         kc, vc, bt = caches[i % a.ncaches]
         ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, KVH, scale, bt, seq_lens, BS, L, None, a.kv, 1.0, 1.0)
 
-    for name, fn in (("v1", v1), ("v2", v2)):
+    legs = [("v1", v1), ("v2", v2)]
+    if a.rope:
+        qkv = (torch.randn(B, (H + 2 * KVH) * D, device=dev) * 0.5).to(dt)
+        qv, kv_, vv = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
+        pos = torch.full((B,), L - 1, dtype=torch.int64, device=dev)
+        inv = 1.0 / (500000.0 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+        fr = torch.einsum("i,j -> ij", torch.arange(L + 8, dtype=torch.float), inv)
+        cos_sin = torch.cat((fr.cos(), fr.sin()), dim=-1).to(dt).to(dev)
+        slots = [(bt[:, (L - 1) // BS].long() * BS + (L - 1) % BS) for _, _, bt in caches]
+        out2 = torch.zeros(B, H, D, dtype=dt, device=dev)
+
+        def rope(i):
+            kc, vc, bt = caches[i % a.ncaches]
+            ok = torch.ops._C_amd.rope_cache_paged_attention(out2, es, ml, tmp, pos, qv, kv_, vv, D, cos_sin, True, kc, vc,
+                                                             slots[i % a.ncaches], KVH, scale, bt, seq_lens, BS, L, a.kv,
+                                                             1.0, 1.0)
+            assert ok
+        legs.append(("v2+rope+cache", rope))
+    for name, fn in legs:
         for i in range(20):
             fn(i)
         torch.cuda.synchronize()
