@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--no-rope-in-attention", action="store_true",
                     help="rope + cache write as their own launch in front of attention (A/B of the fused kernel)")
+    ap.add_argument("--rope-in-attention-fp8", action="store_true",
+                    help="A/B: the fused rope + cache write + attention launch over an fp8 KV cache as well")
     ap.add_argument("--o-proj-partials-min-rows", type=int, default=None,
                     help="A/B: decode steps of at least this many rows split o_proj's K over workgroups (default 33)")
     ap.add_argument("--gemm-partials-ksplit", type=int, default=None,
@@ -655,6 +657,7 @@ def main():
     cfg.pack_weights = not a.library_gemm
     cfg.fuse_decode_ops = not a.no_fusion
     cfg.rope_in_attention = not a.no_rope_in_attention
+    cfg.rope_in_attention_fp8 = a.rope_in_attention_fp8
     if a.o_proj_partials_min_rows is not None:
         cfg.o_proj_partials_min_rows = a.o_proj_partials_min_rows
     cfg.quantization = a.quantization

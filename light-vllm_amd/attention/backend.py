@@ -284,6 +284,8 @@ class PagedAttnImpl:
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
         self.decode_version = decode_version  # None: heuristic; "v1" | "v2": forced
         self.use_hip_prefill = True  # False: torch SDPA per sequence (kept for A/B tests)
+        # rope + cache write + attention in one launch over an fp8 cache too (ModelConfig.rope_in_attention_fp8)
+        self.fuse_rope_over_fp8_cache = False
         self._scratch: Dict[Tuple[int, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
     def make_v2_scratch(self, num_seqs: int, max_seq_len: int, dtype, device):
@@ -394,7 +396,9 @@ class PagedAttnImpl:
         # fp8 caches: the kernel supports them (bit-identical too), but measured SLOWER than the two launches there
         # (13 030 vs 13 300 tokens/s, profiles/r02_tuning.md): the fp8 attention launch is instruction-bound, the
         # prologue and its barrier cost more than the launch they save
-        if self.alibi_slopes is not None or self.decode_version == "v1" or self.kv_cache_dtype != "auto":
+        if self.alibi_slopes is not None or self.decode_version == "v1":
+            return None
+        if self.kv_cache_dtype != "auto" and not self.fuse_rope_over_fp8_cache:
             return None
         # Sliding windows: the fused kernel takes the step's new token for logical position seq_len - 1 of the
         # table it is handed.  The v1 manager's circular table (block_manager/v1.py, block_manager_v1.py:279-295)

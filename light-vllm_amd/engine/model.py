@@ -120,6 +120,8 @@ class DecoderModel:
         self.cos_sin_cache = build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings,
                                                  cfg.rope_theta, cfg.dtype, self.device)
         self.attn = attn_impl  # DecodeOnlyAttentionImpl-like: forward(q, k, v, kv_cache, metadata)
+        if hasattr(attn_impl, "fuse_rope_over_fp8_cache"):
+            attn_impl.fuse_rope_over_fp8_cache = cfg.rope_in_attention_fp8
         self.q_size = cfg.num_attention_heads * cfg.head_dim
         self.kv_size = cfg.num_key_value_heads * cfg.head_dim
         if cfg.quantization is not None:
