@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-fusion", action="store_true", help="reference op sequence (no fused decode launches)")
     ap.add_argument("--no-rope-in-attention", action="store_true",
                     help="rope + cache write as their own launch in front of attention (A/B of the fused kernel)")
+    ap.add_argument("--no-fp8-activations-once", action="store_true",
+                    help="A/B (W8A8): every projection quantises its own activations again (round 2's path)")
     ap.add_argument("--rope-in-attention-fp8", action="store_true",
                     help="A/B: the fused rope + cache write + attention launch over an fp8 KV cache as well")
     ap.add_argument("--o-proj-partials-min-rows", type=int, default=None,
@@ -200,8 +202,19 @@ def gemm_leg(engine, B):
             N, K = ws[0].N, ws[0].K
             x = (torch.randn(B, K, device=dev) * 0.5).to(cfg.dtype)
 
+            once = w8 and cfg.fp8_activations_once and B <= 32 and name != "o"
+            x8 = torch.randint(0, 120, (B, K), device=dev, dtype=torch.uint8) if once else None
+            down_scale = layers[0].down.x_scale
+
             def call(w):
-                if w8:
+                if once and name == "qkv":  # the launches the engine's step makes (activations already fp8)
+                    torch.ops._C_amd.skinny_linear_w8a8_q(x8, w.w8_packed, w.w_scale, w.x_scale, N, K, None, cfg.dtype)
+                elif once and name == "gate_up":
+                    torch.ops._C_amd.skinny_linear_w8a8_q_swiglu_fp8(x8, w.w8_packed, w.w_scale, w.x_scale, N, K, down_scale,
+                                                                     cfg.dtype)
+                elif once:
+                    torch.ops._C_amd.skinny_linear_w8a8_q_partials(x8, w.w8_packed, w.w_scale, w.x_scale, N, K)
+                elif w8:
                     torch.ops._C_amd.skinny_linear_w8a8(x, w.w8_packed, w.w_scale, w.x_scale, N, K, None)
                 else:
                     torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
@@ -216,7 +229,11 @@ def gemm_leg(engine, B):
                 b.record()
             torch.cuda.synchronize(dev)
             t = min(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(ws)
-            by = N * K * (1 if w8 else 2) + B * K * 2 + B * N * 2  # weights once + activations in + result out
+            by = N * K * (1 if w8 else 2) + B * K * (1 if once else 2) + B * N * 2  # weights once + activations in + result out
+            if once and name == "gate_up":
+                by = N * K + B * K + B * (N // 2)          # fp8 in, SwiGLU result out as fp8
+            elif once and name == "down":
+                by = N * K + B * K + 4 * B * N * ((K + 4095) // 4096)  # fp8 in, fp32 split-K slabs out
             per_shape[name] = {"us": round(t * 1e6, 2), "GB/s": round(by / t / 1e9, 1)}
             tot_bytes += by
             tot_s += t
@@ -658,6 +675,7 @@ def main():
     cfg.fuse_decode_ops = not a.no_fusion
     cfg.rope_in_attention = not a.no_rope_in_attention
     cfg.rope_in_attention_fp8 = a.rope_in_attention_fp8
+    cfg.fp8_activations_once = not a.no_fp8_activations_once
     if a.o_proj_partials_min_rows is not None:
         cfg.o_proj_partials_min_rows = a.o_proj_partials_min_rows
     cfg.quantization = a.quantization

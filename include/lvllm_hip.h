@@ -276,6 +276,24 @@ int lvllm_fused_add_rms_norm_splitk_scaled(void* out, void* residual, const floa
                                            int num_partials, const void* weight, float epsilon,
                                            int num_tokens, int hidden_size, int dtype,
                                            const float* x_scale, const float* w_scale, void* stream);
+/* The norm launches of a W8A8 decode step with an fp8 twin of their result: out_fp8 [num_tokens, hidden] bytes =
+ * static_scaled_fp8_quant(normalised row, *q_scale) (csrc/quantization/fp8/common.cu:24-38,171-176) on the value as
+ * rounded to T, bit for bit -- the next projection (lvllm_skinny_gemm_w8a8_q) then takes its activations already
+ * quantised instead of re-quantising them in every workgroup.  16-bit element types, hidden_size % 8 == 0, 16-byte
+ * aligned rows.  lvllm_rms_norm_quant: `out` (the T result) may be NULL.  lvllm_fused_add_rms_norm_quant: residual <-
+ * T(input + residual) as lvllm_fused_add_rms_norm; the normalised rows go to out_fp8 and, when write_normed != 0, to
+ * `input` (otherwise `input` is only read).  lvllm_fused_add_rms_norm_splitk_quant: `out` may be NULL; x_scale /
+ * w_scale as in lvllm_fused_add_rms_norm_splitk_scaled (both NULL: plain partials); out_fp8 / q_scale both NULL = that
+ * entry. */
+int lvllm_rms_norm_quant(void* out, void* out_fp8, const float* q_scale, const void* input, const void* weight,
+                         float epsilon, int num_tokens, int hidden_size, int dtype, void* stream);
+int lvllm_fused_add_rms_norm_quant(void* input, void* residual, const void* weight, float epsilon, int num_tokens,
+                                   int hidden_size, int dtype, void* out_fp8, const float* q_scale, int write_normed,
+                                   void* stream);
+int lvllm_fused_add_rms_norm_splitk_quant(void* out, void* residual, const float* partials, int num_partials,
+                                          const void* weight, float epsilon, int num_tokens, int hidden_size,
+                                          int dtype, const float* x_scale, const float* w_scale, void* out_fp8,
+                                          const float* q_scale, void* stream);
 /* rotary_embedding (rot_dim == head_size) and reshape_and_cache of the rotated key and the
  * value in one launch; returns 3 outside its envelope (use the two separate entry points). */
 int lvllm_rotary_embedding_and_cache(
@@ -428,6 +446,17 @@ int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_packed, cons
                               const float* x_scale, const float* w_scale, int M, int N, int K,
                               int64_t ldx, int dtype, int act, void* workspace,
                               int64_t workspace_bytes, void* stream);
+
+/* W8A8 with activations that arrive ALREADY quantised: x_fp8 [M <= 32, K] bytes, rows ldx BYTES apart, =
+ * static_scaled_fp8_quant(x, *x_scale) as written by the *_quant norm entries above or by this entry's SwiGLU epilogue.
+ * Results are bit-identical to lvllm_skinny_gemm_w8a8_ex on the unquantised x (same quantisation arithmetic, same
+ * MFMA order).  act 0 | 2 (SwiGLU: y [M, N/2]; y_fp8 != NULL: the activation also -- or, with y == NULL, only --
+ * leaves as fp8 [M, N/2] quantised with *y_fp8_scale, for a following call of this entry) | 4 (raw split-K partials
+ * in `workspace`, as lvllm_skinny_gemm_w8a8_ex).  `dtype` = element type of y and bias.  3 = outside the envelope. */
+int lvllm_skinny_gemm_w8a8_q(void* y, void* y_fp8, const float* y_fp8_scale, const void* x_fp8,
+                             const void* w_packed, const void* bias, const float* x_scale, const float* w_scale,
+                             int M, int N, int K, int64_t ldx, int dtype, int act, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);

@@ -11,6 +11,8 @@
 // copy_blocks takes device pointer tables so it never synchronises the host.
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace lvllm {
@@ -337,6 +339,9 @@ extern "C" int lvllm_reshape_and_cache(
     const int cph = head_size / 8;
     const size_t smem = kTileTokens * 8 + kTileTokens * 4 + 16 + (size_t)cph * (kTileTokens + 1) * 16 +
                         (size_t)head_size * (kTileTokens + 2) * 2;
+    if (smem > 64 * 1024)  // head size 256: 67.8 KB of LDS -- say so, as the attention and prefill launches do
+      (void)hipFuncSetAttribute((const void*)reshape_and_cache_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
     hipLaunchKernelGGL(reshape_and_cache_tile_kernel, dim3((num_tokens + kTileTokens - 1) / kTileTokens, num_heads),
                        dim3(256), smem, s, (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
                        (uint16_t*)value_cache, slot_mapping, num_tokens, num_heads, head_size, block_size,
@@ -441,19 +446,32 @@ struct SwapRing {
   bool used[kSlots] = {};
   int next = 0;
   bool ok = false, tried = false;
-  bool init() {
+  std::mutex mu;  // ONE ring per process (8 MiB of pinned memory, 128 events), whichever threads swap
+  void release() {
+    for (int i = 0; i < kSlots; ++i) {
+      if (done[i] != nullptr) (void)hipEventDestroy(done[i]);
+      if (host[i] != nullptr) (void)hipHostFree(host[i]);
+      done[i] = nullptr;
+      host[i] = dev[i] = nullptr;
+    }
+  }
+  bool init() {  // (called with `mu` held)
     if (tried) return ok;
     tried = true;
     for (int i = 0; i < kSlots; ++i) {
-      if (hipHostMalloc((void**)&host[i], (size_t)kMaxPairs * 16, hipHostMallocMapped) != hipSuccess) return false;
-      if (hipHostGetDevicePointer((void**)&dev[i], host[i], 0) != hipSuccess) return false;
-      if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return false;
+      if (hipHostMalloc((void**)&host[i], (size_t)kMaxPairs * 16, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer((void**)&dev[i], host[i], 0) != hipSuccess ||
+          hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        release();  // a partial ring is given back: the DMA path serves every call from now on
+        return false;
+      }
     }
     ok = true;
     return true;
   }
 };
-static thread_local SwapRing g_swap_ring;
+static SwapRing g_swap_ring;
 
 // device-visible address of a host buffer, or nullptr when it is not pinned / mapped
 static void* mapped_host_pointer(const void* p) {
@@ -495,6 +513,7 @@ extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* bloc
     const void* ks = src_is_device ? src : mapped_host_pointer(src);
     void* kd = dst_is_device ? dst : mapped_host_pointer(dst);
     SwapRing& ring = g_swap_ring;
+    std::unique_lock<std::mutex> lock(ring.mu);
     if (ks != nullptr && kd != nullptr && ring.init()) {
       const int slot = ring.next;
       ring.next = (ring.next + 1) % SwapRing::kSlots;
@@ -508,6 +527,7 @@ extern "C" int lvllm_swap_blocks(const void* src, void* dst, const int64_t* bloc
       ring.used[slot] = true;
       return 0;
     }
+    lock.unlock();
   }
   int i = 0;
   while (i < num_pairs) {

@@ -77,7 +77,13 @@ struct F16 {
   __device__ static inline float to_float(store_t v) {
     return (float)__builtin_bit_cast(_Float16, v);
   }
+  // The rounding point is pinned: the fp32 value is materialised (empty asm) and THEN converted.  Left to
+  // instruction selection, `(_Float16)(a * b)` may become one v_fma_mixlo_f16 in one kernel and v_mul_f32 +
+  // v_cvt_f16_f32 in another -- which instruction sequence a kernel got changed with unrelated edits, and two kernels
+  // that must agree bit for bit (fused_add_rms_norm vs its split-K twin, round 3) stopped agreeing on a few elements.
+  // The reference's kernels round the fp32 result to half (`__float2half(x * s)`): two roundings, as here.
   __device__ static inline store_t from_float(float f) {
+    asm("" : "+v"(f));
     return __builtin_bit_cast(uint16_t, (_Float16)f);
   }
 };
@@ -110,6 +116,17 @@ __device__ inline uint32_t fp8_kv_quant4(float a, float b, float c, float d, flo
   if (sc != sc) w = (w & 0xff00ffffu) | 0x007f0000u;
   if (sd != sd) w = (w & 0x00ffffffu) | 0x7f000000u;
   return w;
+}
+
+// 4 activations -> 4 fp8 (OCP e4m3fn) in one dword with the arithmetic of static_scaled_fp8_quant
+// (csrc/quantization/fp8/common.cu:24-38,171-176): e4m3(clamp(x * inv_scale, +-448)), inv_scale = 1.0f / scale, the
+// clamp as fmax(-448, fmin(x, 448)) (a NaN comes out as +448).  ONE definition for every place that quantises an
+// activation -- the quant op, the W8A8 GEMM's own prologue, and the producers that hand the next GEMM its input
+// already quantised (norm kernels, the SwiGLU epilogue) -- so that all of them produce the same bytes.
+__device__ __forceinline__ uint32_t fp8_act_quant4(float a, float b, float c, float d, float inv_scale) {
+  auto prep = [inv_scale](float v) { return fmaxf(-448.f, fminf(v * inv_scale, 448.f)); };
+  const uint32_t w = __builtin_amdgcn_cvt_pk_fp8_f32(prep(a), prep(b), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(prep(c), prep(d), w, true);
 }
 
 // 16-byte vector of storage elements

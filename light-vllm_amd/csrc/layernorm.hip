@@ -15,12 +15,17 @@ namespace lvllm {
 
 constexpr int kMaxCached = 4;  // 16-byte chunks a thread keeps in registers
 
+// out8 / q_scale (both or none): the normalised row ALSO leaves as fp8 -- e4m3(clamp(out * (1 / *q_scale))) on the
+// value rounded to T, i.e. exactly what static_scaled_fp8_quant(out) would produce -- for a W8A8 projection that
+// takes its activations already quantised (lvllm_skinny_gemm_w8a8_q); `out` itself may then be null (FUSED_ADD:
+// `in` is only read).
 template <typename T, bool FUSED_ADD>
 __global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUSED_ADD (no restrict)
                                     typename T::store_t* __restrict__ res,  // residual (FUSED_ADD)
                                     const typename T::store_t* in,
                                     const typename T::store_t* __restrict__ weight,
-                                    const float epsilon, const int hidden_size) {
+                                    const float epsilon, const int hidden_size,
+                                    uint8_t* __restrict__ out8 = nullptr, const float* __restrict__ q_scale = nullptr) {
   LVLLM_TRACE_BEGIN();
   using V = Vec16<T>;
   constexpr int N = V::N;
@@ -77,7 +82,19 @@ __global__ void rms_norm_vec_kernel(typename T::store_t* out,  // == in when FUS
       const typename T::store_t t = T::from_float(T::to_float(x.v[j]) * s);
       o.v[j] = T::from_float(T::to_float(t) * T::to_float(w.v[j]));
     }
-    out_v[i] = o;
+    if (out != nullptr) out_v[i] = o;
+    if (out8 != nullptr) {
+      static_assert(N == 8 || N == 4, "16-byte vectors of 2- or 4-byte elements");
+      const float inv = 1.0f / q_scale[0];
+      uint8_t* dst = out8 + (int64_t)blockIdx.x * hidden_size + (int64_t)i * N;
+      const uint32_t lo = fp8_act_quant4(T::to_float(o.v[0]), T::to_float(o.v[1]), T::to_float(o.v[2]), T::to_float(o.v[3]), inv);
+      if constexpr (N == 8) {
+        const uint32_t hi = fp8_act_quant4(T::to_float(o.v[4]), T::to_float(o.v[5]), T::to_float(o.v[6]), T::to_float(o.v[7]), inv);
+        *reinterpret_cast<uint2*>(dst) = uint2{lo, hi};
+      } else {
+        *reinterpret_cast<uint32_t*>(dst) = lo;
+      }
+    }
   }
   LVLLM_TRACE_END(3);
 }
@@ -93,7 +110,9 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
                                                  const typename T::store_t* __restrict__ weight,
                                                  const float epsilon, const int hidden_size,
                                                  const float* __restrict__ scale_a = nullptr,
-                                                 const float* __restrict__ scale_b = nullptr) {
+                                                 const float* __restrict__ scale_b = nullptr,
+                                                 uint8_t* __restrict__ out8 = nullptr,  // see rms_norm_vec_kernel
+                                                 const float* __restrict__ q_scale = nullptr) {
   LVLLM_TRACE_BEGIN();
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
@@ -159,7 +178,13 @@ __global__ void fused_add_rms_norm_splitk_kernel(typename T::store_t* out,  // [
       const typename T::store_t t = T::from_float(T::to_float(x.v[j]) * s);
       o.v[j] = T::from_float(T::to_float(t) * T::to_float(w.v[j]));
     }
-    out_v[i] = o;
+    if (out != nullptr) out_v[i] = o;
+    if (out8 != nullptr) {
+      const float inv = 1.0f / q_scale[0];
+      const uint32_t lo = fp8_act_quant4(T::to_float(o.v[0]), T::to_float(o.v[1]), T::to_float(o.v[2]), T::to_float(o.v[3]), inv);
+      const uint32_t hi = fp8_act_quant4(T::to_float(o.v[4]), T::to_float(o.v[5]), T::to_float(o.v[6]), T::to_float(o.v[7]), inv);
+      *reinterpret_cast<uint2*>(out8 + (int64_t)blockIdx.x * hidden_size + (int64_t)i * N) = uint2{lo, hi};
+    }
   }
   LVLLM_TRACE_END(4);
 }
@@ -328,7 +353,8 @@ __global__ void add_layer_norm_wave_kernel(typename T::store_t* out, const typen
 
 template <typename T, bool FUSED_ADD>
 static int launch_rms(void* out, void* res, const void* in, const void* weight, float eps,
-                      int num_tokens, int hidden_size, hipStream_t stream) {
+                      int num_tokens, int hidden_size, hipStream_t stream, uint8_t* out8 = nullptr,
+                      const float* q_scale = nullptr) {
   using S = typename T::store_t;
   constexpr int N = Vec16<T>::N;
   const bool vec_ok = hidden_size % N == 0 && (((uintptr_t)out | (uintptr_t)res | (uintptr_t)in |
@@ -338,8 +364,12 @@ static int launch_rms(void* out, void* res, const void* in, const void* weight, 
     int threads = ((nvec + 63) / 64) * 64;
     threads = threads > 1024 ? 1024 : threads;
     hipLaunchKernelGGL((rms_norm_vec_kernel<T, FUSED_ADD>), dim3(num_tokens), dim3(threads), 0,
-                       stream, (S*)out, (S*)res, (const S*)in, (const S*)weight, eps, hidden_size);
+                       stream, (S*)out, (S*)res, (const S*)in, (const S*)weight, eps, hidden_size, out8, q_scale);
   } else {
+    if (out8 != nullptr) {
+      set_error("rms_norm with an fp8 twin: 16-byte aligned rows of a multiple of 8 elements only");
+      return 1;
+    }
     int threads = ((hidden_size + 63) / 64) * 64;
     threads = threads > 1024 ? 1024 : threads;
     hipLaunchKernelGGL((rms_norm_scalar_kernel<T, FUSED_ADD>), dim3(num_tokens), dim3(threads), 0,
@@ -375,6 +405,39 @@ extern "C" int lvllm_fused_add_rms_norm(void* input, void* residual, const void*
   return 0;
 }
 
+// rms_norm / fused_add_rms_norm whose result ALSO (or only: out / write_normed) leaves as fp8 for the next W8A8
+// projection: out_fp8 [num_tokens, hidden] = static_scaled_fp8_quant(normalised row, *q_scale), bit for bit.
+extern "C" int lvllm_rms_norm_quant(void* out, void* out_fp8, const float* q_scale, const void* input, const void* weight,
+                                    float epsilon, int num_tokens, int hidden_size, int dtype, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(out_fp8 != nullptr && q_scale != nullptr, "out_fp8 and q_scale are required");
+  LV_CHECK((dtype == LVLLM_BF16 || dtype == LVLLM_F16) && hidden_size > 0 && hidden_size % 8 == 0 &&
+               (((uintptr_t)out_fp8) & 7) == 0, "16-bit rows of a multiple of 8 elements");
+  int rc = 0;
+  LV_DISPATCH_DTYPE(dtype, (rc = launch_rms<scalar_t, false>(out, nullptr, input, weight, epsilon, num_tokens, hidden_size,
+                                                             (hipStream_t)stream, (uint8_t*)out_fp8, q_scale)));
+  if (rc) return rc;
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+// residual <- T(input + residual); normalised row -> out_fp8 (and -> input when write_normed != 0)
+extern "C" int lvllm_fused_add_rms_norm_quant(void* input, void* residual, const void* weight, float epsilon,
+                                              int num_tokens, int hidden_size, int dtype, void* out_fp8,
+                                              const float* q_scale, int write_normed, void* stream) {
+  if (num_tokens == 0) return 0;
+  LV_CHECK(out_fp8 != nullptr && q_scale != nullptr, "out_fp8 and q_scale are required");
+  LV_CHECK((dtype == LVLLM_BF16 || dtype == LVLLM_F16) && hidden_size > 0 && hidden_size % 8 == 0 &&
+               (((uintptr_t)out_fp8) & 7) == 0, "16-bit rows of a multiple of 8 elements");
+  int rc = 0;
+  LV_DISPATCH_DTYPE(dtype, (rc = launch_rms<scalar_t, true>(write_normed ? input : nullptr, residual, input, weight, epsilon,
+                                                            num_tokens, hidden_size, (hipStream_t)stream,
+                                                            (uint8_t*)out_fp8, q_scale)));
+  if (rc) return rc;
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
 // out = norm(T(sum_s partials[s]) + residual) * weight, residual updated in place; partials fp32
 // [num_partials, num_tokens, hidden_size].  16-bit element types, hidden_size % 8 == 0.
 extern "C" int lvllm_fused_add_rms_norm_splitk(void* out, void* residual, const float* partials,
@@ -389,7 +452,20 @@ extern "C" int lvllm_fused_add_rms_norm_splitk_scaled(void* out, void* residual,
                                                       int num_partials, const void* weight, float epsilon,
                                                       int num_tokens, int hidden_size, int dtype,
                                                       const float* x_scale, const float* w_scale, void* stream) {
+  return lvllm_fused_add_rms_norm_splitk_quant(out, residual, partials, num_partials, weight, epsilon, num_tokens,
+                                               hidden_size, dtype, x_scale, w_scale, nullptr, nullptr, stream);
+}
+
+// ... whose normalised rows also (out != null) or only (out == null) leave as fp8 (see lvllm_rms_norm_quant)
+extern "C" int lvllm_fused_add_rms_norm_splitk_quant(void* out, void* residual, const float* partials,
+                                                     int num_partials, const void* weight, float epsilon,
+                                                     int num_tokens, int hidden_size, int dtype,
+                                                     const float* x_scale, const float* w_scale, void* out_fp8,
+                                                     const float* q_scale, void* stream) {
   if (num_tokens == 0) return 0;
+  LV_CHECK((out_fp8 == nullptr) == (q_scale == nullptr), "out_fp8 and q_scale: both or none");
+  LV_CHECK(out != nullptr || out_fp8 != nullptr, "nowhere to write the normalised rows");
+  LV_CHECK((((uintptr_t)out_fp8) & 7) == 0, "out_fp8 must be 8-byte aligned");
   LV_CHECK((x_scale == nullptr) == (w_scale == nullptr), "x_scale and w_scale: both or none");
   LV_CHECK(dtype == LVLLM_BF16 || dtype == LVLLM_F16, "16-bit element types only");
   LV_CHECK(hidden_size % 8 == 0 && num_partials >= 1, "hidden_size must be a multiple of 8");
@@ -402,11 +478,11 @@ extern "C" int lvllm_fused_add_rms_norm_splitk_scaled(void* out, void* residual,
   if (dtype == LVLLM_BF16)
     hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<BF16>), dim3(num_tokens), dim3(threads), 0,
                        (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
-                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale);
+                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale, (uint8_t*)out_fp8, q_scale);
   else
     hipLaunchKernelGGL((fused_add_rms_norm_splitk_kernel<F16>), dim3(num_tokens), dim3(threads), 0,
                        (hipStream_t)stream, (uint16_t*)out, (uint16_t*)residual, partials, num_partials, stride,
-                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale);
+                       (const uint16_t*)weight, epsilon, hidden_size, x_scale, w_scale, (uint8_t*)out_fp8, q_scale);
   LV_LAUNCH_CHECK();
   return 0;
 }

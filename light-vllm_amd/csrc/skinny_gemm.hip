@@ -86,15 +86,23 @@ constexpr unsigned kOutOfRange = 0xfffffff0u;  // >= any descriptor size: load r
 // the fragments are built, with the arithmetic of static_scaled_fp8_quant (fp8_quant.hip):
 // fp8(clamp(x * (1 / *x_scale))).  The result is T(acc * (*x_scale * *w_scale) + bias): what
 // torch._scaled_mm(fp8(x), fp8(w), scale_a, scale_b) computes (w8a8_utils.py:147-156).
-template <typename T, int MT, int KSTEPS, bool PACKED, int NT, bool W8>
+// XQ (W8 only): X arrives ALREADY quantised -- fp8 [M, K] bytes, rows ldx bytes apart, written by the producer (a norm
+// kernel's fp8 twin, the SwiGLU epilogue below) with the same arithmetic this kernel's own prologue uses.  The
+// prologue then only moves bytes (row order -> LDS transpose -> fragments): every one of the 128-256 workgroups of a
+// W8A8 launch used to re-quantise all of X (1 280 vector instructions per wave at K = 4 096: 13 us for a projection
+// whose 25 MB of weights stream in 5), profiles/r03_tuning.md section 5.
+// y8 / y8_scale (SwiGLU epilogue): the activation leaves as fp8 for the down projection (and as T when y != null).
+template <typename T, int MT, int KSTEPS, bool PACKED, int NT, bool W8, bool XQ = false>
 __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
     typename T::store_t* __restrict__ y,   // [M, N]            (ksplit == 1)
     float* __restrict__ partial,           // [ksplit, M, N]    (ksplit > 1)
     const typename T::store_t* __restrict__ x, const typename T::store_t* __restrict__ w,
     const typename T::store_t* __restrict__ bias, const int M, const int N, const int K,
     const int64_t ldx, const int steps_per_wave, const int ntiles, const int act, const int stage_tiles,
-    const float* __restrict__ x_scale, const float* __restrict__ w_scale) {
+    const float* __restrict__ x_scale, const float* __restrict__ w_scale, uint8_t* __restrict__ y8 = nullptr,
+    const float* __restrict__ y8_scale = nullptr) {
   using S = typename T::store_t;
+  static_assert(!XQ || (W8 && KSTEPS == 8 && MT <= 2), "pre-quantised activations: the W8A8 variants of <= 32 rows");
   LVLLM_TRACE_BEGIN();
   GEMM_TRACE(0);
   const float out_scale = W8 ? x_scale[0] * w_scale[0] : 1.f;
@@ -225,10 +233,15 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         const S a = T::from_float(gf / (1.0f + expf(-gf)));
         o[r] = T::from_float(T::to_float(a) * T::to_float(T::from_float(us[r])));
       }
-      uint2 ov;
-      ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-      ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-      *reinterpret_cast<uint2*>(y + (int64_t)m * half_n + n0) = ov;
+      if (y != nullptr) {
+        uint2 ov;
+        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2*>(y + (int64_t)m * half_n + n0) = ov;
+      }
+      if (y8 != nullptr)  // static_scaled_fp8_quant of the activation as rounded to T
+        *reinterpret_cast<uint32_t*>(y8 + (int64_t)m * half_n + n0) =
+            fp8_act_quant4(T::to_float(o[0]), T::to_float(o[1]), T::to_float(o[2]), T::to_float(o[3]), 1.0f / y8_scale[0]);
     }
   };
 
@@ -422,7 +435,39 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
         }
     }
   }
-  if constexpr (W8 && MT * KSTEPS < 32) {
+  if constexpr (XQ) {
+    // fp8 activations: a pass is 16 rows x this wave's 8 k-steps = 512 bytes per row; 64 lanes x 16 bytes cover two
+    // rows per load, all 8 MT loads in flight at once, then through the wave-private scratch (chunk q of row r at
+    // position q ^ r) into fragment order: lane (g, c) reads chunk 4 s + g of row c = k-step s, k 16 g .. 16 g + 15
+    staged = true;
+    const uint8_t* x8 = reinterpret_cast<const uint8_t*>(x);
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)x8, 0, (int)((int64_t)(M - 1) * ldx + 2 * (int64_t)K), 0x00020000);
+    const int b = lane >> 5, pos = lane & 31;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 2 * i + b, q = pos ^ r;
+        const int ks = q >> 2, m = mt * 16 + r;
+        const unsigned off = (m < M && ks < nvalid)
+                                 ? (unsigned)((int64_t)m * ldx + (int64_t)(step0 + ks) * 64 + (q & 3) * 16)
+                                 : kOutOfRange;
+        xf[mt][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      }
+    load_unit(a0, 0, 0);  // the first weights follow the activations into the queue
+    load_unit(a1, 0, 1);
+    char* xs = reinterpret_cast<char*>(stage + (size_t)stage_tiles * MT * 64) + wave * (16 * 512);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<g_u32x4_t*>(xs + i * 1024 + lane * 16) = xf[mt][i];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        xf[mt][s2] = *reinterpret_cast<const g_u32x4_t*>(xs + c * 512 + (((4 * s2 + g) ^ c) * 16));
+    }
+  }
+  if constexpr (W8 && !XQ && MT * KSTEPS < 32) {
     // The same for W8A8 (variants whose fragments leave 64 registers for two landing sets; the
     // others -- K beyond 4096, more than 32 rows -- keep the fragment-order loads below): X arrives in T, 16 consecutive k (32 bytes) of a row per lane and k-step.
     // A pass is 16 rows x 4 k-steps (512 bytes per row: the geometry of the 16-bit path above), two
@@ -761,11 +806,11 @@ __global__ void skinny_gemm_reduce_argmax_kernel(float* __restrict__ cand, const
   }
 }
 
-template <typename T, int MT, int KSTEPS, bool W8 = false>
+template <typename T, int MT, int KSTEPS, bool W8 = false, bool XQ = false>
 static void launch_skinny(void* y, float* partial, const void* x, const void* w, const void* bias, int M,
                           int N, int K, int64_t ldx, int steps_per_wave, int ntiles, int groups, int ksplit,
                           bool packed, int act, hipStream_t stream, const float* x_scale = nullptr,
-                          const float* w_scale = nullptr) {
+                          const float* w_scale = nullptr, uint8_t* y8 = nullptr, const float* y8_scale = nullptr) {
   using S = typename T::store_t;
   constexpr int NT = LVLLM_GEMM_NT / MT > 0 ? LVLLM_GEMM_NT / MT : 1;  // NT * MT slabs per meeting
   const size_t red_bytes = (size_t)2 * kGemmWaves * NT * MT * 64 * sizeof(g_f32x4_t);
@@ -786,9 +831,11 @@ static void launch_skinny(void* y, float* partial, const void* x, const void* w,
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, stream, (S*)y, partial,
                        (const S*)x, (const S*)w, (const S*)bias, M, N, K, ldx, steps_per_wave, ntiles, act,
-                       stage_tiles, x_scale, w_scale);
+                       stage_tiles, x_scale, w_scale, y8, y8_scale);
   };
-  if constexpr (W8) {
+  if constexpr (W8 && XQ) {
+    go(skinny_gemm_kernel<T, MT, KSTEPS, true, NT, true, true>);
+  } else if constexpr (W8) {
     go(skinny_gemm_kernel<T, MT, KSTEPS, true, NT, true>);  // fp8 weights are always packed
   } else {
     if (packed) go(skinny_gemm_kernel<T, MT, KSTEPS, true, NT, false>);
@@ -1280,6 +1327,82 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
     LV_LAUNCH_CHECK();
     return 0;
   }
+  if (ksplit > 1 && !leave_partials) {
+    const int64_t MN = (int64_t)M * N;
+    const int grid = (int)((MN / 4 + 255) / 256);
+    if (dtype == LVLLM_BF16)
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<BF16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit, x_scale, w_scale);
+    else
+      hipLaunchKernelGGL((skinny_gemm_reduce_kernel<F16>), dim3(grid), dim3(256), 0, s, (uint16_t*)y, partial,
+                         (const uint16_t*)bias, MN, N, ksplit, x_scale, w_scale);
+    LV_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// W8A8 with activations that arrive already quantised: x_fp8 [M, K] bytes (rows ldx BYTES apart), written by
+// lvllm_rms_norm_quant / lvllm_fused_add_rms_norm_quant / lvllm_fused_add_rms_norm_splitk_quant or by this entry's own
+// SwiGLU epilogue -- i.e. static_scaled_fp8_quant(x, *x_scale), which is what lvllm_skinny_gemm_w8a8_ex computes in its
+// prologue: results are bit-identical to that entry's on the unquantised x.  act 0 / 2 (SwiGLU, y [M, N/2]) / 4 (raw
+// split-K partials left in `workspace`).  act = 2 may also (y_fp8 != null) or only (y == null) write the activation as
+// fp8 with *y_fp8_scale, for a following lvllm_skinny_gemm_w8a8_q.  M <= 32, K within 8 k-steps of 64 per wave (K <=
+// 4096 per workgroup; longer K is split over workgroups as in lvllm_skinny_gemm_w8a8_ex).  3 = outside the envelope.
+extern "C" int lvllm_skinny_gemm_w8a8_q(void* y, void* y_fp8, const float* y_fp8_scale, const void* x_fp8,
+                                        const void* w_packed, const void* bias, const float* x_scale,
+                                        const float* w_scale, int M, int N, int K, int64_t ldx, int dtype, int act,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  LV_CHECK(act == 0 || act == 2 || act == 4, "lvllm_skinny_gemm_w8a8_q: act must be 0, 2 or 4");
+  const bool leave_partials = act == 4;
+  if (leave_partials) act = 0;
+  LV_CHECK(x_scale != nullptr && w_scale != nullptr, "scales are device pointers to one float each");
+  LV_CHECK((y_fp8 == nullptr) == (y_fp8_scale == nullptr), "y_fp8 and y_fp8_scale: both or none");
+  LV_CHECK(y_fp8 == nullptr || act == 2, "the fp8 output belongs to the SwiGLU epilogue (act = 2)");
+  LV_CHECK(y != nullptr || y_fp8 != nullptr || leave_partials, "nowhere to write the result");
+  if (!(dtype == LVLLM_BF16 || dtype == LVLLM_F16) || M > 32 || (K % 64) != 0 || (N % 16) != 0 ||
+      (int64_t)N * K >= ((int64_t)1 << 32) - 16 || (ldx % 16) != 0 || (int64_t)(M - 1) * ldx + K >= ((int64_t)1 << 31) ||
+      ((((uintptr_t)x_fp8 | (uintptr_t)w_packed | (uintptr_t)y) & 15) != 0) || (((uintptr_t)y_fp8) & 3) != 0) {
+    set_error("lvllm_skinny_gemm_w8a8_q: shape outside the kernel's envelope");
+    return 3;
+  }
+  const int K2 = K / 2;
+  const int total_steps = K2 / 32;
+  const int cap = kGemmWaves * 8;
+  const int ksplit = (total_steps + cap - 1) / cap;
+  const int steps_per_wg = (total_steps + ksplit - 1) / ksplit;
+  const int steps_per_wave = (steps_per_wg + kGemmWaves - 1) / kGemmWaves;
+  const int ntiles = N / 16;
+  int groups = ((ntiles >= tuning().gemm_wide_min_tiles && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
+                                                                      : tuning().gemm_workgroups) / ksplit;
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  if (act == 2) {
+    LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
+    if (groups > ntiles / 2) groups = ntiles / 2;
+  }
+  LV_CHECK(!leave_partials || (ksplit > 1 && bias == nullptr),
+           "act = 4 needs K split over workgroups (lvllm_skinny_gemm_w8a8_workspace_bytes > 0) and no bias");
+  float* partial = nullptr;
+  if (ksplit > 1) {
+    LV_CHECK(workspace != nullptr && workspace_bytes >= (int64_t)ksplit * M * N * 4,
+             "workspace too small (see lvllm_skinny_gemm_w8a8_workspace_bytes)");
+    partial = (float*)workspace;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int MT = (M + 15) / 16;
+#define LV_SGQ(T_)                                                                                                   \
+  do {                                                                                                               \
+    if (MT == 1)                                                                                                     \
+      launch_skinny<T_, 1, 8, true, true>(y, partial, x_fp8, w_packed, bias, M, N, K2, ldx, steps_per_wave, ntiles,  \
+                                          groups, ksplit, true, act, s, x_scale, w_scale, (uint8_t*)y_fp8, y_fp8_scale); \
+    else                                                                                                             \
+      launch_skinny<T_, 2, 8, true, true>(y, partial, x_fp8, w_packed, bias, M, N, K2, ldx, steps_per_wave, ntiles,  \
+                                          groups, ksplit, true, act, s, x_scale, w_scale, (uint8_t*)y_fp8, y_fp8_scale); \
+  } while (0)
+  if (dtype == LVLLM_BF16) LV_SGQ(BF16); else LV_SGQ(F16);
+#undef LV_SGQ
+  LV_LAUNCH_CHECK();
   if (ksplit > 1 && !leave_partials) {
     const int64_t MN = (int64_t)M * N;
     const int grid = (int)((MN / 4 + 255) / 256);

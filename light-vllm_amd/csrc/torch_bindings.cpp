@@ -820,6 +820,134 @@ torch::Tensor skinny_linear_w8a8_swiglu(const torch::Tensor& x, const torch::Ten
   return y;
 }
 
+// ---- the W8A8 decode step with activations quantised ONCE, by their producer (include/lvllm_hip.h: *_quant entries,
+// lvllm_skinny_gemm_w8a8_q): every op below is bit-identical to the op it stands for followed by / preceded by
+// static_scaled_fp8_quant
+static void check_q_scale(const torch::Tensor& s, const char* op) {
+  TORCH_CHECK(s.is_cuda() && s.scalar_type() == at::kFloat && s.numel() == 1, op, ": one float32 scale on the device");
+}
+
+// x_fp8 [T, hidden] uint8 = quant(rms_norm(input) * weight)
+torch::Tensor rms_norm_fp8(const torch::Tensor& input, const torch::Tensor& weight, double epsilon,
+                           const torch::Tensor& q_scale) {
+  LV_CHECK_DEVICE(input);
+  check_q_scale(q_scale, "rms_norm_fp8");
+  TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && weight.is_contiguous() && weight.numel() == input.size(1));
+  auto out8 = torch::empty(input.sizes(), input.options().dtype(torch::kUInt8));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input));
+  check(lvllm_rms_norm_quant(nullptr, out8.data_ptr(), q_scale.data_ptr<float>(), input.data_ptr(), weight.data_ptr(),
+                             (float)epsilon, (int)input.size(0), (int)input.size(1), dtype_code(input, "rms_norm_fp8"),
+                             current_stream(input)));
+  return out8;
+}
+
+// residual <- input + residual; x_fp8 = quant(norm(residual) * weight); `input` is only read
+torch::Tensor fused_add_rms_norm_fp8(const torch::Tensor& input, torch::Tensor& residual, const torch::Tensor& weight,
+                                     double epsilon, const torch::Tensor& q_scale) {
+  LV_CHECK_DEVICE(input);
+  check_q_scale(q_scale, "fused_add_rms_norm_fp8");
+  TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && residual.is_contiguous() && input.sizes() == residual.sizes() &&
+              input.scalar_type() == residual.scalar_type() && weight.is_contiguous() && weight.numel() == input.size(1));
+  auto out8 = torch::empty(input.sizes(), input.options().dtype(torch::kUInt8));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(input));
+  check(lvllm_fused_add_rms_norm_quant(const_cast<void*>(input.data_ptr()), residual.data_ptr(), weight.data_ptr(),
+                                       (float)epsilon, (int)input.size(0), (int)input.size(1),
+                                       dtype_code(input, "fused_add_rms_norm_fp8"), out8.data_ptr(),
+                                       q_scale.data_ptr<float>(), 0, current_stream(input)));
+  return out8;
+}
+
+// the same behind a projection that left its fp32 split-K partials [S, T, hidden] (x_scale / w_scale: a W8A8 one)
+torch::Tensor fused_add_rms_norm_splitk_fp8(torch::Tensor& residual, const torch::Tensor& partials,
+                                            const torch::Tensor& weight, double epsilon,
+                                            const c10::optional<torch::Tensor>& x_scale,
+                                            const c10::optional<torch::Tensor>& w_scale, const torch::Tensor& q_scale) {
+  LV_CHECK_DEVICE(residual);
+  check_q_scale(q_scale, "fused_add_rms_norm_splitk_fp8");
+  TORCH_CHECK(partials.dim() == 3 && partials.scalar_type() == at::kFloat && partials.is_contiguous());
+  TORCH_CHECK(residual.dim() == 2 && residual.is_contiguous() && partials.size(1) == residual.size(0) &&
+              partials.size(2) == residual.size(1));
+  TORCH_CHECK(x_scale.has_value() == w_scale.has_value(), "x_scale and w_scale: both or none");
+  if (x_scale.has_value()) {
+    check_q_scale(*x_scale, "fused_add_rms_norm_splitk_fp8");
+    check_q_scale(*w_scale, "fused_add_rms_norm_splitk_fp8");
+  }
+  auto out8 = torch::empty(residual.sizes(), residual.options().dtype(torch::kUInt8));
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(residual));
+  check(lvllm_fused_add_rms_norm_splitk_quant(
+      nullptr, residual.data_ptr(), partials.data_ptr<float>(), (int)partials.size(0), weight.data_ptr(), (float)epsilon,
+      (int)residual.size(0), (int)residual.size(1), dtype_code(residual, "fused_add_rms_norm_splitk_fp8"),
+      x_scale.has_value() ? x_scale->data_ptr<float>() : nullptr, w_scale.has_value() ? w_scale->data_ptr<float>() : nullptr,
+      out8.data_ptr(), q_scale.data_ptr<float>(), current_stream(residual)));
+  return out8;
+}
+
+static void check_w8a8_q(const torch::Tensor& x8, const torch::Tensor& w_packed, const torch::Tensor& w_scale,
+                         const torch::Tensor& x_scale, int64_t N, int64_t K, const char* op) {
+  LV_CHECK_DEVICE(x8);
+  LV_CHECK_DEVICE(w_packed);
+  TORCH_CHECK(x8.dim() == 2 && x8.size(1) == K && x8.stride(1) == 1 && x8.element_size() == 1 && x8.size(0) <= 32, op,
+              ": x_fp8 must be [M <= 32, K] bytes");
+  TORCH_CHECK(w_packed.is_contiguous() && w_packed.numel() * w_packed.element_size() == N * K, op,
+              ": w_packed must hold N*K fp8 bytes");
+  check_q_scale(w_scale, op);
+  check_q_scale(x_scale, op);
+}
+
+// y [M, N] in `out_dtype` = the projection of pre-quantised activations (skinny_linear_w8a8 on the unquantised x)
+torch::Tensor skinny_linear_w8a8_q(const torch::Tensor& x8, const torch::Tensor& w_packed, const torch::Tensor& w_scale,
+                                   const torch::Tensor& x_scale, int64_t N, int64_t K,
+                                   const std::optional<torch::Tensor>& bias, at::ScalarType out_dtype) {
+  check_w8a8_q(x8, w_packed, w_scale, x_scale, N, K, "skinny_linear_w8a8_q");
+  const int64_t M = x8.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x8));
+  auto y = torch::empty({M, N}, x8.options().dtype(out_dtype));
+  const int64_t ws_bytes = lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({ws_bytes / 4}, x8.options().dtype(torch::kFloat));
+  check(lvllm_skinny_gemm_w8a8_q(y.data_ptr(), nullptr, nullptr, x8.data_ptr(), w_packed.data_ptr(),
+                                 bias ? bias->data_ptr() : nullptr, x_scale.data_ptr<float>(), w_scale.data_ptr<float>(),
+                                 (int)M, (int)N, (int)K, x8.stride(0), dtype_code(y, "skinny_linear_w8a8_q"), 0,
+                                 ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes, current_stream(x8)));
+  return y;
+}
+
+// the gate_up projection + silu_and_mul + static_scaled_fp8_quant(act, q_scale) in one launch: fp8 [M, N / 2]
+torch::Tensor skinny_linear_w8a8_q_swiglu_fp8(const torch::Tensor& x8, const torch::Tensor& w_packed,
+                                              const torch::Tensor& w_scale, const torch::Tensor& x_scale, int64_t N,
+                                              int64_t K, const torch::Tensor& q_scale, at::ScalarType compute_dtype) {
+  check_w8a8_q(x8, w_packed, w_scale, x_scale, N, K, "skinny_linear_w8a8_q_swiglu_fp8");
+  check_q_scale(q_scale, "skinny_linear_w8a8_q_swiglu_fp8");
+  TORCH_CHECK(N % 32 == 0 && lvllm_skinny_gemm_w8a8_workspace_bytes((int)x8.size(0), (int)N, (int)K) == 0,
+              "skinny_linear_w8a8_q_swiglu_fp8: N % 32 == 0 and K within one workgroup");
+  const int64_t M = x8.size(0);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x8));
+  auto y8 = torch::empty({M, N / 2}, x8.options().dtype(torch::kUInt8));
+  const int dt = compute_dtype == at::kBFloat16 ? LVLLM_BF16 : LVLLM_F16;
+  TORCH_CHECK(compute_dtype == at::kBFloat16 || compute_dtype == at::kHalf, "compute_dtype: bfloat16 or float16");
+  check(lvllm_skinny_gemm_w8a8_q(nullptr, y8.data_ptr(), q_scale.data_ptr<float>(), x8.data_ptr(), w_packed.data_ptr(),
+                                 nullptr, x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N, (int)K,
+                                 x8.stride(0), dt, 2, nullptr, 0, current_stream(x8)));
+  return y8;
+}
+
+// raw fp32 split-K partials [S, M, N] of a projection of pre-quantised activations (empty: K is not split here)
+torch::Tensor skinny_linear_w8a8_q_partials(const torch::Tensor& x8, const torch::Tensor& w_packed,
+                                            const torch::Tensor& w_scale, const torch::Tensor& x_scale, int64_t N,
+                                            int64_t K) {
+  check_w8a8_q(x8, w_packed, w_scale, x_scale, N, K, "skinny_linear_w8a8_q_partials");
+  const int64_t M = x8.size(0);
+  const int64_t ws_bytes = lvllm_skinny_gemm_w8a8_workspace_bytes((int)M, (int)N, (int)K);
+  if (ws_bytes == 0 || M == 0) return torch::empty({0}, x8.options().dtype(torch::kFloat));
+  const int64_t S = ws_bytes / (M * N * 4);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(x8));
+  auto partials = torch::empty({S, M, N}, x8.options().dtype(torch::kFloat));
+  check(lvllm_skinny_gemm_w8a8_q(nullptr, nullptr, nullptr, x8.data_ptr(), w_packed.data_ptr(), nullptr,
+                                 x_scale.data_ptr<float>(), w_scale.data_ptr<float>(), (int)M, (int)N, (int)K,
+                                 x8.stride(0), LVLLM_BF16, 4, partials.data_ptr(), ws_bytes, current_stream(x8)));
+  return partials;
+}
+
 // W8A8 lm_head + greedy sampling in one launch (see skinny_linear_packed_argmax)
 torch::Tensor skinny_linear_w8a8_argmax(const torch::Tensor& x, const torch::Tensor& w_packed, const torch::Tensor& w_scale,
                                         const torch::Tensor& x_scale, int64_t N, int64_t K) {
@@ -1013,6 +1141,22 @@ TORCH_LIBRARY(_C_amd, amd) {
           "Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables, "
           "Tensor! token_log) -> ()");
   amd.impl("advance_step_logged", torch::kCUDA, &advance_step_logged);
+  amd.def("rms_norm_fp8(Tensor input, Tensor weight, float epsilon, Tensor q_scale) -> Tensor");
+  amd.impl("rms_norm_fp8", torch::kCUDA, &rms_norm_fp8);
+  amd.def("fused_add_rms_norm_fp8(Tensor input, Tensor! residual, Tensor weight, float epsilon, Tensor q_scale) -> Tensor");
+  amd.impl("fused_add_rms_norm_fp8", torch::kCUDA, &fused_add_rms_norm_fp8);
+  amd.def("fused_add_rms_norm_splitk_fp8(Tensor! residual, Tensor partials, Tensor weight, float epsilon, "
+          "Tensor? x_scale, Tensor? w_scale, Tensor q_scale) -> Tensor");
+  amd.impl("fused_add_rms_norm_splitk_fp8", torch::kCUDA, &fused_add_rms_norm_splitk_fp8);
+  amd.def("skinny_linear_w8a8_q(Tensor x_fp8, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
+          "Tensor? bias, ScalarType out_dtype) -> Tensor");
+  amd.impl("skinny_linear_w8a8_q", torch::kCUDA, &skinny_linear_w8a8_q);
+  amd.def("skinny_linear_w8a8_q_swiglu_fp8(Tensor x_fp8, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
+          "Tensor q_scale, ScalarType compute_dtype) -> Tensor");
+  amd.impl("skinny_linear_w8a8_q_swiglu_fp8", torch::kCUDA, &skinny_linear_w8a8_q_swiglu_fp8);
+  amd.def("skinny_linear_w8a8_q_partials(Tensor x_fp8, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K) "
+          "-> Tensor");
+  amd.impl("skinny_linear_w8a8_q_partials", torch::kCUDA, &skinny_linear_w8a8_q_partials);
   amd.def("sample_rows(Tensor! tokens_out, Tensor logits, Tensor? state_slot, Tensor(a!)? params, Tensor(b!)? counts, "
           "Tensor(c!)? scratch, Tensor(d!)? processed_out, bool update_state) -> ()");
   amd.impl("sample_rows", torch::kCUDA, &sample_rows);

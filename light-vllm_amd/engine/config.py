@@ -35,6 +35,9 @@ class ModelConfig:
     # "fp8": W8A8 projections (BASELINE config 5): per-tensor e4m3 weights, static per-tensor
     # activation scales calibrated once on a random batch (the reference's activation_scheme="static")
     quantization: Optional[str] = None
+    # W8A8 decode steps: activations quantised once by their producer (norm launches, SwiGLU epilogue) and handed to
+    # the projections as fp8 (bit-identical to quantising inside every projection; off = A/B runs)
+    fp8_activations_once: bool = True
 
     @property
     def head_dim(self) -> int:

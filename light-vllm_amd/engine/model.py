@@ -186,6 +186,21 @@ class DecoderModel:
         ops.fused_add_rms_norm(x, residual, weight, self.cfg.rms_norm_eps)
         return x
 
+    def _norm_fp8(self, x, residual: Optional[torch.Tensor], weight: torch.Tensor, q_scale: torch.Tensor) -> torch.Tensor:
+        """The add + norm in front of a W8A8 projection with its result leaving as fp8 ONLY, quantised with the
+        projection's static activation scale (bit-identical to the norm followed by static_scaled_fp8_quant): the
+        projection then takes its activations as they are (skinny_linear_w8a8_q) instead of re-quantising all of X in
+        every one of its workgroups.  x: the layer's first hidden states (residual None), a projection output, or the
+        raw split-K partials + scales of a W8A8 down projection."""
+        eps = self.cfg.rms_norm_eps
+        if residual is None:
+            return torch.ops._C_amd.rms_norm_fp8(x, weight, eps, q_scale)
+        if isinstance(x, tuple):
+            return torch.ops._C_amd.fused_add_rms_norm_splitk_fp8(residual, x[0], weight, eps, x[1], x[2], q_scale)
+        if x.dim() == 3:
+            return torch.ops._C_amd.fused_add_rms_norm_splitk_fp8(residual, x, weight, eps, None, None, q_scale)
+        return torch.ops._C_amd.fused_add_rms_norm_fp8(x, residual, weight, eps, q_scale)
+
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor,
                 kv_caches: Optional[List[torch.Tensor]], attn_metadata, unified=None) -> torch.Tensor:
         """`unified` = (block_tables, seq_lens, query_start_loc, max_query_len, slot_mapping): the step is
@@ -200,17 +215,29 @@ class DecoderModel:
             cfg.fuse_decode_ops and kv_caches is not None and T <= 64 and
             attn_metadata.num_prefill_tokens == 0 and hasattr(self.attn, "decode_attention"))
         slot_mapping = unified[4] if unified is not None else getattr(attn_metadata, "slot_mapping", None)
+        # W8A8 decode steps of <= 32 rows: activations are quantised ONCE, by the kernel that produces them (the norm
+        # launches, the SwiGLU epilogue), not again in every workgroup of the projection that consumes them
+        q_once = (decode_only and cfg.fp8_activations_once and 0 < T <= 32 and
+                  all(w.w8_packed is not None for w in (self.layers[0].qkv, self.layers[0].gate_up, self.layers[0].down))
+                  and self.layers[0].gate_up.N % 32 == 0 and self.layers[0].gate_up.K <= 4096)
         residual = None
         unified_out = None
         for i, lw in enumerate(self.layers):
-            if residual is None:  # qwen2.py:203-208
-                residual = hidden
-                normed = torch.empty_like(hidden)
-                ops.rms_norm(normed, hidden, lw.input_norm, cfg.rms_norm_eps)
-                hidden = normed
+            if q_once:
+                x8 = self._norm_fp8(hidden, residual, lw.input_norm, lw.qkv.x_scale)
+                if residual is None:
+                    residual = hidden
+                qkv = torch.ops._C_amd.skinny_linear_w8a8_q(x8, lw.qkv.w8_packed, lw.qkv.w_scale, lw.qkv.x_scale,
+                                                            lw.qkv.N, lw.qkv.K, lw.qkv_bias, cfg.dtype)
             else:
-                hidden = self._add_norm(hidden, residual, lw.input_norm)
-            qkv = linear(hidden, lw.qkv, lw.qkv_bias)
+                if residual is None:  # qwen2.py:203-208
+                    residual = hidden
+                    normed = torch.empty_like(hidden)
+                    ops.rms_norm(normed, hidden, lw.input_norm, cfg.rms_norm_eps)
+                    hidden = normed
+                else:
+                    hidden = self._add_norm(hidden, residual, lw.input_norm)
+                qkv = linear(hidden, lw.qkv, lw.qkv_bias)
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)  # strided views
             fused = False
             attn_out = None
@@ -244,6 +271,18 @@ class DecoderModel:
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(attn_out, lw.o.packed, lw.o.N, lw.o.K, False)
             else:
                 hidden = linear(attn_out, lw.o)
+            if q_once:
+                g, d = lw.gate_up, lw.down
+                h8 = self._norm_fp8(hidden, residual, lw.post_norm, g.x_scale)
+                act8 = torch.ops._C_amd.skinny_linear_w8a8_q_swiglu_fp8(h8, g.w8_packed, g.w_scale, g.x_scale, g.N, g.K,
+                                                                        d.x_scale, cfg.dtype)
+                part = torch.ops._C_amd.skinny_linear_w8a8_q_partials(act8, d.w8_packed, d.w_scale, d.x_scale, d.N, d.K)
+                if part.numel() > 0:  # the next add + norm sums the raw partials and applies the scales
+                    hidden = (part, d.x_scale, d.w_scale)
+                else:
+                    hidden = torch.ops._C_amd.skinny_linear_w8a8_q(act8, d.w8_packed, d.w_scale, d.x_scale, d.N, d.K,
+                                                                   None, cfg.dtype)
+                continue
             hidden = self._add_norm(hidden, residual, lw.post_norm)
             if (decode_only and cfg.swiglu_epilogue and lw.gate_up.w8_packed is not None and lw.gate_up.N % 32 == 0
                     and T <= 64):

@@ -5,10 +5,14 @@ exponential-race multinomial.  Torch ops on the device, as in the reference (no 
 either); formulated independently (descending order, cumulative mass from the top) and checked
 against golden outputs of the reference functions (tests/golden/sampler_front_half.npz).
 The engine samples plain-greedy requests inside the captured step (arg-max epilogue of the lm_head
-projection); requests with any other SamplingParams go through `SamplingBatch` below."""
+projection) and every other request through the device-side sampler (csrc/sampler.hip, device_sampler.py: one launch,
+inside the captured step and the multi-step burst); this module is the torch statement of the same stages that the
+kernel is compared with (tests/test_sampler_gpu.py) and that the memory-profiling run uses."""
 from typing import List, Optional
 
 import torch
+
+_SAMPLING_EPS = 1e-5  # sampling_params.py:14: below it a request is greedy
 
 
 def token_counts(tokens: torch.Tensor, vocab_size: int) -> torch.Tensor:
@@ -80,7 +84,7 @@ def sample(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None, top
     greedy = greedy_sample(logits)
     if temperature is None:
         return greedy
-    t = torch.where(temperature > 0, temperature, torch.ones_like(temperature))
+    t = torch.where(temperature >= _SAMPLING_EPS, temperature, torch.ones_like(temperature))
     x = logits / t[:, None]
     if top_p is not None or top_k is not None:
         V = logits.shape[1]
@@ -89,7 +93,7 @@ def sample(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None, top
     if min_p is not None:
         x = apply_min_p(x, min_p)
     drawn = random_sample(torch.softmax(x, dim=-1), generator)
-    return torch.where(temperature > 0, drawn, greedy)
+    return torch.where(temperature >= _SAMPLING_EPS, drawn, greedy)
 
 
 class SamplingBatch:
@@ -136,7 +140,7 @@ class SamplingBatch:
         greedy = greedy_sample(x)
         if self.all_greedy:
             return greedy
-        t = torch.where(self.temperature > 0, self.temperature, torch.ones_like(self.temperature))
+        t = torch.where(self.temperature >= _SAMPLING_EPS, self.temperature, torch.ones_like(self.temperature))
         x = x / t[:, None]
         if self.do_top:
             x = apply_top_k_top_p(x, self.top_p, self.top_k)
@@ -146,9 +150,11 @@ class SamplingBatch:
         drawn = random_sample(probs, self.generator)
         for i, seed in enumerate(self.seeds):  # a seeded request draws from its own stream (sampler.py:479-493)
             if seed is not None:
-                g = torch.Generator(device=probs.device).manual_seed(seed + int(self._step_of(i)))
+                # (seed, step) mixed, not added: seed s at step t + 1 must not repeat seed s + 1 at step t
+                mixed = (seed * 0x9E3779B97F4A7C15 + int(self._step_of(i)) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) % (1 << 63)
+                g = torch.Generator(device=probs.device).manual_seed(mixed)
                 drawn[i] = random_sample(probs[i:i + 1], g)[0]
-        return torch.where(self.temperature > 0, drawn, greedy)
+        return torch.where(self.temperature >= _SAMPLING_EPS, drawn, greedy)
 
     def _step_of(self, i: int) -> int:
         return self._steps[i] if hasattr(self, "_steps") else 0

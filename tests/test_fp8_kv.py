@@ -419,3 +419,132 @@ def test_w8a8_partials_into_add_norm_are_bit_identical_to_the_separate_launches(
     assert torch.equal(out.view(torch.int16), y.view(torch.int16))
     assert torch.ops._C_amd.skinny_linear_w8a8_partials(x[:, :4096].contiguous(), wp.view(-1)[: N * 4096], w_scale, x_scale,
                                                         N, 4096).numel() == 0
+
+
+# ------------------------------------------------------------------ W8A8 decode step: activations quantised ONCE
+def _w8(N, K, g):
+    from light_vllm_amd.quantization import pack_fp8_weight
+    w = torch.randn(N, K, generator=g, device=DEV) * 0.05
+    w_scale = (w.abs().max() / 448.0).reshape(1).float()
+    return pack_fp8_weight((w / w_scale).clamp(-448, 448).to(torch.float8_e4m3fn)), w_scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,hidden", [(32, 4096), (1, 256), (7, 1024), (19, 2048)])
+def test_norm_launches_with_an_fp8_twin_equal_norm_then_quant(ops, dtype, M, hidden):
+    """rms_norm_fp8 / fused_add_rms_norm_fp8 / fused_add_rms_norm_splitk_fp8: the bytes static_scaled_fp8_quant writes
+    for the normalised rows of rms_norm / fused_add_rms_norm / fused_add_rms_norm_splitk[_scaled], and the same
+    residual, bit for bit (some values saturate on purpose)."""
+    g = torch.Generator(device=DEV).manual_seed(M + hidden)
+    x = torch.randn(M, hidden, generator=g, device=DEV).to(dtype)
+    res = torch.randn(M, hidden, generator=g, device=DEV).to(dtype)
+    weight = (1 + 0.1 * torch.randn(hidden, generator=g, device=DEV)).to(dtype)
+    qs = torch.tensor([0.004], device=DEV)
+
+    def quant(t):
+        out = torch.empty(t.shape, dtype=torch.float8_e4m3fn, device=DEV)
+        torch.ops._C.static_scaled_fp8_quant(out, t.contiguous(), qs)
+        return out.view(torch.uint8)
+    normed = torch.empty_like(x)
+    ops.rms_norm(normed, x, weight, 1e-5)
+    assert torch.equal(torch.ops._C_amd.rms_norm_fp8(x, weight, 1e-5, qs), quant(normed))
+    y, r1 = x.clone(), res.clone()
+    ops.fused_add_rms_norm(y, r1, weight, 1e-5)
+    r2 = res.clone()
+    got = torch.ops._C_amd.fused_add_rms_norm_fp8(x, r2, weight, 1e-5, qs)
+    assert torch.equal(got, quant(y)) and torch.equal(r1.view(torch.int16), r2.view(torch.int16))
+    assert int((got.view(torch.int8).abs() == 0x7e).sum()) > 0 or hidden < 1024  # 448 = 0x7e: saturation happened
+    part = torch.randn(3, M, hidden, generator=g, device=DEV) * 0.7
+    xs, ws = torch.tensor([0.03], device=DEV), torch.tensor([0.5], device=DEV)
+    for scales in ((None, None), (xs, ws)):
+        o1, r1 = torch.empty_like(res), res.clone()
+        torch.ops._C_amd.fused_add_rms_norm_splitk_scaled(o1, r1, part, weight, 1e-5, *scales)
+        r2 = res.clone()
+        got = torch.ops._C_amd.fused_add_rms_norm_splitk_fp8(r2, part, weight, 1e-5, scales[0], scales[1], qs)
+        assert torch.equal(got, quant(o1)) and torch.equal(r1.view(torch.int16), r2.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (512, 64), (256, 1024), (4096, 14336), (48, 8192)])
+def test_w8a8_projection_of_prequantised_activations_is_bit_identical(ops, dtype, M, N, K):
+    """skinny_linear_w8a8_q(static_scaled_fp8_quant(x)) == skinny_linear_w8a8(x): same bytes into the same MFMAs; the
+    raw split-K partials too (K beyond one workgroup), with and without a bias."""
+    from light_vllm_amd.quantization import skinny_fp8_linear
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    wp, w_scale = _w8(N, K, g)
+    bias = torch.randn(N, generator=g, device=DEV).to(dtype)
+    x_scale = (x.float().abs().max() / 448.0 * 0.8).reshape(1)
+    x8 = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+    torch.ops._C.static_scaled_fp8_quant(x8, x, x_scale)
+    x8 = x8.view(torch.uint8)
+    for b in (None, bias):
+        want = skinny_fp8_linear(x, wp, w_scale, x_scale, N, K, b)
+        got = torch.ops._C_amd.skinny_linear_w8a8_q(x8, wp, w_scale, x_scale, N, K, b, dtype)
+        assert got.dtype == dtype and torch.equal(got.view(torch.int16), want.view(torch.int16))
+    p1 = torch.ops._C_amd.skinny_linear_w8a8_partials(x, wp, w_scale, x_scale, N, K)
+    p2 = torch.ops._C_amd.skinny_linear_w8a8_q_partials(x8, wp, w_scale, x_scale, N, K)
+    assert p1.shape == p2.shape and torch.equal(p1, p2) and (p1.numel() > 0) == (K > 4096)
+    # rows of a wider buffer (row stride > K bytes)
+    wide = torch.zeros(M, K + 64, dtype=torch.uint8, device=DEV)
+    wide[:, :K] = x8
+    got = torch.ops._C_amd.skinny_linear_w8a8_q(wide[:, :K], wp, w_scale, x_scale, N, K, None, dtype)
+    assert torch.equal(got.view(torch.int16), skinny_fp8_linear(x, wp, w_scale, x_scale, N, K, None).view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,inter,K", [(32, 14336, 4096), (1, 256, 128), (17, 1040, 1024), (9, 2048, 2048)])
+def test_w8a8_swiglu_epilogue_with_an_fp8_result_is_bit_identical_to_the_launches_it_replaces(ops, dtype, M, inter, K):
+    """gate_up projection of pre-quantised activations + silu_and_mul + static_scaled_fp8_quant in one launch."""
+    g = torch.Generator(device=DEV).manual_seed(M + inter + K)
+    x = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    wp, w_scale = _w8(2 * inter, K, g)
+    x_scale = (x.float().abs().max() / 448.0).reshape(1)
+    x8 = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+    torch.ops._C.static_scaled_fp8_quant(x8, x, x_scale)
+    act = torch.ops._C_amd.skinny_linear_w8a8_swiglu(x, wp, w_scale, x_scale, 2 * inter, K, None)
+    qs = (act.float().abs().max() / 448.0 * 0.7).reshape(1)
+    want = torch.empty(M, inter, dtype=torch.float8_e4m3fn, device=DEV)
+    torch.ops._C.static_scaled_fp8_quant(want, act, qs)
+    got = torch.ops._C_amd.skinny_linear_w8a8_q_swiglu_fp8(x8.view(torch.uint8), wp, w_scale, x_scale, 2 * inter, K, qs, dtype)
+    assert got.shape == (M, inter) and torch.equal(got, want.view(torch.uint8))
+
+
+@pytest.mark.gpu
+def test_w8a8_model_forward_with_activations_quantised_once_is_bit_identical():
+    """Two layers at Llama-3-8B widths, W8A8: the decode forward with ModelConfig.fp8_activations_once (norm launches
+    and the SwiGLU epilogue hand fp8 to the projections) against the forward in which every projection quantises its
+    own input -- hidden states equal bit for bit, 1, 8 and 32 rows."""
+    import light_vllm_amd  # noqa: F401
+    from light_vllm_amd.attention.backend import PagedAttnImpl, PagedAttnMetadata
+    from light_vllm_amd.engine.config import ModelConfig
+    from light_vllm_amd.engine.model import DecoderModel
+    cfg = ModelConfig.llama3_8b()
+    cfg.num_hidden_layers, cfg.vocab_size, cfg.quantization = 2, 1024, "fp8"
+    attn = PagedAttnImpl(cfg.num_attention_heads, cfg.head_dim, cfg.head_dim ** -0.5, cfg.num_key_value_heads, None, None, "auto")
+    model = DecoderModel(cfg, attn, DEV, seed=0)
+    NB, BS = 64, 16
+    for n in (1, 8, 32):
+        g = torch.Generator(device=DEV).manual_seed(n)
+        kv = [(torch.randn(2, NB, BS * cfg.num_key_value_heads * cfg.head_dim, generator=g, device=DEV) * 0.3).to(cfg.dtype)
+              for _ in range(2)]
+        ids = torch.randint(0, cfg.vocab_size, (n,), generator=g, device=DEV)
+        lens = torch.randint(1, 2 * BS, (n,), generator=g, device=DEV).to(torch.int32)
+        bt = torch.randperm(NB, generator=g, device=DEV)[: 2 * n].view(n, 2).to(torch.int32)
+        pos = (lens - 1).long()
+        slots = bt[torch.arange(n, device=DEV), (pos // BS)].long() * BS + pos % BS
+        md = PagedAttnMetadata(num_prefills=0, num_prefill_tokens=0, num_decode_tokens=n, slot_mapping=slots, seq_lens=None,
+                               seq_lens_tensor=lens, max_query_len=1, max_prefill_seq_len=0, max_decode_seq_len=2 * BS,
+                               query_start_loc=None, seq_start_loc=None, context_lens_tensor=None, block_tables=bt)
+        outs = []
+        for once in (True, False):
+            cfg.fp8_activations_once = once
+            outs.append(model.forward(ids, pos, [t.clone() for t in kv], md))
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), n
+    cfg.fp8_activations_once = True
