@@ -202,12 +202,12 @@ def gemm_leg(engine, B):
             N, K = ws[0].N, ws[0].K
             x = (torch.randn(B, K, device=dev) * 0.5).to(cfg.dtype)
 
-            once = w8 and cfg.fp8_activations_once and B <= 32 and name != "o"
+            once = w8 and cfg.fp8_activations_once and B <= 32
             x8 = torch.randint(0, 120, (B, K), device=dev, dtype=torch.uint8) if once else None
             down_scale = layers[0].down.x_scale
 
             def call(w):
-                if once and name == "qkv":  # the launches the engine's step makes (activations already fp8)
+                if once and name in ("qkv", "o"):  # the launches the engine's step makes (activations already fp8)
                     torch.ops._C_amd.skinny_linear_w8a8_q(x8, w.w8_packed, w.w_scale, w.x_scale, N, K, None, cfg.dtype)
                 elif once and name == "gate_up":
                     torch.ops._C_amd.skinny_linear_w8a8_q_swiglu_fp8(x8, w.w8_packed, w.w_scale, w.x_scale, N, K, down_scale,
@@ -440,9 +440,10 @@ def prefill_leg(engine, qlen=16384, iters=12):
 def decode_region(engine, B, steps, burst, in_flight, sync=False):
     """`steps` model steps of the decode engine as bursts of `burst`, `in_flight` engine steps in flight, the
     pipeline empty on both sides; returns (tokens appended -- counted by the engine, not inferred --, seconds)."""
+    n = steps // burst
+    in_flight = max(1, min(in_flight, n))
     engine.scheduler_config.num_scheduler_steps = burst
     engine.scheduler_config.max_num_on_the_fly = in_flight
-    n = steps // burst
     tok0, st0 = engine.stat_tokens_appended, engine.stat_model_steps
     torch.cuda.synchronize(engine.device)
     t0 = time.perf_counter()
@@ -707,10 +708,10 @@ def main():
         """n_model_steps model steps as n / burst engine steps (each `burst` model steps chained on the device);
         the last (in_flight - 1) calls only collect, so the pipeline is empty on both sides of the region.
         Returns the tokens produced."""
-        in_flight = in_flight or on_the_fly
+        n = n_model_steps // burst
+        in_flight = max(1, min(in_flight or on_the_fly, n))  # the pipeline cannot hold more engine steps than there are
         engine.scheduler_config.num_scheduler_steps = burst  # lookahead slots stay at k_max - 1
         engine.scheduler_config.max_num_on_the_fly = in_flight
-        n = n_model_steps // burst
         # tokens are COUNTED, not inferred: what the engine appended to its sequences, cross-checked against the
         # sequences' own output lengths; and every engine step of the region must have been a burst of `burst`
         # model steps (a step that fell back to the general path would otherwise be credited `burst` tokens)

@@ -458,6 +458,27 @@ int lvllm_skinny_gemm_w8a8_q(void* y, void* y_fp8, const float* y_fp8_scale, con
                              int M, int N, int K, int64_t ldx, int dtype, int act, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* paged_attention_v2 / lvllm_rope_cache_paged_attention with an fp8 twin of the result: out_fp8 [num_seqs, num_heads,
+ * head_size] bytes = static_scaled_fp8_quant(out, *out_fp8_scale), for a W8A8 output projection that takes its
+ * activations already quantised (lvllm_skinny_gemm_w8a8_q).  Same arguments otherwise (no ALiBi, no block-sparse
+ * arguments).  Only launches that are NOT cut into shares write the twin (bs 32 x 8 kv heads: one pass); otherwise 3
+ * is returned and nothing was launched. */
+int lvllm_paged_attention_v2_q(
+    void* out, void* out_fp8, const float* out_fp8_scale, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes,
+    void* stream);
+int lvllm_rope_cache_paged_attention_q(
+    void* out, void* out_fp8, const float* out_fp8_scale, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key, const void* value, void* key_cache, void* value_cache, int num_seqs,
+    int num_heads, int head_size, int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
+    int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream);
+
 /* ---- device queries (csrc/cuda_utils.h, torch_bindings.cpp:271-279) ------- */
 int64_t lvllm_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t lvllm_get_max_shared_memory_per_block_device_attribute(int64_t device_id);

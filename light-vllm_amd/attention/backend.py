@@ -364,15 +364,32 @@ class PagedAttnImpl:
                                       kv_cache_dtype=self.kv_cache_dtype, output=out)
 
     def decode_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
-                         attn_metadata: PagedAttnMetadata) -> torch.Tensor:
-        """Decode attention only (all tokens are decode tokens, K/V already in the cache)."""
+                         attn_metadata: PagedAttnMetadata, fp8_twin_scale: Optional[torch.Tensor] = None):
+        """Decode attention only (all tokens are decode tokens, K/V already in the cache).
+        `fp8_twin_scale` (one float on the device): the W8A8 output projection's activation scale -- the result is
+        then a pair (out, out_fp8 | None): out_fp8 [T, H * D] uint8 = static_scaled_fp8_quant(out, scale), written
+        by the attention launch itself when that launch is a single pass (None otherwise: quantise `out`)."""
         num_tokens, hidden_size = query.shape
         dq = query.view(-1, self.num_heads, self.head_size)
         md = attn_metadata.decode_metadata
         if self.logits_soft_cap > 0.0:
             out = torch.empty(dq.shape, dtype=dq.dtype, device=dq.device)
             self._decode_as_chunks(dq, key_cache, value_cache, md, out)
-            return out.view(num_tokens, hidden_size)
+            out = out.view(num_tokens, hidden_size)
+            return out if fp8_twin_scale is None else (out, None)
+        if fp8_twin_scale is not None:
+            pair = None
+            if self.alibi_slopes is None and self.decode_version != "v1" and dq.dtype in (torch.bfloat16, torch.float16):
+                max_len = md.max_decode_seq_len
+                scratch = md.decode_scratch or self._v2_scratch(dq.shape[0], max_len, dq)
+                out = torch.empty(dq.shape, dtype=dq.dtype, device=dq.device)
+                out8 = torch.empty(dq.shape, dtype=torch.uint8, device=dq.device)
+                if torch.ops._C_amd.paged_attention_v2_q(out, out8, fp8_twin_scale, scratch[0], scratch[1], scratch[2], dq,
+                                                         key_cache, value_cache, self.num_kv_heads, self.scale,
+                                                         md.block_tables, md.seq_lens_tensor, value_cache.shape[3], max_len,
+                                                         self.kv_cache_dtype, 1.0, 1.0):
+                    pair = (out.view(num_tokens, hidden_size), out8.view(num_tokens, hidden_size))
+            return pair if pair is not None else (self.decode_attention(query, key_cache, value_cache, attn_metadata), None)
         max_len = md.max_decode_seq_len
         force = self.decode_version
         use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads,
@@ -389,7 +406,8 @@ class PagedAttnImpl:
 
     def rope_cache_decode_attention(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                                     value: torch.Tensor, cos_sin_cache: torch.Tensor, key_cache: torch.Tensor,
-                                    value_cache: torch.Tensor, attn_metadata: PagedAttnMetadata) -> Optional[torch.Tensor]:
+                                    value_cache: torch.Tensor, attn_metadata: PagedAttnMetadata,
+                                    fp8_twin_scale: Optional[torch.Tensor] = None):
         """rotary_embedding + reshape_and_cache + paged_attention_v2 of a decode-only step in ONE launch
         (lvllm_rope_cache_paged_attention; bit-identical to the three).  None when the shapes are outside the
         fused kernel's envelope -- nothing was done, the caller runs the separate launches."""
@@ -411,10 +429,18 @@ class PagedAttnImpl:
         max_len = md.max_decode_seq_len
         scratch = md.decode_scratch or self._v2_scratch(num_tokens, max_len, query)
         out = torch.empty(num_tokens, self.num_heads, self.head_size, dtype=query.dtype, device=query.device)
-        ok = torch.ops._C_amd.rope_cache_paged_attention(
-            out, scratch[0], scratch[1], scratch[2], positions, query, key, value, self.head_size, cos_sin_cache, True,
-            key_cache, value_cache, attn_metadata.slot_mapping, self.num_kv_heads, self.scale, md.block_tables,
-            md.seq_lens_tensor, value_cache.shape[3], max_len, self.kv_cache_dtype, 1.0, 1.0)
+        args = (out, scratch[0], scratch[1], scratch[2], positions, query, key, value, self.head_size, cos_sin_cache, True,
+                key_cache, value_cache, attn_metadata.slot_mapping, self.num_kv_heads, self.scale, md.block_tables,
+                md.seq_lens_tensor, value_cache.shape[3], max_len, self.kv_cache_dtype, 1.0, 1.0)
+        if fp8_twin_scale is not None:
+            # (out, out_fp8 | None): the twin exists when the launch is a single pass; cut into shares the launch is
+            # refused WITH a twin (nothing done) and repeated without
+            out8 = torch.empty(out.shape, dtype=torch.uint8, device=query.device)
+            if torch.ops._C_amd.rope_cache_paged_attention(*args, out8, fp8_twin_scale):
+                return out.view(num_tokens, hidden_size), out8.view(num_tokens, hidden_size)
+            ok = torch.ops._C_amd.rope_cache_paged_attention(*args)
+            return (out.view(num_tokens, hidden_size), None) if ok else None
+        ok = torch.ops._C_amd.rope_cache_paged_attention(*args)
         return out.view(num_tokens, hidden_size) if ok else None
 
     def unified_attention(self, query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,

@@ -327,7 +327,7 @@ static int paged_attention_v2_impl(
     float v_scale, int tp_rank, int blocksparse_local_blocks,
     int blocksparse_vert_stride, int blocksparse_block_size,
     int blocksparse_head_sliding_step, int64_t kv_cache_bytes, int phases, void* stream,
-    const RopeArgs* rope) {
+    const RopeArgs* rope, void* out_fp8 = nullptr, const float* out_fp8_scale = nullptr) {
   if (int rc = check_common(num_seqs, num_heads, head_size, num_kv_heads, block_size, dtype,
                             kv_dtype, k_scale, v_scale, blocksparse_vert_stride))
     return rc;
@@ -404,6 +404,15 @@ static int paged_attention_v2_impl(
     p.partitioned = 0;
     p.max_num_partitions = 1;
   }
+  if (out_fp8 != nullptr) {  // the fp8 twin is written by the MFMA kernel's merge, when that merge writes `out`
+    if (!(nsplit == 1 && forced != -1 && use_mfma)) {
+      set_error("paged_attention_v2 with an fp8 twin: single-pass MFMA launches only");
+      return 3;
+    }
+    LV_CHECK(out_fp8_scale != nullptr, "out_fp8 needs out_fp8_scale");
+    p.out_fp8 = (uint8_t*)out_fp8;
+    p.out_fp8_scale = out_fp8_scale;
+  }
   const int tokens_per_wg = (max_seq_len + nsplit - 1) / nsplit;
   int rc = 0;
   if (phases & 1) {
@@ -459,14 +468,15 @@ extern "C" int lvllm_paged_attention_v2_phases(
 // Extension: one decode step's rotary_embedding (NeoX, rot_dim == head_size) + reshape_and_cache +
 // paged_attention_v2 in ONE launch (plus the reduce pass when contexts are cut into shares).  Returns 3 when
 // the arguments are outside the fused kernel's envelope (nothing was launched: run the three operators).
-extern "C" int lvllm_rope_cache_paged_attention(
+static int rope_cache_paged_attention_impl(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key,
     const void* value, void* key_cache, void* value_cache, int num_seqs, int num_heads, int head_size,
     int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
     const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
     int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
     int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
-    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream, void* out_fp8,
+    const float* out_fp8_scale) {
   const bool fp8 = kv_dtype == LVLLM_KV_FP8_E4M3;
   const bool ok =
       (dtype == LVLLM_BF16 || dtype == LVLLM_F16) && (kv_dtype == LVLLM_KV_AUTO || fp8) && is_neox &&
@@ -487,7 +497,58 @@ extern "C" int lvllm_rope_cache_paged_attention(
                                  num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens, block_size,
                                  max_seq_len, max_num_blocks_per_seq, max_num_partitions, nullptr, q_stride,
                                  kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, 0, 0, 64, 0,
-                                 kv_cache_bytes, 3, stream, &r);
+                                 kv_cache_bytes, 3, stream, &r, out_fp8, out_fp8_scale);
+}
+
+extern "C" int lvllm_rope_cache_paged_attention(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key,
+    const void* value, void* key_cache, void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
+    int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
+  return rope_cache_paged_attention_impl(out, exp_sums, max_logits, tmp_out, query, key, value, key_cache, value_cache,
+                                         num_seqs, num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens,
+                                         positions, slot_mapping, cos_sin_cache, rot_dim, is_neox, block_size, max_seq_len,
+                                         max_num_blocks_per_seq, max_num_partitions, q_stride, key_stride, value_stride,
+                                         kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale,
+                                         kv_cache_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int lvllm_rope_cache_paged_attention_q(
+    void* out, void* out_fp8, const float* out_fp8_scale, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key, const void* value, void* key_cache, void* value_cache, int num_seqs,
+    int num_heads, int head_size, int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    const int64_t* positions, const int64_t* slot_mapping, const void* cos_sin_cache, int rot_dim, int is_neox,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride,
+    int64_t key_stride, int64_t value_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
+  LV_CHECK(out_fp8 != nullptr && out_fp8_scale != nullptr, "out_fp8 and out_fp8_scale are required");
+  return rope_cache_paged_attention_impl(out, exp_sums, max_logits, tmp_out, query, key, value, key_cache, value_cache,
+                                         num_seqs, num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens,
+                                         positions, slot_mapping, cos_sin_cache, rot_dim, is_neox, block_size, max_seq_len,
+                                         max_num_blocks_per_seq, max_num_partitions, q_stride, key_stride, value_stride,
+                                         kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale,
+                                         kv_cache_bytes, stream, out_fp8, out_fp8_scale);
+}
+
+// paged_attention_v2 / the fused rope + cache + attention launch with an fp8 twin of the result for a W8A8 output
+// projection (include/lvllm_hip.h).  3 = this launch would be cut into shares (or is not an MFMA launch): nothing was
+// launched, call the plain entry and quantise.
+extern "C" int lvllm_paged_attention_v2_q(
+    void* out, void* out_fp8, const float* out_fp8_scale, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache, int num_seqs, int num_heads, int head_size,
+    int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens, int block_size,
+    int max_seq_len, int max_num_blocks_per_seq, int max_num_partitions, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes,
+    void* stream) {
+  LV_CHECK(out_fp8 != nullptr && out_fp8_scale != nullptr, "out_fp8 and out_fp8_scale are required");
+  return paged_attention_v2_impl(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+                                 head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                                 max_num_blocks_per_seq, max_num_partitions, nullptr, q_stride, kv_block_stride,
+                                 kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, 0, 0, 64, 0, kv_cache_bytes, 3,
+                                 stream, nullptr, out_fp8, out_fp8_scale);
 }
 
 extern "C" int lvllm_paged_attention_v2(

@@ -611,7 +611,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
     }
     o *= __fdividef(1.f, L + 1e-6f);
     const int64_t row = ((int64_t)seq * p.num_heads + head0 + h) * P + (p.partitioned ? part : 0);
-    reinterpret_cast<S*>(p.out)[row * D + d] = T::from_float(o);
+    const S ot = T::from_float(o);
+    reinterpret_cast<S*>(p.out)[row * D + d] = ot;
+    if (p.out_fp8 != nullptr)  // (the host allows the twin only for single-pass launches: `out` is the final result)
+      p.out_fp8[row * D + d] = (uint8_t)fp8_act_quant4(T::to_float(ot), 0.f, 0.f, 0.f, 1.0f / p.out_fp8_scale[0]);
     if (p.partitioned && d == 0) {
       p.max_logits[row] = M;
       p.exp_sums[row] = L;

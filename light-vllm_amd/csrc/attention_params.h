@@ -46,6 +46,10 @@ struct AttnParams {
   const void* v_new;            // [num_seqs, num_kv_heads, D], row stride v_new_stride
   const int64_t* slot_mapping;  // [num_seqs]; < 0 or beyond the caches: nothing is written
   int64_t k_new_stride, v_new_stride, num_slots;
+  // fp8 twin of the result (single-pass launches only): out_fp8[seq, head, d] = static_scaled_fp8_quant(out as rounded
+  // to T, *out_fp8_scale) -- the W8A8 output projection behind the attention then takes its activations as they are
+  uint8_t* out_fp8;
+  const float* out_fp8_scale;
 };
 
 __host__ __device__ inline bool blocksparse_attended(const AttnParams& p, int token, int seq_len, int head,

@@ -503,9 +503,15 @@ bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, tor
                                 torch::Tensor& value_cache, const torch::Tensor& slot_mapping, int64_t num_kv_heads,
                                 double scale, const torch::Tensor& block_tables, const torch::Tensor& seq_lens,
                                 int64_t block_size, int64_t max_seq_len, const std::string& kv_cache_dtype,
-                                double k_scale, double v_scale) {
+                                double k_scale, double v_scale, const c10::optional<torch::Tensor>& out_fp8,
+                                const c10::optional<torch::Tensor>& out_fp8_scale) {
   LV_CHECK_DEVICE(query);
   TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
+  TORCH_CHECK(out_fp8.has_value() == out_fp8_scale.has_value(), "out_fp8 and out_fp8_scale: both or none");
+  if (out_fp8.has_value())
+    TORCH_CHECK(out_fp8->is_cuda() && out_fp8->element_size() == 1 && out_fp8->is_contiguous() &&
+                out_fp8->numel() == out.numel() && out_fp8_scale->is_cuda() && out_fp8_scale->scalar_type() == at::kFloat &&
+                out_fp8_scale->numel() == 1, "out_fp8: bytes of out's shape; out_fp8_scale: one float on the device");
   TORCH_CHECK(query.dim() == 2 && key.dim() == 2 && value.dim() == 2, "query / key / value must be [tokens, heads * head_size]");
   TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt,
               "block_tables / seq_lens must be int32");
@@ -520,7 +526,17 @@ bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, tor
   TORCH_CHECK(positions.numel() >= num_seqs && slot_mapping.numel() >= num_seqs && seq_lens.numel() >= num_seqs &&
               block_tables.size(0) >= num_seqs);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
-  const int rc = lvllm_rope_cache_paged_attention(
+  const int rc = out_fp8.has_value() ? lvllm_rope_cache_paged_attention_q(
+      out.data_ptr(), out_fp8->data_ptr(), out_fp8_scale->data_ptr<float>(), exp_sums.data_ptr<float>(),
+      max_logits.data_ptr<float>(), tmp_out.data_ptr(), query.data_ptr(),
+      key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs, (int)num_heads,
+      (int)head_size, (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(), seq_lens.data_ptr<int32_t>(),
+      positions.data_ptr<int64_t>(), slot_mapping.data_ptr<int64_t>(), cos_sin_cache.data_ptr(),
+      (int)cos_sin_cache.size(1), is_neox ? 1 : 0, (int)block_size, (int)max_seq_len, (int)block_tables.size(1),
+      (int)exp_sums.size(-1), query.stride(-2), key.stride(-2), value.stride(-2), key_cache.stride(0),
+      key_cache.stride(1), dtype_code(query, "rope_cache_paged_attention"), kv_code, (float)k_scale, (float)v_scale,
+      cache_extent_bytes(key_cache, value_cache), current_stream(query))
+                                     : lvllm_rope_cache_paged_attention(
       out.data_ptr(), exp_sums.data_ptr<float>(), max_logits.data_ptr<float>(), tmp_out.data_ptr(), query.data_ptr(),
       key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs, (int)num_heads,
       (int)head_size, (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(), seq_lens.data_ptr<int32_t>(),
@@ -528,6 +544,37 @@ bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, tor
       (int)cos_sin_cache.size(1), is_neox ? 1 : 0, (int)block_size, (int)max_seq_len, (int)block_tables.size(1),
       (int)exp_sums.size(-1), query.stride(-2), key.stride(-2), value.stride(-2), key_cache.stride(0),
       key_cache.stride(1), dtype_code(query, "rope_cache_paged_attention"), kv_code, (float)k_scale, (float)v_scale,
+      cache_extent_bytes(key_cache, value_cache), current_stream(query));
+  if (rc == 3) return false;
+  check(rc);
+  return true;
+}
+
+// paged_attention_v2 with an fp8 twin of its result (lvllm_paged_attention_v2_q); false = the launch would be cut into
+// shares (nothing was done: call paged_attention_v2)
+bool paged_attention_v2_q(torch::Tensor& out, torch::Tensor& out_fp8, const torch::Tensor& out_fp8_scale,
+                          torch::Tensor& exp_sums, torch::Tensor& max_logits, torch::Tensor& tmp_out,
+                          const torch::Tensor& query, const torch::Tensor& key_cache, const torch::Tensor& value_cache,
+                          int64_t num_kv_heads, double scale, const torch::Tensor& block_tables,
+                          const torch::Tensor& seq_lens, int64_t block_size, int64_t max_seq_len,
+                          const std::string& kv_cache_dtype, double k_scale, double v_scale) {
+  LV_CHECK_DEVICE(query);
+  TORCH_CHECK(query.dim() == 3 && out.is_contiguous() && out.sizes() == query.sizes(), "query / out: [seqs, heads, head_size]");
+  TORCH_CHECK(out_fp8.is_cuda() && out_fp8.element_size() == 1 && out_fp8.is_contiguous() && out_fp8.numel() == out.numel() &&
+              out_fp8_scale.is_cuda() && out_fp8_scale.scalar_type() == at::kFloat && out_fp8_scale.numel() == 1,
+              "out_fp8: bytes of out's shape; out_fp8_scale: one float on the device");
+  TORCH_CHECK(block_tables.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt, "block_tables / seq_lens must be int32");
+  const int kv_code = kv_dtype_code(kv_cache_dtype);
+  check_cache_dtype(key_cache, query, kv_code, "paged_attention_v2_q");
+  check_cache_dtype(value_cache, query, kv_code, "paged_attention_v2_q");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
+  const int rc = lvllm_paged_attention_v2_q(
+      out.data_ptr(), out_fp8.data_ptr(), out_fp8_scale.data_ptr<float>(), exp_sums.data_ptr<float>(),
+      max_logits.data_ptr<float>(), tmp_out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+      (int)query.size(0), (int)query.size(1), (int)query.size(2), (int)num_kv_heads, (float)scale,
+      block_tables.data_ptr<int32_t>(), seq_lens.data_ptr<int32_t>(), (int)block_size, (int)max_seq_len,
+      (int)block_tables.size(1), (int)exp_sums.size(-1), query.stride(0), key_cache.stride(0), key_cache.stride(1),
+      dtype_code(query, "paged_attention_v2_q"), kv_code, (float)k_scale, (float)v_scale,
       cache_extent_bytes(key_cache, value_cache), current_stream(query));
   if (rc == 3) return false;
   check(rc);
@@ -1130,8 +1177,14 @@ TORCH_LIBRARY(_C_amd, amd) {
           "Tensor positions, Tensor query, Tensor key, Tensor value, int head_size, Tensor cos_sin_cache, "
           "bool is_neox, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, int num_kv_heads, "
           "float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, "
-          "str kv_cache_dtype, float k_scale=1.0, float v_scale=1.0) -> bool");
+          "str kv_cache_dtype, float k_scale=1.0, float v_scale=1.0, Tensor(a!)? out_fp8=None, "
+          "Tensor? out_fp8_scale=None) -> bool");
   amd.impl("rope_cache_paged_attention", torch::kCUDA, &rope_cache_paged_attention);
+  amd.def("paged_attention_v2_q(Tensor! out, Tensor! out_fp8, Tensor out_fp8_scale, Tensor! exp_sums, Tensor! max_logits, "
+          "Tensor! tmp_out, Tensor query, Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, "
+          "Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, str kv_cache_dtype, "
+          "float k_scale=1.0, float v_scale=1.0) -> bool");
+  amd.impl("paged_attention_v2_q", torch::kCUDA, &paged_attention_v2_q);
   amd.def("fused_add_rms_norm_splitk_scaled(Tensor! out, Tensor! residual, Tensor partials, Tensor weight, "
           "float epsilon, Tensor? x_scale, Tensor? w_scale) -> ()");
   amd.impl("fused_add_rms_norm_splitk_scaled", torch::kCUDA, &fused_add_rms_norm_splitk_scaled);

@@ -241,12 +241,16 @@ class DecoderModel:
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)  # strided views
             fused = False
             attn_out = None
+            attn8 = None  # fp8 twin of the attention result for a W8A8 output projection (q_once)
+            twin = lw.o.x_scale if (q_once and lw.o.w8_packed is not None and unified is None) else None
             if decode_only:
                 key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
             if decode_only and unified is None and cfg.rope_in_attention and hasattr(self.attn, "rope_cache_decode_attention"):
                 # rope + cache write + attention in one launch (bit-identical to the three)
                 attn_out = self.attn.rope_cache_decode_attention(positions, q, k, v, self.cos_sin_cache, key_cache,
-                                                                 value_cache, attn_metadata)
+                                                                 value_cache, attn_metadata, **({"fp8_twin_scale": twin} if twin is not None else {}))
+                if isinstance(attn_out, tuple):
+                    attn_out, attn8 = attn_out
             if decode_only and attn_out is None:
                 fused = torch.ops._C_amd.rotary_embedding_and_cache(
                     positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
@@ -259,6 +263,8 @@ class DecoderModel:
                     unified_out = torch.zeros(T, self.q_size, dtype=q.dtype, device=q.device)
                 attn_out = self.attn.unified_attention(q, key_cache, value_cache, unified[0], unified[1],
                                                        unified[2], unified[3], output=unified_out)
+            elif fused and twin is not None:
+                attn_out, attn8 = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata, fp8_twin_scale=twin)
             elif fused:
                 attn_out = self.attn.decode_attention(q, key_cache, value_cache, attn_metadata)
             else:
@@ -269,6 +275,9 @@ class DecoderModel:
                 # K is split over workgroups at this many rows: the add+norm launch sums the fp32 partials
                 # itself (as for the down projection), one reduce launch less
                 hidden = torch.ops._C_amd.skinny_linear_packed_partials(attn_out, lw.o.packed, lw.o.N, lw.o.K, False)
+            elif attn8 is not None:
+                hidden = torch.ops._C_amd.skinny_linear_w8a8_q(attn8, lw.o.w8_packed, lw.o.w_scale, lw.o.x_scale, lw.o.N,
+                                                               lw.o.K, None, cfg.dtype)
             else:
                 hidden = linear(attn_out, lw.o)
             if q_once:

@@ -515,23 +515,57 @@ def test_w8a8_swiglu_epilogue_with_an_fp8_result_is_bit_identical_to_the_launche
 
 
 @pytest.mark.gpu
-def test_w8a8_model_forward_with_activations_quantised_once_is_bit_identical():
-    """Two layers at Llama-3-8B widths, W8A8: the decode forward with ModelConfig.fp8_activations_once (norm launches
-    and the SwiGLU epilogue hand fp8 to the projections) against the forward in which every projection quantises its
-    own input -- hidden states equal bit for bit, 1, 8 and 32 rows."""
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_attention_launch_with_an_fp8_twin_of_its_result(ops, kv):
+    """paged_attention_v2_q / rope_cache_paged_attention(out_fp8=...): `out` as the plain launch writes it and
+    out_fp8 = static_scaled_fp8_quant(out, scale), for a W8A8 output projection; a launch that would be cut into
+    shares is refused (False, nothing written) instead of silently skipping the twin."""
+    S, H, KVH, D, BS = 32, 32, 8, 128, 16
+    lens = [1024 - 7 * i for i in range(S)]
+    inp = make_paged_inputs(S, H, KVH, D, BS, lens, dtype=torch.bfloat16, seed=5)
+    if kv == "fp8":
+        inp = quantize_paged_inputs_fp8(inp, 1.0, 1.0)
+    d = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    es, ml, tmp = v2_scratch(S, H, D, max(lens), torch.bfloat16, DEV)
+    want = torch.zeros_like(d["query"])
+    ops.paged_attention_v2(want, es, ml, tmp, d["query"], d["key_cache"], d["value_cache"], KVH, inp["scale"],
+                           d["block_tables"], d["seq_lens"], BS, max(lens), None, kv, 1.0, 1.0)
+    qs = (want.float().abs().max() / 448.0 * 0.6).reshape(1)
+    want8 = torch.empty(want.shape, dtype=torch.float8_e4m3fn, device=DEV)
+    torch.ops._C.static_scaled_fp8_quant(want8, want, qs)
+    out, out8 = torch.zeros_like(want), torch.zeros(want.shape, dtype=torch.uint8, device=DEV)
+    assert torch.ops._C_amd.paged_attention_v2_q(out, out8, qs, es, ml, tmp, d["query"], d["key_cache"], d["value_cache"], KVH,
+                                                 inp["scale"], d["block_tables"], d["seq_lens"], BS, max(lens), kv, 1.0, 1.0)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16)) and torch.equal(out8, want8.view(torch.uint8))
+    # two sequences of 1024 tokens: the library cuts them into shares -> no twin, nothing launched
+    out8.zero_()
+    assert not torch.ops._C_amd.paged_attention_v2_q(out[:2], out8[:2], qs, es[:2], ml[:2], tmp[:2], d["query"][:2],
+                                                     d["key_cache"], d["value_cache"], KVH, inp["scale"],
+                                                     d["block_tables"][:2], d["seq_lens"][:2], BS, max(lens), kv, 1.0, 1.0)
+    assert int(out8.sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_w8a8_model_forward_with_activations_quantised_once_is_bit_identical(kv):
+    """Two layers at Llama-3-8B widths, W8A8: the decode forward with ModelConfig.fp8_activations_once (norm launches,
+    the attention launch and the SwiGLU epilogue hand fp8 to the projections) against the forward in which every
+    projection quantises its own input -- hidden states equal bit for bit, 1, 8 and 32 rows, 16-bit and fp8 KV cache."""
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.attention.backend import PagedAttnImpl, PagedAttnMetadata
     from light_vllm_amd.engine.config import ModelConfig
     from light_vllm_amd.engine.model import DecoderModel
     cfg = ModelConfig.llama3_8b()
     cfg.num_hidden_layers, cfg.vocab_size, cfg.quantization = 2, 1024, "fp8"
-    attn = PagedAttnImpl(cfg.num_attention_heads, cfg.head_dim, cfg.head_dim ** -0.5, cfg.num_key_value_heads, None, None, "auto")
+    attn = PagedAttnImpl(cfg.num_attention_heads, cfg.head_dim, cfg.head_dim ** -0.5, cfg.num_key_value_heads, None, None, kv)
     model = DecoderModel(cfg, attn, DEV, seed=0)
     NB, BS = 64, 16
     for n in (1, 8, 32):
         g = torch.Generator(device=DEV).manual_seed(n)
-        kv = [(torch.randn(2, NB, BS * cfg.num_key_value_heads * cfg.head_dim, generator=g, device=DEV) * 0.3).to(cfg.dtype)
-              for _ in range(2)]
+        caches = [(torch.randn(2, NB, BS * cfg.num_key_value_heads * cfg.head_dim, generator=g, device=DEV) * 0.3).to(cfg.dtype)
+                  for _ in range(2)]
+        if kv == "fp8":
+            caches = [c.to(torch.float8_e4m3fn).view(torch.uint8) for c in caches]
         ids = torch.randint(0, cfg.vocab_size, (n,), generator=g, device=DEV)
         lens = torch.randint(1, 2 * BS, (n,), generator=g, device=DEV).to(torch.int32)
         bt = torch.randperm(NB, generator=g, device=DEV)[: 2 * n].view(n, 2).to(torch.int32)
@@ -543,7 +577,7 @@ def test_w8a8_model_forward_with_activations_quantised_once_is_bit_identical():
         outs = []
         for once in (True, False):
             cfg.fp8_activations_once = once
-            outs.append(model.forward(ids, pos, [t.clone() for t in kv], md))
+            outs.append(model.forward(ids, pos, [t.clone() for t in caches], md))
         torch.cuda.synchronize()
         assert torch.isfinite(outs[0].float()).all()
         assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), n
