@@ -503,11 +503,25 @@ def fp8_config_leg(a, dev, B, ctx, steps=32):
                                   "unit": "GB/s", "frac": round(kl["algo_bytes"] / kl["avg_s"] / 1e9 / HBM_PEAK_GBS, 4),
                                   "algorithmic_bytes_per_launch": kl["algo_bytes"],
                                   "avg_launch_us": round(kl["avg_s"] * 1e6, 2)}}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_attn_fp8.json")) as f:
+            out["roofline_attention"]["traffic"] = int(json.load(f)["traffic_over_algorithmic"] * kl["algo_bytes"])
+    except (OSError, KeyError, ValueError):
+        out["roofline_attention"]["traffic"] = None
     if gm is not None:
         ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
-        out["roofline_projections"] = {"bound": "hbm", "kernel": f"skinny_gemm_w8a8_kernel (qkv, o, gate_up, down of one layer, M = {B})",
+        w8_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_w8a8.json")) as f:
+                pm = json.load(f)
+            if B == pm["M"] and not a.tiny and cfg.fp8_activations_once:
+                w8_traffic = sum(v["hbm_bytes_per_launch"] for v in pm["shapes"].values())
+        except (OSError, KeyError, ValueError):
+            pass
+        out["roofline_projections"] = {"bound": "hbm", "kernel": f"skinny_gemm_kernel<W8, XQ> (qkv, o, gate_up + SwiGLU, down of one "
+                                                                  f"layer, M = {B}, fp8 weights, fp8 activations in)",
                                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": w8_traffic,
                                        "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
                                        "us_per_layer": round(gm["s_per_layer"] * 1e6, 2), "per_shape": gm["per_shape"]}
     del eng
@@ -779,7 +793,8 @@ def main():
     # measured on the same kernel at seq=1024 and scaled by this launch's algorithmic bytes.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_attn.json")) as f:
+        pmc_attn = "r03_pmc_attn_fp8.json" if a.kv_cache_dtype != "auto" else "r03_pmc_attn.json"
+        with open(os.path.join(ROOT, "profiles", pmc_attn)) as f:
             traffic = int(json.load(f)["traffic_over_algorithmic"] * kl["algo_bytes"])
     except (OSError, KeyError, ValueError):
         pass
@@ -825,7 +840,9 @@ def main():
                                                       f"; seq_lens = {ctx} for all {B} sequences",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_attn.json (2*FETCH_SIZE + WRITE_SIZE per launch, scaled)",
+                         "traffic_source": "profiles/r03_pmc_attn[_fp8].json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                           "separate passes of the same kernel at seq = 1024: 2*FETCH_SIZE + WRITE_SIZE per "
+                                           "launch, scaled by this launch's algorithmic bytes; a recording, not this run)",
                          "algorithmic_bytes_per_launch": kl["algo_bytes"],
                          "avg_launch_us": round(kl["avg_s"] * 1e6, 2), "min_launch_us": round(kl["min_s"] * 1e6, 2)},
             "cpu_baseline": cpu,
@@ -840,9 +857,9 @@ def main():
             g_ach = gm["bytes_per_layer"] / gm["s_per_layer"] / 1e9
             gm_traffic = None
             try:  # PMC passes of the same kernels at the same shapes (tools/pmc_gemm.py), M = 32 only
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_w8a8.json" if gm["w8"] else "r03_pmc_gemm.json")) as f:
                     pm = json.load(f)
-                if B == pm["M"] and not a.tiny and not gm["w8"]:
+                if B == pm["M"] and not a.tiny and (not gm["w8"] or cfg.fp8_activations_once):
                     gm_traffic = sum(v["hbm_bytes_per_launch"] for v in pm["shapes"].values())
             except (OSError, KeyError, ValueError):
                 pass
@@ -850,8 +867,8 @@ def main():
                 "bound": "hbm", "kernel": ("skinny_gemm_w8a8_kernel" if gm["w8"] else "skinny_gemm_kernel") +
                                           f" (qkv, o, gate_up + SwiGLU input, down of one layer, M = {B}, 256 workgroups)",
                 "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_ach / HBM_PEAK_GBS, 4),
-                "traffic": gm_traffic, "traffic_source": "profiles/r01_pmc_gemm.json (2*FETCH_SIZE + WRITE_SIZE per launch, "
-                                                         "the four shapes summed; M = 32)",
+                "traffic": gm_traffic, "traffic_source": "profiles/r03_pmc_gemm[_w8a8].json (2*FETCH_SIZE + WRITE_SIZE per "
+                                                         "launch, the four shapes summed; M = 32; a recording)",
                 "algorithmic_bytes_per_layer": gm["bytes_per_layer"],
                 "us_per_layer": round(gm["s_per_layer"] * 1e6, 2), "per_shape": gm["per_shape"]}
         print(json.dumps(line), flush=True)

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
             }
       }
 #endif
+#ifndef LVLLM_GEMM_NO_XPOSE  // diagnosis build (wrong results): what the LDS transpose of the activations costs
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -433,6 +434,9 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
             xf[mt][h * HALF + s2] =
                 *reinterpret_cast<const g_u32x4_t*>(xs + c * (NCH * 16) + (((4 * s2 + g) ^ c) * 16));
         }
+#else
+      (void)xs;
+#endif
     }
   }
   if constexpr (XQ) {

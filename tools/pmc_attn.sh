@@ -18,8 +18,8 @@ for kv in ${KV:-fp8 auto}; do
     i=$((i+1))
     timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/${kv}_p$i -- python3 tools/bench_attn.py --kv $kv --iters 64 > $O/${kv}_p$i.log 2> $O/${kv}_p$i.err || echo "pass $kv $i failed: $grp"
   done
-  python3 tools/prof_summary.py counters paged_attn_mfma_kernel $O/pmc_attn_${kv}.json $O/${kv}_p[0-9]* > /dev/null
-  rm -rf $O/${kv}_p[0-9]*
+  python3 tools/prof_summary.py counters paged_attn_mfma_kernel $O/pmc_attn_${kv}.json $(ls -d $O/${kv}_p*/) > /dev/null
+  rm -rf $O/${kv}_p*
   timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${kv}_stats -- python3 tools/bench_attn.py --kv $kv --iters 256 > $O/${kv}_stats.log 2> $O/${kv}_stats.err
   python3 tools/prof_summary.py stats $O/${kv}_stats $O/attn_${kv}_kernel_stats.csv > /dev/null
   rm -rf $O/${kv}_stats
