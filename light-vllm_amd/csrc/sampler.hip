@@ -12,9 +12,10 @@
 //
 // HOW: one workgroup of 1024 threads per row.  The row's fp32 working copy lives in a caller-provided scratch (it
 // stays in the XCD's L2 between passes).  Nothing is sorted: the k-th largest value and the top-p cut are found by a
-// three-level radix descent (11 + 11 + 10 bits of the order-preserving integer image of the float) over LDS
-// histograms -- counts for top-k, probability mass for top-p.  Mass is accumulated in 2^-40 fixed point with integer
-// atomics, so the result does not depend on the order in which the adds arrive: the kernel is deterministic.
+// descent over LDS histograms (select_key below: one level of linear bins under the row's maximum, then 11 bits at a
+// time of the order-preserving integer image of the float) -- counts for top-k, probability mass for top-p.  Mass is
+// accumulated in 2^-40 fixed point with integer atomics, so the result does not depend on the order in which the
+// adds arrive: the kernel is deterministic.
 // Per-request state lives on the device in `state slots` (SamplerParams + one int32 per vocabulary entry: bit 31 =
 // seen in the prompt, bits 0..30 = occurrences in the output); the kernel appends the token it drew to that state, so
 // the k model steps of a burst need no host round trip.  Random numbers: Philox4x32-10 keyed by the request's seed,
@@ -75,6 +76,59 @@ __device__ __forceinline__ float logit_to_float<BF16Bits>(BF16Bits v) { return B
 template <>
 __device__ __forceinline__ float logit_to_float<F16Bits>(F16Bits v) { return F16::to_float(v.v); }
 
+// f(item, index) for `n` items of a row, the block striding over them; U independent loads are issued before the first
+// one is used.  One workgroup walks a whole row: a loop that waits for each 2- or 4-byte load in turn runs at the
+// memory latency (30 us for a 128 k row of bf16), so the passes below move 16-byte groups and keep several in flight.
+template <int U, typename LOAD, typename F>
+__device__ __forceinline__ void for_each_in_row(const int n, LOAD&& load, F&& f) {
+  int i = threadIdx.x;
+  for (; i + (U - 1) * kSamplerThreads < n; i += U * kSamplerThreads) {
+    decltype(load(0)) v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load(i + u * kSamplerThreads);
+#pragma unroll
+    for (int u = 0; u < U; ++u) f(v[u], i + u * kSamplerThreads);
+  }
+  for (; i < n; i += kSamplerThreads) f(load(i), i);
+}
+
+template <typename V>
+struct alignas(16) Group {  // 16 bytes of a row
+  static constexpr int N = 16 / sizeof(V);
+  V v[N];
+};
+
+// group g of a row of n values: one 16-byte load when the row allows it, element by element otherwise (rows whose
+// base or pitch is not a multiple of 16 bytes, and the ragged last group, whose missing values read as `pad`)
+template <typename V>
+__device__ __forceinline__ Group<V> load_group(const V* __restrict__ row, const int g, const int n, const bool aligned,
+                                               const V pad) {
+  constexpr int N = Group<V>::N;
+  Group<V> r;
+  if (aligned && (g + 1) * N <= n) {
+    r = *reinterpret_cast<const Group<V>*>(row + g * N);
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) r.v[e] = g * N + e < n ? row[g * N + e] : pad;
+  }
+  return r;
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// f(value, index) for every value of a row
+template <typename V, typename F>
+__device__ __forceinline__ void for_each_value(const V* __restrict__ row, const int n, F&& f) {
+  constexpr int N = Group<V>::N;
+  const bool al = aligned16(row);
+  for_each_in_row<4>((n + N - 1) / N, [&](int g) { return load_group<V>(row, g, n, al, V{}); },
+                     [&](const Group<V>& v, int g) {
+#pragma unroll
+                       for (int e = 0; e < N; ++e)
+                         if (g * N + e < n) f(v.v[e], g * N + e);
+                     });
+}
+
 // (value, index) arg-max of the block, ties to the smaller index; result in every thread
 __device__ inline void block_argmax(float& v, int& i, float* sv, int* si) {
 #pragma unroll
@@ -112,18 +166,18 @@ __device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t* red) {
   return __shfl(r, 0);
 }
 
-// Histogram search by wave 0.  `from_top`: first bin b (walking down from the last) whose running total reaches
-// `target` (counts: the k-th largest lies in b); else first bin (walking up) whose running total EXCEEDS `target`
-// (mass: the cut lies in b).  Writes the bin and the total accumulated before it; bin = -1 when no bin qualifies.
-template <int NBINS, bool FROM_TOP>
+// Histogram search by wave 0: the first bin -- walking down from the last one (DESC) or up from bin 0 -- at which the
+// running total reaches `target` (STRICT: exceeds it).  Writes the bin and the total accumulated before it; bin = -1
+// when no bin qualifies.
+template <int NBINS, bool DESC, bool STRICT>
 __device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_out, uint64_t* before_out) {
   if (threadIdx.x < 64) {
     constexpr int PER = NBINS / 64;
     const int lane = threadIdx.x;
-    const int base = FROM_TOP ? NBINS - 1 - lane * PER : lane * PER;
+    const int base = DESC ? NBINS - 1 - lane * PER : lane * PER;
     uint64_t mine = 0;
 #pragma unroll 4
-    for (int j = 0; j < PER; ++j) mine += hist[FROM_TOP ? base - j : base + j];
+    for (int j = 0; j < PER; ++j) mine += hist[DESC ? base - j : base + j];
     uint64_t incl = mine;  // inclusive scan over lanes
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -131,7 +185,7 @@ __device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_
       if (lane >= d) incl += o;
     }
     const uint64_t excl = incl - mine;
-    const bool hit = FROM_TOP ? (excl < target && incl >= target) : (excl <= target && incl > target);
+    const bool hit = STRICT ? (excl <= target && incl > target) : (excl < target && incl >= target);
     const uint64_t ballot = __ballot(hit);
     if (ballot == 0) {
       if (lane == 0) { *bin_out = -1; *before_out = 0; }
@@ -139,9 +193,9 @@ __device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_
       uint64_t run = excl;
       int b = -1;
       for (int j = 0; j < PER; ++j) {
-        const int idx = FROM_TOP ? base - j : base + j;
+        const int idx = DESC ? base - j : base + j;
         const uint64_t h = hist[idx];
-        const bool here = FROM_TOP ? (run + h >= target) : (run + h > target);
+        const bool here = STRICT ? (run + h > target) : (run + h >= target);
         if (here) { b = idx; break; }
         run += h;
       }
@@ -150,6 +204,94 @@ __device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_
     }
   }
   __syncthreads();
+}
+
+// Selection without a sort.  MASS = false: the key of the `want`-th largest value of the row.  MASS = true: the
+// smallest key whose probability mass from the bottom, counted inside {key >= floor_key}, exceeds drop_frac x the
+// mass of that set (*found = false when no key does).
+//
+// Level 1 bins the row LINEARLY by its distance below the maximum (1/64 per bin, the last bin takes everything 32 or
+// more below): the values of a row of logits crowd a few octaves, so bins cut from the float's exponent bits put
+// 128 k LDS atomics on ~40 addresses and the pass costs what the serialised atomics cost; cut linearly they spread
+// over hundreds.  The last bin is not counted with atomics at all (a register sum per thread).  The levels below
+// work on the order-preserving integer keys of the values inside the chosen bin, 11 bits at a time from the span
+// the bin can hold, until single keys are told apart -- two more passes for ordinary logits, so the answer is the
+// exact k-th value / cut, whatever the binning above it was.
+constexpr int kLinBins = 2048;
+constexpr float kLinPerUnit = 64.f;
+
+__device__ __forceinline__ int lin_bin(float m, float x) {
+  return (int)fminf((m - x) * kLinPerUnit, (float)(kLinBins - 1));  // NaN -> the last bin
+}
+
+template <bool MASS>
+__device__ __forceinline__ uint32_t select_key(const float* __restrict__ x_row, const int vocab, const float m,
+                                      const uint32_t floor_key, uint64_t target, const float drop_frac, uint64_t* hist,
+                                      uint64_t* red, int* s_bin, uint64_t* s_before, bool* found) {
+  const int tid = threadIdx.x;
+  *found = true;
+  for (int b = tid; b < kLinBins; b += kSamplerThreads) hist[b] = 0;
+  __syncthreads();
+  uint64_t tail = 0;
+  for_each_value<float>(x_row, vocab, [&](float x, int) {
+    if (MASS && order_key(x) < floor_key) return;
+    const int b = lin_bin(m, x);
+    const uint64_t w = MASS ? (uint64_t)(expf(x - m) * 1099511627776.f) : 1ull;  // 2^40
+    if (b < kLinBins - 1) atomicAdd((unsigned long long*)&hist[b], (unsigned long long)w);
+    else tail += w;
+  });
+  tail = block_sum_u64(tail, red);
+  if (tid == 0) hist[kLinBins - 1] = tail;
+  __syncthreads();
+  if (MASS) {
+    const uint64_t z = block_sum_u64(hist[tid] + hist[tid + kSamplerThreads], red);
+    target = (uint64_t)((double)drop_frac * (double)z);
+  }
+  if (MASS) find_bin<kLinBins, true, true>(hist, target, s_bin, s_before);   // from the smallest values up
+  else find_bin<kLinBins, false, false>(hist, target, s_bin, s_before);      // from the largest values down
+  const int lb = *s_bin;
+  if (lb < 0) {  // MASS: the whole mass is <= the target (p -> 0).  Counts: only with NaNs in the row
+    *found = false;
+    __syncthreads();
+    return 0;
+  }
+  target -= *s_before;
+  // keys the bin can hold: its value bounds widened by more than the rounding of (m - x) and of the bounds themselves
+  const float slack = (fabsf(m) + 32.f) * 1e-6f;
+  uint32_t lo = lb == kLinBins - 1 ? 0u : order_key((m - (float)(lb + 1) / kLinPerUnit) - slack);
+  const uint32_t hi = order_key((m - (float)lb / kLinPerUnit) + slack);
+  if (hi < lo) lo = 0;
+  int bits = 32 - __clz((int)((hi - lo) | 1u));
+  __syncthreads();
+#pragma unroll 1
+  while (true) {
+    const int shift = bits > 11 ? bits - 11 : 0;
+    for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
+    __syncthreads();
+    for_each_value<float>(x_row, vocab, [&](float x, int) {
+      const uint32_t key = order_key(x);
+      if (MASS && key < floor_key) return;
+      const uint32_t d = key - lo;
+      if (key < lo || ((uint64_t)d >> bits) != 0 || lin_bin(m, x) != lb) return;
+      const uint64_t w = MASS ? (uint64_t)(expf(x - m) * 1099511627776.f) : 1ull;
+      atomicAdd((unsigned long long*)&hist[d >> shift], (unsigned long long)w);
+    });
+    __syncthreads();
+    if (MASS) find_bin<2048, false, true>(hist, target, s_bin, s_before);
+    else find_bin<2048, true, false>(hist, target, s_bin, s_before);
+    const int b = *s_bin;
+    if (b < 0) {  // cannot happen for a bin level 1 chose (same elements, same integer weights); stay safe
+      *found = false;
+      __syncthreads();
+      return 0;
+    }
+    target -= *s_before;
+    lo += (uint32_t)b << shift;
+    bits = shift;
+    __syncthreads();
+    if (shift == 0) break;
+  }
+  return lo;
 }
 
 template <typename LT>
@@ -164,6 +306,7 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   __shared__ uint64_t red[16];
   __shared__ int s_bin;
   __shared__ uint64_t s_before;
+  __shared__ bool s_found;
 
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
@@ -173,10 +316,10 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   if (sid < 0 || sid >= num_slots) {  // plain greedy row: arg-max of the logits as they are
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < vocab; i += kSamplerThreads) {
-      const float x = logit_to_float<LT>(lrow[i]);
+    for_each_value<LT>(lrow, vocab, [&](LT v, int i) {
+      const float x = logit_to_float<LT>(v);
       if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
-    }
+    });
     block_argmax(bv, bi, sv, si);
     if (processed_out != nullptr)
       for (int i = tid; i < vocab; i += kSamplerThreads)
@@ -198,121 +341,110 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   // ---- pass A: ban, penalties, temperature; the row's maximum ----
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = tid; i < vocab; i += kSamplerThreads) {
-    float x = logit_to_float<LT>(lrow[i]);
-    for (int b = 0; b < nban; ++b)
-      if (P.banned[b] == i) x = -INFINITY;
-    if (do_pen) {
-      const uint32_t c = (uint32_t)crow[i];
-      if (c != 0) x = x > 0.f ? x / P.repetition : x * P.repetition;
-      const float oc = (float)(c & 0x7fffffffu);
-      x -= P.frequency * oc;
-      x -= P.presence * (oc > 0.f ? 1.f : 0.f);
-    }
-    x = x / temp;
-    x_row[i] = x;
-    if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+  {
+    constexpr int N = Group<LT>::N;  // 8 logits of 16 bits (4 of fp32) = N / 4 groups of counts and of working values
+    struct Item { Group<LT> l; Group<int32_t> c[N / 4]; };
+    const bool l_al = aligned16(lrow), c_al = aligned16(crow), x_al = aligned16(x_row);
+    for_each_in_row<2>((vocab + N - 1) / N, [&](int g) {
+      Item it;
+      it.l = load_group<LT>(lrow, g, vocab, l_al, LT{});
+#pragma unroll
+      for (int h = 0; h < N / 4; ++h)
+        it.c[h] = do_pen ? load_group<int32_t>(crow, g * (N / 4) + h, vocab, c_al, 0) : Group<int32_t>{};
+      return it;
+    }, [&](const Item& it, int g) {
+#pragma unroll
+      for (int h = 0; h < N / 4; ++h) {
+        Group<float> o;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int e = h * 4 + e4, i = g * N + e;
+          float x = logit_to_float<LT>(it.l.v[e]);
+          for (int b = 0; b < nban; ++b)
+            if (P.banned[b] == i) x = -INFINITY;
+          if (do_pen) {
+            const uint32_t c = (uint32_t)it.c[h].v[e4];
+            if (c != 0) x = x > 0.f ? x / P.repetition : x * P.repetition;
+            const float oc = (float)(c & 0x7fffffffu);
+            x -= P.frequency * oc;
+            x -= P.presence * (oc > 0.f ? 1.f : 0.f);
+          }
+          x = x / temp;
+          o.v[e4] = x;
+          if (i < vocab && (x > bv || (x == bv && i < bi) || bi == 0x7fffffff)) { bv = x; bi = i; }
+        }
+        const int i0 = g * N + h * 4;
+        if (x_al && i0 + 4 <= vocab) {
+          *reinterpret_cast<Group<float>*>(x_row + i0) = o;
+        } else {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4)
+            if (i0 + e4 < vocab) x_row[i0 + e4] = o.v[e4];
+        }
+      }
+    });
   }
   block_argmax(bv, bi, sv, si);
   const float m = bv;
   int token = bi;
 
   if (!greedy) {
-    // ---- top-k: the key of the k-th largest value (counts, from the top) ----
+    // ---- top-k: the key of the k-th largest value ----
     uint32_t kth_key = 0;  // everything is >= key 0
     if (P.top_k > 0 && P.top_k < vocab) {
-      uint64_t want = (uint64_t)P.top_k;
-      uint32_t prefix = 0;
-#pragma unroll 1
-      for (int level = 0; level < 3; ++level) {
-        const int shift = level == 0 ? 21 : level == 1 ? 10 : 0;
-        const int nb = level == 2 ? 1024 : 2048;
-        for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
-        __syncthreads();
-        for (int i = tid; i < vocab; i += kSamplerThreads) {
-          const uint32_t key = order_key(x_row[i]);
-          const bool in = level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix);
-          if (in) atomicAdd((unsigned long long*)&hist[(key >> shift) & (nb - 1)], 1ull);
-        }
-        __syncthreads();
-        if (level == 2) find_bin<1024, true>(hist, want, &s_bin, &s_before);
-        else find_bin<2048, true>(hist, want, &s_bin, &s_before);
-        const int b = s_bin;
-        want -= s_before;
-        prefix = level == 0 ? (uint32_t)b : level == 1 ? ((prefix << 11) | (uint32_t)b) : ((prefix << 10) | (uint32_t)b);
-        __syncthreads();
-      }
-      kth_key = prefix;
+      const uint32_t k = select_key<false>(x_row, vocab, m, 0u, (uint64_t)P.top_k, 0.f, hist, red, &s_bin, &s_before,
+                                           &s_found);
+      if (s_found) kth_key = k;
+      __syncthreads();
     }
     // ---- top-p: the smallest key whose mass from the bottom (inside the top-k set) exceeds (1 - p) Z ----
     uint32_t cut_key = kth_key;
     if (P.top_p < 1.f) {
-      uint64_t z = 0;
-      for (int i = tid; i < vocab; i += kSamplerThreads) {
-        const float x = x_row[i];
-        if (order_key(x) >= kth_key) z += (uint64_t)(expf(x - m) * 1099511627776.f);  // 2^40
-      }
-      z = block_sum_u64(z, red);
-      uint64_t target = (uint64_t)((double)(1.f - P.top_p) * (double)z);
-      uint32_t prefix = 0;
-      bool found = true;
-#pragma unroll 1
-      for (int level = 0; level < 3 && found; ++level) {
-        const int shift = level == 0 ? 21 : level == 1 ? 10 : 0;
-        const int nb = level == 2 ? 1024 : 2048;
-        for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
-        __syncthreads();
-        for (int i = tid; i < vocab; i += kSamplerThreads) {
-          const float x = x_row[i];
-          const uint32_t key = order_key(x);
-          const bool in = key >= kth_key &&
-                          (level == 0 || (level == 1 ? (key >> 21) == prefix : (key >> 10) == prefix));
-          if (in)
-            atomicAdd((unsigned long long*)&hist[(key >> shift) & (nb - 1)],
-                      (unsigned long long)(expf(x - m) * 1099511627776.f));
-        }
-        __syncthreads();
-        if (level == 2) find_bin<1024, false>(hist, target, &s_bin, &s_before);
-        else find_bin<2048, false>(hist, target, &s_bin, &s_before);
-        const int b = s_bin;
-        if (b < 0) {
-          found = false;  // the whole mass is <= the target (p -> 0): only the largest survives ("at least one")
-        } else {
-          target -= s_before;
-          prefix = level == 0 ? (uint32_t)b : level == 1 ? ((prefix << 11) | (uint32_t)b) : ((prefix << 10) | (uint32_t)b);
-        }
-        __syncthreads();
-      }
+      const uint32_t c = select_key<true>(x_row, vocab, m, kth_key, 0, 1.f - P.top_p, hist, red, &s_bin, &s_before,
+                                          &s_found);
       const uint32_t max_key = order_key(m);
-      cut_key = found ? prefix : max_key;
+      cut_key = s_found ? c : max_key;  // nothing exceeds the target: only the largest survives ("at least one")
       if (cut_key > max_key) cut_key = max_key;
       if (cut_key < kth_key) cut_key = kth_key;
+      __syncthreads();
     }
     // ---- min-p + the draw: arg-max over the kept tokens of (x - m) - log(q), q ~ Exp(1) ----
     const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
     const uint32_t step = (uint32_t)P.output_len;
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    for (int i4 = tid; i4 * 4 < vocab; i4 += kSamplerThreads) {
+    float* prow = processed_out != nullptr ? processed_out + (int64_t)row * processed_stride : nullptr;
+    const bool x_al = aligned16(x_row);
+    for_each_in_row<4>((vocab + 3) / 4, [&](int i4) { return load_group<float>(x_row, i4, vocab, x_al, -INFINITY); },
+                       [&](Group<float> f, int i4) {
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i4 * 4 + e;
+        float x = f.v[e];
+        bool keep = order_key(x) >= cut_key && x > -INFINITY;
+        if (keep && P.min_p > 0.f) keep = !(expf(x - m) < P.min_p);
+        if (!keep) x = -INFINITY;
+        if (prow != nullptr && i < vocab) prow[i] = x;
+        f.v[e] = x;
+        any = any || keep;
+      }
+      if (!any) return;  // random numbers only where a token is still in the race (top-k 50: 50 of 128 k)
       uint32_t r[4];
       philox4x32_10((uint32_t)i4, step, k0, k1, r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = i4 * 4 + e;
-        if (i >= vocab) break;
-        float x = x_row[i];
-        bool keep = order_key(x) >= cut_key && x > -INFINITY;
-        if (keep && P.min_p > 0.f) keep = !(expf(x - m) < P.min_p);
-        if (!keep) x = -INFINITY;
-        if (processed_out != nullptr) processed_out[(int64_t)row * processed_stride + i] = x;
-        if (keep) {
+        if (f.v[e] > -INFINITY) {
+          // arg-max of p_i / q_i, q_i = -ln(u_i) ~ Exp(1), as x_i - ln(q_i); the hardware logarithm (v_log_f32) is
+          // this kernel's own definition of its random stream: nothing outside compares these bits
           const float u = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
-          const float q = -logf(u);
-          const float s = (x - m) - logf(q);
-          if (s > best || (s == best && i < besti)) { best = s; besti = i; }
+          const float q = -__logf(u);
+          const float sc = (f.v[e] - m) - __logf(q);
+          const int i = i4 * 4 + e;
+          if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
         }
       }
-    }
+    });
     block_argmax(best, besti, sv, si);
     token = besti != 0x7fffffff ? besti : bi;
   } else if (processed_out != nullptr) {

@@ -1470,7 +1470,7 @@ extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, c
   if (groups < 1) groups = 1;
   if (groups > groups_total) groups = groups_total;
   hipStream_t s = (hipStream_t)stream;
-  const size_t smem = M > 128 ? (size_t)2 * 256 * 256 : (size_t)3 * 128 * 256;  // [NST][ROWS][RB]
+  const size_t smem = M > 128 ? (size_t)2 * 256 * 256 : M > 64 ? (size_t)3 * 128 * 256 : (size_t)3 * 64 * 256;  // [NST][ROWS][RB]
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(groups, ksplit), dim3(kGemmWaves * 64), smem, s, (uint16_t*)y, partial,
@@ -1478,9 +1478,13 @@ extern "C" int lvllm_stream_gemm(void* y, const void* x, const void* w_packed, c
                        steps_per_split);
   };
   if (dtype == LVLLM_BF16) {
-    if (M <= 128) go(stream_gemm_kernel<BF16, 8, 4, 3>); else go(stream_gemm_kernel<BF16, 16, 4, 2>);
+    if (M <= 64) go(stream_gemm_kernel<BF16, 4, 4, 3>);
+    else if (M <= 128) go(stream_gemm_kernel<BF16, 8, 4, 3>);
+    else go(stream_gemm_kernel<BF16, 16, 4, 2>);
   } else {
-    if (M <= 128) go(stream_gemm_kernel<F16, 8, 4, 3>); else go(stream_gemm_kernel<F16, 16, 4, 2>);
+    if (M <= 64) go(stream_gemm_kernel<F16, 4, 4, 3>);
+    else if (M <= 128) go(stream_gemm_kernel<F16, 8, 4, 3>);
+    else go(stream_gemm_kernel<F16, 16, 4, 2>);
   }
   LV_LAUNCH_CHECK();
   if (ksplit > 1) {

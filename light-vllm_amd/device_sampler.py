@@ -18,6 +18,8 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from . import _custom_ops  # noqa: F401  (registers torch.ops._C_amd; raises if the HIP library is missing)
+
 PARAMS_BYTES = 128
 MAX_BANNED = 20
 _FMT = "<6f2iQ2i20i"

@@ -14,6 +14,8 @@ B, V = 32, 128256
 g = torch.Generator(device=dev).manual_seed(0)
 logits = (torch.randn(B, V, generator=g, device=dev) * 3).to(torch.bfloat16)
 cases = {"greedy rows (no state)": None,
+         "greedy rows with a state slot (first pass only)": dict(temperature=0.0),
+         "greedy + penalties": dict(temperature=0.0, repetition_penalty=1.2, frequency_penalty=0.3),
          "temperature only": dict(temperature=0.8),
          "top-k 50": dict(temperature=0.8, top_k=50),
          "top-p 0.9": dict(temperature=0.8, top_p=0.9),
@@ -31,17 +33,26 @@ for name, kw in cases.items():
     for _ in range(5):
         ds.sample(logits, slots, tokens_out=out, scratch=scratch, update_state=False)
     torch.cuda.synchronize()
+    # a captured train of 20 launches, replayed 5 times: the launch's own duration, not the host's dispatch cost
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(20):
+                ds.sample(logits, slots, tokens_out=out, scratch=scratch, update_state=False)
+    graph.replay()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(50):
-        ds.sample(logits, slots, tokens_out=out, scratch=scratch, update_state=False)
+    for _ in range(5):
+        graph.replay()
     b.record()
     torch.cuda.synchronize()
-    t_kernel = a.elapsed_time(b) / 50 * 1e3
+    t_kernel = a.elapsed_time(b) / 100 * 1e3
     t_torch = float("nan")
     if kw is not None:
         x = logits.float()
-        T = torch.full((B,), kw["temperature"], device=dev)
+        T = torch.full((B,), kw["temperature"] or 1.0, device=dev)
         tk = torch.full((B,), kw.get("top_k", V), device=dev, dtype=torch.long)
         tp = torch.full((B,), kw.get("top_p", 1.0), device=dev)
         mp = torch.full((B,), kw.get("min_p", 0.0), device=dev) if "min_p" in kw else None
