@@ -344,6 +344,26 @@ int lvllm_paged_prefill_attention_ex(
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, void* stream);
 
+/* The same with scratch for launches of SHORT chunks (every chunk <= 32 query tokens: the mixed steps of chunked
+ * prefill, one chunk beside one-token sequences -- flash_attn.py:538-555 is called for these too).  Such launches walk
+ * K/V the way paged_attention does (csrc/prefill_chunk.h); when they would leave CUs idle the key range is cut into
+ * partitions across workgroups, which needs max_seq_len (the caller's bound on seq_lens; 0: unknown, no partitions)
+ * and `workspace` of at least lvllm_paged_prefill_workspace_bytes(...) bytes, 256-byte aligned (null / too small: no
+ * partitions).  Results do not depend on whether the walk was cut beyond the rounding of the partial results to the
+ * model dtype (paged_attention_v2's scheme).  num_tokens: the rows of `query` (query_start_loc[num_seqs] or more; 0:
+ * unknown) -- it sizes the grid of launches that are mostly one-token sequences.  lvllm_paged_prefill_attention_ex
+ * is this with num_tokens 0 and no workspace. */
+int64_t lvllm_paged_prefill_workspace_bytes(int num_seqs, int num_tokens, int max_query_len, int num_heads,
+                                            int num_kv_heads, int head_size, int max_seq_len);
+int lvllm_paged_prefill_attention_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
+    int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int num_tokens, int max_seq_len, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Dense varlen attention without a KV cache: the encode-only / prefill-only path
  * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
  * cu_seqlens, causal=...); in-tree definition torch_naive.py:65-149).  query [T, num_heads, D],

@@ -69,13 +69,15 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
                             query_start_loc: torch.Tensor, max_query_len: int, block_size: int,
                             alibi_slopes: Optional[torch.Tensor] = None, sliding_window: int = 0,
                             softcap: float = 0.0, kv_cache_dtype: str = "auto", causal: bool = True,
-                            k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+                            k_scale: float = 1.0, v_scale: float = 1.0, max_seq_len: int = 0) -> None:
     """Causal varlen attention of prompt chunks over the paged cache: the job of
-    flash_attn_varlen_func(..., block_table=...) at flash_attn.py:538-555 of the reference."""
+    flash_attn_varlen_func(..., block_table=...) at flash_attn.py:538-555 of the reference.
+    max_seq_len: a bound on seq_lens when the caller has one (the reference passes max_seqlen_k); launches of short
+    chunks use it to cut long key walks across workgroups (csrc/prefill_chunk.h)."""
     torch.ops._C_amd.paged_prefill_attention(out, query, key_cache, value_cache, num_kv_heads, scale,
                                              block_tables, seq_lens, query_start_loc, max_query_len,
                                              block_size, alibi_slopes, sliding_window, softcap,
-                                             kv_cache_dtype, causal, k_scale, v_scale)
+                                             kv_cache_dtype, causal, k_scale, v_scale, max_seq_len)
 
 
 _VARLEN_WS = {}

@@ -481,7 +481,8 @@ class PagedAttnImpl:
                                           meta.query_start_loc, meta.seq_lens_tensor,
                                           meta.context_lens_tensor, meta.max_query_len, alibi,
                                           self.sliding_window, scale=self.scale, softcap=self.logits_soft_cap,
-                                          kv_cache_dtype=self.kv_cache_dtype, output=out)
+                                          kv_cache_dtype=self.kv_cache_dtype, output=out,
+                                          max_seq_len=meta.max_prefill_seq_len)
             return
         if self.logits_soft_cap > 0.0 and key_cache is not None:
             raise NotImplementedError("logits_soft_cap needs the HIP prefill kernel (16-bit model dtype, block size 16 / 32, "

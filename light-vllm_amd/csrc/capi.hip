@@ -16,6 +16,7 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     if (const char* e = getenv("LVLLM_PREFILL_MFMA32_MIN_QUERY")) v.prefill_mfma32_min_query = atoi(e);
+    if (const char* e = getenv("LVLLM_PREFILL_CHUNK_MAX_QUERY")) v.prefill_chunk_max_query = atoi(e);
     return v;
   }();
   return t;
@@ -55,6 +56,12 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "prefill_mfma32_min_query") {
     LV_CHECK(value >= 0, "prefill_mfma32_min_query must be non-negative (0: never)");
     lvllm::tuning().prefill_mfma32_min_query = value;
+  } else if (k == "prefill_chunk_max_query") {
+    LV_CHECK(value >= 0, "prefill_chunk_max_query must be non-negative (0: never)");
+    lvllm::tuning().prefill_chunk_max_query = value;
+  } else if (k == "prefill_chunk_max_avg_x8") {
+    LV_CHECK(value >= 8, "prefill_chunk_max_avg_x8 must be at least 8 (one token per sequence)");
+    lvllm::tuning().prefill_chunk_max_avg_x8 = value;
   } else {
     LV_CHECK(false, "unknown tuning key '" + k + "'");
   }
@@ -75,6 +82,8 @@ extern "C" int lvllm_get_tuning(const char* key, int* value) {
   else if (k == "cache_tile_min_tokens") *value = t.cache_tile_min_tokens;
   else if (k == "prefill_lds") *value = t.prefill_lds;
   else if (k == "prefill_mfma32_min_query") *value = t.prefill_mfma32_min_query;
+  else if (k == "prefill_chunk_max_query") *value = t.prefill_chunk_max_query;
+  else if (k == "prefill_chunk_max_avg_x8") *value = t.prefill_chunk_max_avg_x8;
   else LV_CHECK(false, "unknown tuning key '" + k + "'");
   return 0;
 }

@@ -25,6 +25,7 @@ void set_error(const std::string& msg);
 //                    512-token partitions (scratch contents then equal the reference's)
 //   prefill_lds      1 | 0, see Tuning
 //   prefill_mfma32_min_query   see Tuning
+//   prefill_chunk_max_query, prefill_chunk_max_avg_x8    see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
   int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
@@ -40,6 +41,10 @@ struct Tuning {
   int prefill_mfma32_min_query = 64;  // launches whose longest chunk has at least this many query tokens take the
                                       // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache) --
                                       // and launches with chunks of 16+ tokens whose grid fits the CUs at once; 0 = never
+  int prefill_chunk_max_query = 64;   // launches that are mostly one-token sequences (mixed steps of chunked prefill:
+  int prefill_chunk_max_avg_x8 = 16;  // at most max_avg_x8 / 8 = 2 query tokens per sequence on average, no chunk
+                                      // longer than max_query) take the decode-style walk of prefill_chunk.h (plain
+                                      // causal, head size 64 / 128, 16-bit cache); max_query 0 = never
 };
 Tuning& tuning();
 

@@ -3,6 +3,7 @@
 
 #include "../../include/lvllm_hip.h"
 #include "prefill_mfma32.h"
+#include "prefill_chunk.h"
 
 using namespace lvllm;
 
@@ -28,6 +29,36 @@ extern "C" int lvllm_paged_prefill_attention_ex(
     int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, void* stream) {
+  return lvllm_paged_prefill_attention_ws(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                                          num_kv_heads, scale, block_tables, seq_lens, query_start_loc,
+                                          max_query_len, block_size, max_num_blocks_per_seq, alibi_slopes, causal,
+                                          sliding_window, softcap, q_stride, out_stride, kv_block_stride,
+                                          kv_head_stride, dtype, kv_dtype, k_scale, v_scale, kv_cache_bytes, 0, 0,
+                                          nullptr, 0, stream);
+}
+
+extern "C" int64_t lvllm_paged_prefill_workspace_bytes(int num_seqs, int num_tokens, int max_query_len, int num_heads,
+                                                       int num_kv_heads, int head_size, int max_seq_len) {
+  if (num_seqs <= 0 || max_query_len <= 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
+    return 0;
+  lvllm::PrefillParams p{};
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.num_tokens = num_tokens;
+  if (!lvllm::chunk_kernel_takes(p, head_size, num_seqs, max_query_len)) return 0;
+  return lvllm::chunk_plan(num_seqs, max_query_len, num_heads, num_kv_heads, head_size, max_seq_len).ws_bytes;
+}
+
+extern "C" int lvllm_paged_prefill_attention_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, const int32_t* query_start_loc,
+    int max_query_len, int block_size, int max_num_blocks_per_seq, const float* alibi_slopes,
+    int causal, int sliding_window, float softcap, int64_t q_stride, int64_t out_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int num_tokens, int max_seq_len, void* workspace, int64_t workspace_bytes, void* stream) {
+  LV_CHECK(num_tokens >= 0 && max_seq_len >= 0 && workspace_bytes >= 0 &&
+               (workspace != nullptr || workspace_bytes == 0),
+           "bad num_tokens / max_seq_len / workspace");
+  LV_CHECK(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   LV_CHECK(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
            "num_heads must be a positive multiple of num_kv_heads");
   LV_CHECK(dtype == LVLLM_F16 || dtype == LVLLM_BF16, "dtype must be float16 or bfloat16");
@@ -63,6 +94,7 @@ extern "C" int lvllm_paged_prefill_attention_ex(
   p.sliding_window = sliding_window; p.scale = scale; p.softcap = softcap;
   p.q_stride = q_stride; p.out_stride = out_stride;
   p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  p.max_seq_len = max_seq_len; p.num_tokens = num_tokens; p.workspace = workspace; p.workspace_bytes = workspace_bytes;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (dtype == LVLLM_BF16)

@@ -64,6 +64,11 @@ struct PrefillParams {
   int64_t q_stride, out_stride, kv_block_stride, kv_head_stride;  // kv strides in cache elements
   int kv_fp8;                // caches hold OCP e4m3fn bytes (x = 16 layouts); see attention_mfma.h KV8
   float k_scale, v_scale;    // a dequantised element is T(float(fp8) * scale)
+  // host side only (prefill_chunk.h): the caller's bound on seq_lens (0: unknown) and scratch for partitioned walks
+  int max_seq_len;
+  int num_tokens;  // rows of `query` the caller states (0: unknown)
+  void* workspace;
+  int64_t workspace_bytes;
 };
 
 // Column layout of one 16-column MFMA block: column c = (query token c / GP, head c % GP) with
@@ -556,10 +561,18 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
 template <typename T, int D, int BS>
 static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream);
 
+// launches that are mostly one-token sequences: the decode-style walk (prefill_chunk.h)
+template <typename T, int D, int BS>
+static int launch_prefill_chunk(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream);
+inline bool chunk_kernel_takes(const PrefillParams& p, int head_size, int num_seqs, int max_query_len);
+
 template <typename T, int D, int BS>
 static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
   constexpr int NB = D > 128 ? 1 : LVLLM_PREFILL_NB;  // accumulators: NB * D/4 VGPRs per lane
   if constexpr (D == 64 || D == 128) {
+    if (p0.causal && !p0.kv_fp8 && p0.alibi_slopes == nullptr && p0.softcap <= 0.f && p0.sliding_window <= 0 &&
+        chunk_kernel_takes(p0, D, num_seqs, max_query_len))
+      return launch_prefill_chunk<T, D, BS>(p0, num_seqs, max_query_len, stream);
     const int min_query = tuning().prefill_mfma32_min_query;
     // Shorter chunks (16 tokens up) take it too when its whole grid fits the CUs at once: the launch then lasts as
     // long as its slowest workgroup, and the 64-key tile walk is the faster one whatever the number of live

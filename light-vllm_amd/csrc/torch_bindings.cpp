@@ -587,7 +587,7 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
                              const torch::Tensor& query_start_loc, int64_t max_query_len, int64_t block_size,
                              const c10::optional<torch::Tensor>& alibi_slopes, int64_t sliding_window,
                              double softcap, const std::string& kv_cache_dtype, bool causal, double k_scale,
-                             double v_scale) {
+                             double v_scale, int64_t max_seq_len) {
   LV_CHECK_DEVICE(query);
   LV_CHECK_DEVICE(out);
   check_cache_dtype(key_cache, query, kv_dtype_code(kv_cache_dtype), "paged_prefill_attention");
@@ -605,7 +605,15 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
   TORCH_CHECK(value_cache.size(3) == block_size, "paged_prefill_attention: block_size does not match the cache");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
   const float* alibi = alibi_slopes.has_value() ? alibi_slopes->data_ptr<float>() : nullptr;
-  check(lvllm_paged_prefill_attention_ex(
+  // short chunks with a known bound on seq_lens: scratch for a partitioned key walk (0 bytes: single pass)
+  torch::Tensor workspace;
+  const int64_t ws_bytes =
+      max_seq_len > 0 ? lvllm_paged_prefill_workspace_bytes((int)num_seqs, (int)query.size(0), (int)max_query_len,
+                                                            (int)query.size(1), (int)num_kv_heads, (int)query.size(2),
+                                                            (int)max_seq_len)
+                      : 0;
+  if (ws_bytes > 0) workspace = torch::empty({ws_bytes}, query.options().dtype(torch::kUInt8));
+  check(lvllm_paged_prefill_attention_ws(
       out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs,
       (int)query.size(1), (int)query.size(2), (int)num_kv_heads, (float)scale, block_tables.data_ptr<int32_t>(),
       seq_lens.data_ptr<int32_t>(), query_start_loc.data_ptr<int32_t>(), (int)max_query_len, (int)block_size,
@@ -613,7 +621,14 @@ void paged_prefill_attention(torch::Tensor& out, const torch::Tensor& query, con
       out.stride(0),
       key_cache.stride(0), key_cache.stride(1), dtype_code(query, "paged_prefill_attention"),
       kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale, cache_extent_bytes(key_cache, value_cache),
+      (int)query.size(0), (int)max_seq_len, ws_bytes > 0 ? workspace.data_ptr() : nullptr, ws_bytes,
       current_stream(query)));
+}
+
+int64_t paged_prefill_workspace_bytes(int64_t num_seqs, int64_t num_tokens, int64_t max_query_len, int64_t num_heads,
+                                      int64_t num_kv_heads, int64_t head_size, int64_t max_seq_len) {
+  return lvllm_paged_prefill_workspace_bytes((int)num_seqs, (int)num_tokens, (int)max_query_len, (int)num_heads,
+                                             (int)num_kv_heads, (int)head_size, (int)max_seq_len);
 }
 
 int64_t varlen_attention_workspace_bytes(int64_t num_tokens, int64_t num_seqs, int64_t max_seq_len,
@@ -1163,7 +1178,7 @@ TORCH_LIBRARY(_C_amd, amd) {
   amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
           "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "
-          "str kv_cache_dtype, bool causal=True, float k_scale=1.0, float v_scale=1.0) -> ()");
+          "str kv_cache_dtype, bool causal=True, float k_scale=1.0, float v_scale=1.0, int max_seq_len=0) -> ()");
   amd.impl("paged_prefill_attention", torch::kCUDA, &paged_prefill_attention);
   amd.def("skinny_linear_w8a8(Tensor x, Tensor w_packed, Tensor w_scale, Tensor x_scale, int N, int K, "
           "Tensor? bias) -> Tensor");
@@ -1223,6 +1238,8 @@ TORCH_LIBRARY(_C_amd, amd) {
     check(lvllm_get_tuning(key.c_str(), &v));
     return (int64_t)v;
   });
+  amd.def("paged_prefill_workspace_bytes(int num_seqs, int num_tokens, int max_query_len, int num_heads, "
+          "int num_kv_heads, int head_size, int max_seq_len) -> int", &paged_prefill_workspace_bytes);
   amd.def("varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads, "
           "int head_size) -> int", &varlen_attention_workspace_bytes);
   amd.def("varlen_attention(Tensor! out, Tensor query, Tensor key, Tensor value, Tensor cu_seqlens, "

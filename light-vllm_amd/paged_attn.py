@@ -112,12 +112,14 @@ class PagedAttention:
                        alibi_slopes: Optional[torch.Tensor], sliding_window: Optional[int],
                        scale: Optional[float] = None, softcap: float = 0.0,
                        kv_cache_dtype: str = "auto", output: Optional[torch.Tensor] = None,
-                       k_scale: float = 1.0, v_scale: float = 1.0) -> torch.Tensor:
+                       k_scale: float = 1.0, v_scale: float = 1.0, max_seq_len: int = 0) -> torch.Tensor:
         """Prompt chunks against the paged cache (paged_attn.py:194-225 of the reference, which
         runs the Triton context_attention_fwd; the live backend calls flash_attn_varlen_func with
         block_table, flash_attn.py:538-555).  query [T, H, D]; `key`/`value` of the chunk must
         already be in the cache (write_to_paged_cache runs first in both reference backends), so
-        they are not read here; `context_lens` is implied by seq_lens - query lengths."""
+        they are not read here; `context_lens` is implied by seq_lens - query lengths.  `max_seq_len` (the reference
+        passes max_seqlen_k, flash_attn.py:547): a bound on seq_lens valid for every run of this call -- launches of
+        short chunks cut long key walks with it; 0 (captured steps, whose lengths change under the graph) = never."""
         del key, value, context_lens
         if output is None:
             output = torch.empty_like(query)
@@ -127,7 +129,7 @@ class PagedAttention:
         ops.paged_prefill_attention(output, query, key_cache, value_cache, num_kv_heads, scale,
                                     block_tables, seq_lens_tensor, query_start_loc, max_query_len,
                                     value_cache.shape[3], alibi_slopes, sliding_window or 0, softcap,
-                                    kv_cache_dtype, True, k_scale, v_scale)
+                                    kv_cache_dtype, True, k_scale, v_scale, max_seq_len)
         return output
 
     @staticmethod

@@ -24,10 +24,13 @@ def first_body_everywhere(ops, request):
     chunks); tests/test_prefill_mfma32_gpu.py runs the same cases through the 32x32-MFMA body, and
     test_prefill_dispatch_* below the shipped choice between the two."""
     default = int(torch.ops._C_amd.get_tuning("prefill_mfma32_min_query"))
+    default_chunk = int(torch.ops._C_amd.get_tuning("prefill_chunk_max_query"))
     if "dispatch" not in request.node.name:
         torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 0)
+        torch.ops._C_amd.set_tuning("prefill_chunk_max_query", 0)  # (tests/test_prefill_chunk_gpu.py has that walk)
     yield
     torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", default)
+    torch.ops._C_amd.set_tuning("prefill_chunk_max_query", default_chunk)
 
 
 def run_hip(ops, inp, alibi=None, window=0, softcap=0.0, out=None, causal=True):
@@ -250,8 +253,9 @@ def test_prefill_non_causal_sees_the_whole_context(ops, block_size):
 
 def test_prefill_dispatch_default_threshold(ops):
     """As shipped: a launch whose longest chunk has >= 64 query tokens takes the 32x32-MFMA body, and so does one with
-    chunks of 16+ tokens whose grid fits the CUs at once; the others the first body.  Both meet the bar, and a launch
-    is bit-identical to the body it is documented to take."""
+    chunks of 16+ tokens whose grid fits the CUs at once; the others the first body (launches that are mostly
+    one-token sequences take the walk of prefill_chunk.h: tests/test_prefill_chunk_gpu.py::test_dispatch_rule).  Both
+    meet the bar, and a launch is bit-identical to the body it is documented to take."""
     assert int(torch.ops._C_amd.get_tuning("prefill_mfma32_min_query")) == 64
     # (chunk lengths, takes the 32x32 body): >= 64 tokens always; 16..63 when the grid fits the CUs (2 kv heads x 3
     # sequences here: it does); below 16 never; 16..63 in a launch of many sequences (2 x 200 workgroups) not either
@@ -262,8 +266,10 @@ def test_prefill_dispatch_default_threshold(ops):
         out = run_hip(ops, inp)
         check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
         torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 1 if new_body else 0)
+        torch.ops._C_amd.set_tuning("prefill_chunk_max_query", 0)
         same = run_hip(ops, inp)
         torch.ops._C_amd.set_tuning("prefill_mfma32_min_query", 64)
+        torch.ops._C_amd.set_tuning("prefill_chunk_max_query", 64)
         assert torch.equal(out.view(torch.int16), same.view(torch.int16))
 
 
