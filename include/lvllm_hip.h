@@ -344,15 +344,16 @@ int lvllm_paged_prefill_attention_ex(
     int64_t kv_block_stride, int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, void* stream);
 
-/* The same with scratch for launches of SHORT chunks (every chunk <= 32 query tokens: the mixed steps of chunked
- * prefill, one chunk beside one-token sequences -- flash_attn.py:538-555 is called for these too).  Such launches walk
- * K/V the way paged_attention does (csrc/prefill_chunk.h); when they would leave CUs idle the key range is cut into
- * partitions across workgroups, which needs max_seq_len (the caller's bound on seq_lens; 0: unknown, no partitions)
- * and `workspace` of at least lvllm_paged_prefill_workspace_bytes(...) bytes, 256-byte aligned (null / too small: no
- * partitions).  Results do not depend on whether the walk was cut beyond the rounding of the partial results to the
- * model dtype (paged_attention_v2's scheme).  num_tokens: the rows of `query` (query_start_loc[num_seqs] or more; 0:
- * unknown) -- it sizes the grid of launches that are mostly one-token sequences.  lvllm_paged_prefill_attention_ex
- * is this with num_tokens 0 and no workspace. */
+/* The same with what lets a launch that would leave CUs idle cut its key walk into partitions across workgroups
+ * (paged_attention_v2's scheme; csrc/prefill_partitions.h): max_seq_len, the caller's bound on seq_lens (the
+ * reference passes max_seqlen_k to flash_attn_varlen_func, flash_attn.py:547; 0: unknown, no partitions), and
+ * `workspace` of at least lvllm_paged_prefill_workspace_bytes(...) bytes, 256-byte aligned (null / too small: no
+ * partitions).  Launches of a few sequences with short chunks over long contexts are the ones cut (8 x (32 tokens over
+ * 2 048): 38 -> see profiles/r03_bench_chunk_attn.txt).  Results do not depend on whether the walk was cut beyond the
+ * rounding of the partial results to the model dtype.  num_tokens: the rows of `query` (query_start_loc[num_seqs] or
+ * more; 0: unknown) -- launches that are mostly one-token sequences (the mixed steps of chunked prefill) are
+ * recognised by it and walk K/V the way paged_attention does (csrc/prefill_chunk.h).
+ * lvllm_paged_prefill_attention_ex is this with num_tokens 0 and no workspace. */
 int64_t lvllm_paged_prefill_workspace_bytes(int num_seqs, int num_tokens, int max_query_len, int num_heads,
                                             int num_kv_heads, int head_size, int max_seq_len);
 int lvllm_paged_prefill_attention_ws(

@@ -41,10 +41,15 @@ extern "C" int64_t lvllm_paged_prefill_workspace_bytes(int num_seqs, int num_tok
                                                        int num_kv_heads, int head_size, int max_seq_len) {
   if (num_seqs <= 0 || max_query_len <= 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
     return 0;
+  if (head_size != 64 && head_size != 128) return 0;  // (the bodies that can cut their key walk)
   lvllm::PrefillParams p{};
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.num_tokens = num_tokens;
-  if (!lvllm::chunk_kernel_takes(p, head_size, num_seqs, max_query_len)) return 0;
-  return lvllm::chunk_plan(num_seqs, max_query_len, num_heads, num_kv_heads, head_size, max_seq_len).ws_bytes;
+  if (lvllm::chunk_kernel_takes(p, head_size, num_seqs, max_query_len))
+    return lvllm::chunk_plan(num_seqs, max_query_len, num_heads, num_kv_heads, head_size, max_seq_len, num_tokens)
+        .ws_bytes;
+  if (lvllm::takes_mfma32(p, num_seqs, max_query_len))
+    return lvllm::prefill32_plan(num_seqs, max_query_len, num_heads, num_kv_heads, head_size, max_seq_len).ws_bytes;
+  return 0;
 }
 
 extern "C" int lvllm_paged_prefill_attention_ws(

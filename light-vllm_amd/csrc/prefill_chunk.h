@@ -30,20 +30,13 @@
 // with prefill_mfma.h.
 #pragma once
 #include "attention_mfma.h"
+#include "prefill_partitions.h"
 
 #ifndef LVLLM_CHUNK_NBUF
 #define LVLLM_CHUNK_NBUF 2
 #endif
 
 namespace lvllm {
-
-struct ChunkScratch {   // partitions (null tmp_out: single pass, results go to `out`)
-  void* tmp_out;        // [num_tokens * num_heads][num_parts][D]  T, normalised inside the partition
-  float* max_logits;    // [num_tokens * num_heads][num_parts]  (base-2 logits, as the kernel keeps them)
-  float* exp_sums;      // [num_tokens * num_heads][num_parts]
-  int num_parts;
-  int part_tokens;      // keys per partition, a multiple of 16
-};
 
 // maximum over the four 16-lane rows of a wave (lanes c, c + 16, c + 32, c + 48), in every lane: two VALU swaps
 // (v_permlane16_swap, v_permlane32_swap) instead of two trips through the LDS crossbar
@@ -395,39 +388,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_chunk_kernel(con
   }
 }
 
-// One workgroup of D threads per (sequence, query token, head): the partitions the row reaches (its own horizon, not
-// the chunk's).
-template <typename T, int D>
-__global__ __launch_bounds__(D) void prefill_chunk_reduce_kernel(const PrefillParams p, const ChunkScratch sc) {
-  using S = typename T::store_t;
-  const int head = blockIdx.x, t = blockIdx.y, seq = blockIdx.z, d = threadIdx.x;
-  const int qbeg = p.query_start_loc[seq];
-  const int qlen = p.query_start_loc[seq + 1] - qbeg;
-  if (t >= qlen) return;
-  const int tok = qbeg + t;
-  const int visible = p.seq_lens[seq] - qlen + t + 1;
-  const int np = min(sc.num_parts, (visible + sc.part_tokens - 1) / sc.part_tokens);
-  const int64_t row = ((int64_t)tok * p.num_heads + head) * sc.num_parts;
-  float M = -FLT_MAX;
-  for (int i = 0; i < np; ++i) M = fmaxf(M, sc.max_logits[row + i]);
-  float L = 0.f, o = 0.f;
-  for (int i = 0; i < np; ++i) {
-    const float w = sc.exp_sums[row + i] * __builtin_amdgcn_exp2f(sc.max_logits[row + i] - M);
-    L += w;
-    o += w * T::to_float(reinterpret_cast<const S*>(sc.tmp_out)[(row + i) * D + d]);
-  }
-  o *= L > 0.f ? __fdividef(1.f, L) : 0.f;
-  reinterpret_cast<S*>(p.out)[(int64_t)tok * p.out_stride + (int64_t)head * D + d] = T::from_float(o);
-}
-
 // The shape of a launch: query groups per sequence, partitions of the key walk, scratch.
 struct ChunkPlan {
   int gp_shift, qgroups, parts, part_tokens;
   int64_t rows, ws_bytes;  // rows = scratch rows per partition (an upper bound of tokens x heads)
 };
-constexpr int kChunkNCG = 1, kChunkWaves = 8, kChunkMaxParts = 16;  // (NCG 2 and 4 build and pass the tests: slower)
-
-inline int64_t chunk_up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+constexpr int kChunkNCG = 1, kChunkWaves = 8, kChunkMaxParts = kMaxPartitions;  // (NCG 2 and 4 build and pass the tests: slower)
 
 // Partitions: when the workgroups of a single pass would leave CUs idle and the contexts are long enough to cut
 // (>= 8 tiles per partition: two per wave).  max_seq_len is the caller's bound on seq_lens (0: unknown, no cut).
@@ -455,7 +421,7 @@ inline ChunkPlan chunk_plan(int num_seqs, int max_query_len, int num_heads, int 
     if (parts >= 2) {
       pl.parts = parts;
       pl.part_tokens = (((max_seq_len + parts - 1) / parts) + 15) & ~15;
-      pl.ws_bytes = chunk_up256(pl.rows * parts * head_size * 2) + 2 * chunk_up256(pl.rows * parts * 4);
+      pl.ws_bytes = partition_scratch_bytes(pl.rows, parts, head_size);
     }
   }
   return pl;
@@ -481,11 +447,7 @@ static int launch_prefill_chunk(const PrefillParams& p0, int num_seqs, int max_q
   ChunkScratch sc{};
   sc.num_parts = 1;
   if (pl.parts >= 2 && p.workspace != nullptr && p.workspace_bytes >= pl.ws_bytes) {
-    sc.num_parts = pl.parts;
-    sc.part_tokens = pl.part_tokens;
-    sc.tmp_out = p.workspace;
-    sc.max_logits = (float*)((char*)p.workspace + chunk_up256(pl.rows * pl.parts * D * 2));
-    sc.exp_sums = (float*)((char*)sc.max_logits + chunk_up256(pl.rows * pl.parts * 4));
+    sc = partition_scratch(p.workspace, pl.rows, pl.parts, pl.part_tokens, D);
   }
   const size_t smem = (size_t)kChunkWaves * 16 * 2 * sizeof(float) + (size_t)kChunkWaves * 16 * D * sizeof(float) +
                       (size_t)kChunkNCG * (D / 32) * 64 * 16;  // merge area | Q fragments
@@ -500,8 +462,7 @@ static int launch_prefill_chunk(const PrefillParams& p0, int num_seqs, int max_q
   hipLaunchKernelGGL(kern, dim3(p.num_kv_heads, rows, sc.num_parts), dim3(kChunkWaves * 64), smem, stream, p, sc,
                      flat ? -num_seqs : pl.qgroups);
   if (sc.tmp_out != nullptr)
-    hipLaunchKernelGGL((prefill_chunk_reduce_kernel<T, D>), dim3(p.num_heads, max_query_len, num_seqs), dim3(D), 0,
-                       stream, p, sc);
+    launch_partition_reduce<T, D>(p, sc, num_seqs, max_query_len, stream);
   return 0;
 }
 

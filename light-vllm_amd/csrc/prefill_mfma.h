@@ -561,6 +561,30 @@ __global__ __launch_bounds__(256, LVLLM_PREFILL_WAVES_PER_SIMD) void paged_prefi
 template <typename T, int D, int BS>
 static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream);
 
+// Whether a plain launch of head size 64 / 128 takes the 32x32-MFMA body: chunks of prefill_mfma32_min_query tokens
+// up always.  Shorter chunks (16 tokens up) take it too when its whole grid fits the CUs at once: the launch then
+// lasts as long as its slowest workgroup, and the 64-key tile walk is the faster one whatever the number of live
+// columns (1 x (32 over 4 096): 74 against 139 us; profiles/r02_prefill_threshold_ab.txt).  Larger launches
+// with short chunks are typically mixed steps full of one-token sequences.
+inline bool takes_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len) {
+  const int min_query = tuning().prefill_mfma32_min_query;
+  bool take32 = min_query > 0 && max_query_len >= min_query;
+  if (!take32 && min_query > 0 && max_query_len >= 16) {
+    static const int num_cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+      return n;
+    }();
+    const int G_ = p0.num_heads / p0.num_kv_heads;
+    const int cols_per_token = G_ == 1 ? 1 : G_ == 2 ? 2 : G_ <= 4 ? 4 : G_ <= 8 ? 8 : G_ <= 16 ? 16 : 32;
+    const int tqwg = 256 / cols_per_token;
+    const int64_t wgs = (int64_t)p0.num_kv_heads * ((G_ + 31) / 32) * num_seqs * ((max_query_len + tqwg - 1) / tqwg);
+    take32 = wgs <= num_cus;
+  }
+  return take32;
+}
+
 // launches that are mostly one-token sequences: the decode-style walk (prefill_chunk.h)
 template <typename T, int D, int BS>
 static int launch_prefill_chunk(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream);
@@ -573,25 +597,7 @@ static int launch_prefill_gp(const PrefillParams& p0, int num_seqs, int max_quer
     if (p0.causal && !p0.kv_fp8 && p0.alibi_slopes == nullptr && p0.softcap <= 0.f && p0.sliding_window <= 0 &&
         chunk_kernel_takes(p0, D, num_seqs, max_query_len))
       return launch_prefill_chunk<T, D, BS>(p0, num_seqs, max_query_len, stream);
-    const int min_query = tuning().prefill_mfma32_min_query;
-    // Shorter chunks (16 tokens up) take it too when its whole grid fits the CUs at once: the launch then lasts as
-    // long as its slowest workgroup, and the 64-key tile walk is the faster one whatever the number of live
-    // columns (1 x (32 over 4 096): 74 against 139 us; profiles/r02_prefill_threshold_ab.txt).  Larger launches
-    // with short chunks are typically mixed steps full of one-token sequences: the 128-column body's case.
-    bool take32 = min_query > 0 && max_query_len >= min_query;
-    if (!take32 && min_query > 0 && max_query_len >= 16) {
-      static const int num_cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-      }();
-      const int G_ = p0.num_heads / p0.num_kv_heads;
-      const int cols_per_token = G_ == 1 ? 1 : G_ == 2 ? 2 : G_ <= 4 ? 4 : G_ <= 8 ? 8 : G_ <= 16 ? 16 : 32;
-      const int tqwg = 256 / cols_per_token;
-      const int64_t wgs = (int64_t)p0.num_kv_heads * ((G_ + 31) / 32) * num_seqs * ((max_query_len + tqwg - 1) / tqwg);
-      take32 = wgs <= num_cus;
-    }
+    const bool take32 = takes_mfma32(p0, num_seqs, max_query_len);
     if (take32 && !p0.kv_fp8 && p0.alibi_slopes == nullptr && p0.softcap <= 0.f && p0.sliding_window <= 0)
       return launch_prefill_mfma32<T, D, BS>(p0, num_seqs, max_query_len, stream);
   }

@@ -24,6 +24,7 @@
 //     relative, so nothing is lost).
 #pragma once
 #include "prefill_mfma.h"
+#include "prefill_partitions.h"
 
 #ifndef LVLLM_PREFILL32_PINGPONG
 #define LVLLM_PREFILL32_PINGPONG 0  // 1: the two waves of a SIMD run half a tile out of phase (3 stages instead of 2)
@@ -89,7 +90,7 @@ __device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
 // Accumulator layout of the 32x32 MFMA: lane (col = lane & 31, hi = lane >> 5), register r holds row
 // (r & 3) + 8 * (r >> 2) + 4 * hi.
 template <typename T, int D, int BS>
-__global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const PrefillParams p) {
+__global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const PrefillParams p, const ChunkScratch sc) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "16-bit element types");
   static_assert(BS == 16 || BS == 32, "block size 16 or 32");
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   const int head0 = kvh * G + hg * 32;
   const int nh = min(GP, G - hg * 32);
   const int seq = blockIdx.y;
-  const int qtile = gridDim.z - 1 - blockIdx.z;  // heaviest first
+  // blockIdx.z = partition of the key walk (prefill_partitions.h; one when sc.tmp_out is null) x query tile
+  const int qtiles = gridDim.z / sc.num_parts;
+  const int part = blockIdx.z / qtiles;
+  const int qtile = qtiles - 1 - (blockIdx.z - part * qtiles);  // heaviest first
 
   const int qbeg = p.query_start_loc[seq];
   const int qlen = p.query_start_loc[seq + 1] - qbeg;
@@ -142,8 +146,17 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   // keys: the workgroup walks [0, khi_walk), this wave computes the tiles below khi
   const int khi = nq == 0 ? 0 : (p.causal ? ctx + t_first + nq : seq_len);
   const int khi_walk = p.causal ? ctx + min(qlen, (qtile + 1) * TQWG) : seq_len;
-  const int ntiles = (khi_walk + KT - 1) / KT;
-  const int my_ntiles = (khi + KT - 1) / KT;
+  // tiles j0 .. ntiles-1 are walked (a partition: its share of them; none: the workgroup has nothing to add, and no
+  // row of it reaches the partition, so the merge never reads what it would have written)
+  int ntiles = (khi_walk + KT - 1) / KT;
+  int my_ntiles = (khi + KT - 1) / KT;
+  int j0 = 0;
+  if (sc.tmp_out != nullptr) {
+    j0 = part * (sc.part_tokens / KT);
+    ntiles = min(ntiles, j0 + sc.part_tokens / KT);
+    my_ntiles = min(my_ntiles, ntiles);
+    if (j0 >= ntiles) return;
+  }
 
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * 2;
@@ -424,9 +437,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     // barrier that publishes it -- after the softmax of tile j, so that the loads have had K.Q^T and the softmax
     // to arrive and the writes drain under P.V.  The stage of tile j+1 held tile j+1-kStages, which every wave
     // has left behind before the barrier of tile j.
-    load_block_chunk(0, ld_blk);
-    fetch(0, block_of_tile(0));
-    stash(0);
+    load_block_chunk(j0 >> 6, ld_blk);
+    fetch(j0, block_of_tile(j0));
+    stash(j0);
 #if LVLLM_PREFILL32_STAMPS
     // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
     const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 8 && lane == 0;
@@ -461,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     // all of them at every loop end.)
     auto run = [&](auto late_tag) __attribute__((always_inline)) {
       constexpr bool late = decltype(late_tag)::value;
-      if constexpr (late) publish(0);
-      int j = 0;
+      if constexpr (late) publish(j0);
+      int j = j0;
 #pragma nounroll
       for (; j < my_ntiles; ++j) {
         stamp(j, 0);
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
         stamp(j, 5);
       }
 #pragma nounroll
-      for (; j < ntiles; ++j) {  // tiles this wave copies for the others
+      for (j = max(j, j0); j < ntiles; ++j) {  // tiles this wave copies for the others
         if constexpr (!late) publish(j);
         stash(j + 1);
         if constexpr (late)
@@ -512,6 +525,14 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     const float inv = l > 0.f ? __fdividef(1.f, l) : 0.f;
     if (live) {
       S* orow = (S*)p.out + (int64_t)(qbeg + t_first + cq) * p.out_stride + (int64_t)(head0 + ch) * D;
+      if (sc.tmp_out != nullptr) {  // the partition's share: (maximum in base 2, sum, normalised partial result)
+        const int64_t row = ((int64_t)(qbeg + t_first + cq) * p.num_heads + head0 + ch) * sc.num_parts + part;
+        orow = (S*)sc.tmp_out + row * D;
+        if (hi == 0) {
+          sc.max_logits[row] = m_run * kf;
+          sc.exp_sums[row] = l;
+        }
+      }
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -538,21 +559,64 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 #endif
 }
 
-// 0 = launched; -1 = not this kernel's case (the caller falls back to prefill_mfma.h)
+// The grid of a launch and, for launches that would leave most CUs idle (short chunks of a few sequences over long
+// contexts: 8 x (32 tokens over 2 048) is 64 workgroups walking 33 tiles each), the partitions of its key walk:
+// as many as fill the CUs, at least 4 tiles (256 keys) each, when the caller states a bound on seq_lens and
+// brings the scratch (prefill_partitions.h).
+struct Prefill32Plan {
+  int gp_shift, qtiles, parts, part_tokens;
+  int64_t rows, ws_bytes;
+};
+inline Prefill32Plan prefill32_plan(int num_seqs, int max_query_len, int num_heads, int num_kv_heads, int head_size,
+                                    int max_seq_len) {
+  static const int num_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  Prefill32Plan pl{};
+  const int G = num_heads / num_kv_heads;
+  const int HG = (G + 31) / 32;
+  pl.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : G <= 16 ? 4 : 5;
+  const int tqwg = 8 * (32 >> pl.gp_shift);
+  pl.qtiles = (max_query_len + tqwg - 1) / tqwg;
+  pl.parts = 1;
+  pl.rows = (int64_t)num_seqs * max_query_len * num_heads;
+  const int64_t wgs = (int64_t)num_kv_heads * HG * num_seqs * pl.qtiles;
+  if (max_seq_len > 0 && num_cus > 0 && wgs * 2 <= num_cus) {
+    int parts = (int)(num_cus / wgs);
+    const int tiles = (max_seq_len + 63) / 64;
+    if (parts > tiles / 4) parts = tiles / 4;
+    if (parts > kMaxPartitions) parts = kMaxPartitions;
+    if (parts >= 2) {
+      pl.parts = parts;
+      pl.part_tokens = ((tiles + parts - 1) / parts) * 64;
+      pl.ws_bytes = partition_scratch_bytes(pl.rows, parts, head_size);
+    }
+  }
+  return pl;
+}
+
 template <typename T, int D, int BS>
 static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
   PrefillParams p = p0;
   const int G = p.num_heads / p.num_kv_heads;
   const int HG = (G + 31) / 32;
-  p.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : G <= 16 ? 4 : 5;
-  const int tqwg = 8 * (32 >> p.gp_shift);
-  const int qtiles = (max_query_len + tqwg - 1) / tqwg;
-  const dim3 grid(p.num_kv_heads * HG, num_seqs, qtiles);
+  const Prefill32Plan pl = prefill32_plan(num_seqs, max_query_len, p.num_heads, p.num_kv_heads, D, p.max_seq_len);
+  p.gp_shift = pl.gp_shift;
+  ChunkScratch sc{};
+  sc.num_parts = 1;
+  if (pl.parts >= 2 && p.causal && p.workspace != nullptr && p.workspace_bytes >= pl.ws_bytes)
+    sc = partition_scratch(p.workspace, pl.rows, pl.parts, pl.part_tokens, D);
+  const dim3 grid(p.num_kv_heads * HG, num_seqs, pl.qtiles * sc.num_parts);
   const size_t smem = (size_t)LVLLM_PREFILL32_STAGES * 2 * D * 64 * 2;
   auto kern = paged_prefill_mfma32_kernel<T, D, BS>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, sc);
+  if (sc.tmp_out != nullptr)
+    launch_partition_reduce<T, D>(p, sc, num_seqs, max_query_len, stream);
 #if LVLLM_PREFILL32_STAMPS == 2
   if (getenv("LVLLM_PREFILL32_WG_FILE")) {
     static unsigned long long hostw[kWgRecords * kWgFields];

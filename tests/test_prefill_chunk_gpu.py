@@ -169,5 +169,6 @@ def test_workspace_rule(ops):
     assert f(64, 96, 32, 32, 8, 128, 2048) == 0     # a full mixed step: hundreds of workgroups
     assert f(2, 3, 2, 32, 8, 128, 200) == 0         # nothing to cut
     assert f(2, 3, 2, 32, 8, 128, 0) == 0           # no bound
-    assert f(2, 64, 32, 32, 8, 128, 4096) == 0      # chunks only: another body
+    assert f(2, 64, 32, 32, 8, 128, 4096) > 0       # chunks only: the 32x32 body, which cuts its walk too
+    assert f(64, 2048, 32, 32, 8, 128, 4096) == 0   # ... unless the launch fills the CUs by itself
     assert f(2, 3, 2, 32, 8, 128, 4096) > 0

@@ -224,3 +224,44 @@ def test_mfma32_contexts_longer_than_one_block_number_chunk(ops, block_size):
     out = run_hip(ops, inp)
     assert torch.isfinite(out).all()
     check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+@pytest.mark.parametrize("shape", [([2080] * 2, [32] * 2), ([1040] * 4, [16] * 4), ([4128], [32]),
+                                   ([700, 2080, 130], [40, 64, 9]), ([1500], [100])])
+@pytest.mark.parametrize("block_size", [16, 32])
+def test_partitioned_key_walk_matches_single_pass_and_the_oracle(ops, shape, block_size):
+    """Few workgroups over long contexts: with max_seq_len stated (and the scratch the op allocates) the key walk is cut
+    across workgroups (csrc/prefill_partitions.h) and merged per row over the partitions the row's own horizon
+    reaches.  Same bar as the single pass; against it the partial results are rounded once more to the model dtype."""
+    seq, ql = shape
+    inp = make_prefill_inputs(8, 2, 128, block_size, seq, ql, dtype=torch.bfloat16, seed=7)
+    need = torch.ops._C_amd.paged_prefill_workspace_bytes(len(seq), sum(ql), max(ql), 8, 2, 128, max(seq))
+    assert need > 0  # these launches are cut
+    d = to_dev(inp)
+
+    def run(max_seq_len):
+        out = torch.full_like(d["query"], float("nan"))
+        ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], 2, inp["scale"],
+                                    d["block_tables"], d["seq_lens"], d["query_start_loc"], inp["max_query_len"],
+                                    block_size, None, 0, 0.0, "auto", True, 1.0, 1.0, max_seq_len)
+        torch.cuda.synchronize()
+        return out
+
+    cut, whole = run(max(seq)), run(0)
+    want, ref64 = run_oracle(inp), dense_prefill_fp64(inp)
+    check_attention(cut, want, ref64)
+    check_attention(whole, want, ref64)
+    assert not torch.equal(cut.view(torch.int16), whole.view(torch.int16))  # (the cut is observable)
+    assert float((cut.float() - whole.float()).abs().max()) <= 2e-2 * float(whole.float().abs().max())
+
+
+def test_partitioned_key_walk_ignores_garbage_past_the_sequences(ops):
+    inp = make_prefill_inputs(8, 2, 128, 16, [1030, 517], [20, 33], dtype=torch.bfloat16, seed=9, garbage=float("nan"))
+    d = to_dev(inp)
+    out = torch.full_like(d["query"], float("nan"))
+    ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], 2, inp["scale"], d["block_tables"],
+                                d["seq_lens"], d["query_start_loc"], inp["max_query_len"], 16, None, 0, 0.0, "auto",
+                                True, 1.0, 1.0, 1030)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))

@@ -12,7 +12,7 @@ import light_vllm_amd  # noqa
 from light_vllm_amd import _custom_ops as ops
 
 
-def bench(seq_lens, qlens, H=32, KVH=8, D=128, BS=16, iters=200, dt=torch.bfloat16, dev="cuda:0"):
+def bench(seq_lens, qlens, H=32, KVH=8, D=128, BS=16, iters=200, dt=torch.bfloat16, dev="cuda:0", only_shipped=False):
     B = len(seq_lens)
     nblk = (max(seq_lens) + BS - 1) // BS
     NB = B * nblk + 7
@@ -46,12 +46,15 @@ def bench(seq_lens, qlens, H=32, KVH=8, D=128, BS=16, iters=200, dt=torch.bfloat
 
     res = {}
     tune = torch.ops._C_amd.set_tuning
+    if only_shipped:
+        return {"as shipped": time(lambda: run(max(seq_lens)))}, nbytes
     tune("prefill_chunk_max_avg_x8", 1 << 20)  # the walk of prefill_chunk.h whatever the token count
     res["mixed-step walk (forced), single pass"] = time(lambda: run(0))
     res["mixed-step walk (forced), partitions allowed"] = time(lambda: run(max(seq_lens)))
     tune("prefill_chunk_max_avg_x8", 16)
     tune("prefill_chunk_max_query", 0)
-    res["prefill bodies (round 2 dispatch)"] = time(lambda: run(0))
+    res["prefill bodies, single pass (round 2)"] = time(lambda: run(0))
+    res["prefill bodies, partitions allowed"] = time(lambda: run(max(seq_lens)))
     tune("prefill_chunk_max_query", 64)
     res["as shipped"] = time(lambda: run(max(seq_lens)))
     return res, nbytes
@@ -60,6 +63,7 @@ def bench(seq_lens, qlens, H=32, KVH=8, D=128, BS=16, iters=200, dt=torch.bfloat
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--only-shipped", action="store_true")
     a = ap.parse_args()
     shapes = {"16 seqs x (16 tokens over 1 024)": ([1040] * 16, [16] * 16),
               "8 seqs x (32 tokens over 2 048)": ([2080] * 8, [32] * 8),
@@ -68,7 +72,7 @@ if __name__ == "__main__":
               "32 decode rows at 1 024 (one-token chunks)": ([1024] * 32, [1] * 32),
               "1 seq x (32 tokens over 4 096)": ([4128], [32])}
     for name, (sl, ql) in shapes.items():
-        res, nbytes = bench(sl, ql, iters=a.iters)
+        res, nbytes = bench(sl, ql, iters=a.iters, only_shipped=a.only_shipped)
         print(name, f"({nbytes / 1e6:.1f} MB of K/V)")
         for k, us in res.items():
             print(f"    {k:46s} {us:8.1f} us   {nbytes / us / 1e6:6.2f} TB/s   {nbytes / us / 1e6 / 8:5.3f} of 8 TB/s")
