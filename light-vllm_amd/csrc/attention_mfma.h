@@ -114,6 +114,20 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   return r;
 }
 
+// maximum over the four 16-lane rows of a wave (lanes c, c + 16, c + 32, c + 48), in every lane: two VALU swaps
+// (v_permlane16_swap, v_permlane32_swap) instead of two trips through the LDS crossbar.  (Used by prefill_chunk.h.
+// In the decode kernel below it -- with base-2 exponentials and a rescale skipped when no maximum moved -- changed
+// nothing measurable: 22.96 against 22.96 us at the metric's shape, 14.3 against 14.5 with an fp8 cache, A/B of round 3,
+// profiles/r03_tuning.md section 8; that kernel waits for memory, not for its softmax.)
+__device__ __forceinline__ float rows_max(float m) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, m);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+  const uint32_t w = __builtin_bit_cast(uint32_t, m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+
 // gfx9-family raw buffer descriptor word 3 (32-bit data format, no swizzle)
 constexpr int kSrdFlags = 0x00020000;
 // cache policy of the K/V stream loads (buffer_load aux bits; 2 = nt: data read once)

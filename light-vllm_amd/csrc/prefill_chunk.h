@@ -38,17 +38,6 @@
 
 namespace lvllm {
 
-// maximum over the four 16-lane rows of a wave (lanes c, c + 16, c + 32, c + 48), in every lane: two VALU swaps
-// (v_permlane16_swap, v_permlane32_swap) instead of two trips through the LDS crossbar
-__device__ __forceinline__ float rows_max(float m) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, m);
-  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  m = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
-  const uint32_t w = __builtin_bit_cast(uint32_t, m);
-  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-  return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
-}
-
 // The lane number, recomputed where it is used: the asm "depends" on the tile counter, so it is not hoisted out of
 // the tile loop (and it is not volatile: a volatile asm counts as a store to anything, which turns the scalar
 // block-table loads into vector loads behind an s_waitcnt vmcnt(0)).  Everything a lane derives from its number --
