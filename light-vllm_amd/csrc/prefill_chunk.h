@@ -19,8 +19,8 @@
 //     prefill_chunk_reduce_kernel -- paged_attention_v2's scheme with per-row horizons -- when the launch would not
 //     fill the CUs otherwise;
 //   * logits in base 2 (v_exp_f32 is 2^x, log2(e) folded into the scale), the tile maximum over the four 16-lane rows
-//     by v_permlane16/32_swap instead of LDS round trips: 32 one-token sequences at 1 024 run in 21.8-23.3 us
-//     (0.72-0.77 of the HBM rate; the decode kernel proper: 22.9).
+//     by v_permlane16/32_swap instead of LDS round trips: 32 one-token sequences at 1 024 run in 21.8 us
+//     (tools/bench_chunk_attn.py; 31.5 through the prefill body).
 // The kernel is written for NCG column groups per workgroup (NCG x 16 / GP tokens against one read of K/V, Q
 // fragments in LDS, groups taken two at a time, K and V of the next tile requested apart so that NCG x D/4
 // accumulator registers fit) and ships with NCG = 1: with 4 groups a tile costs a wave ~4 000 issue cycles (48 MFMAs
