@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--scheduling", default="async", choices=["sync", "simple_async", "async"])
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
                     help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
+    ap.add_argument("--kv-block-pad-bytes", type=int, default=None,
+                    help="non-default runs only: CacheConfig.block_pad_bytes (default: the engine's, 1024; 0 = the "
+                         "reference's dense block layout)")
     ap.add_argument("--quantization", default=None, choices=["fp8"],
                     help="non-default runs only: W8A8 projections (BASELINE config 5; the headline is bf16)")
     ap.add_argument("--on-the-fly", type=int, default=2,
@@ -147,7 +150,7 @@ def kernel_leg(engine, B, iters, seq_len=None):
                 ctypes.c_int(dt), ctypes.c_int(1 if kv_fp8 else 0), ctypes.c_float(1.0), ctypes.c_float(1.0),
                 ctypes.c_int(0),
                 ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(64), ctypes.c_int(0),
-                ctypes.c_int64(kc.numel() * kc.element_size()), ctypes.c_int(phases), vp(stream))
+                ctypes.c_int64(kc.size(0) * kc.stride(0) * kc.element_size()), ctypes.c_int(phases), vp(stream))
         assert rc == 0, lib.lvllm_last_error()
 
     for i in range(32):  # one untimed train
@@ -699,7 +702,10 @@ def main():
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
     blocks = B * slots * ((max_len + bs - 1) // bs + 1) + 64
-    engine = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype),
+    cache_cfg = CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype)
+    if a.kv_block_pad_bytes is not None:
+        cache_cfg.block_pad_bytes = a.kv_block_pad_bytes
+    engine = LLMEngine(cfg, cache_cfg,
                        SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
                                        max_model_len=max_model_len, scheduling=a.scheduling,
                                        max_num_on_the_fly=slots, use_v2_block_manager=k_max > 1,
@@ -826,7 +832,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
                                    f"decode bs={B} per step, context {ctx} at the first step growing to {int(ctx_end)}, "
-                                   f"block_size 16, {a.scheduling} scheduling ({on_the_fly} batches in flight, one stream "
+                                   f"block_size 16 (blocks {engine.cache_config.block_pad_bytes} bytes apart beyond their "
+                                   f"size), {a.scheduling} scheduling ({on_the_fly} batches in flight, one stream "
                                    f"each), {k} model steps per engine step"
                                    + (" (advance_step on the device between them)" if k > 1 else "") +
                                    f", attention {a.attn_version}, HIP graph {'off' if a.no_graph else 'on'}, "

@@ -162,6 +162,18 @@ int lvllm_reshape_and_cache(
     int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
     int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream);
 
+/* The same over caches whose blocks are kv_block_stride cache elements apart (>= num_heads * head_size * block_size,
+ * a multiple of 16 bytes): what key_cache.stride(0) says.  The attention entries have always taken that stride; with
+ * it the cache ops follow a padded allocation too -- blocks exactly 32 KiB apart put the same tile of every
+ * sequence of a freshly filled cache on the same HBM channels (sequence i's blocks start i x 2 MiB in), and 1 KiB of
+ * padding per block makes the decode attention launch 12 % faster there (profiles/r03_tuning.md section 9).
+ * lvllm_reshape_and_cache is this with the dense stride. */
+int lvllm_reshape_and_cache_strided(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream);
+
 /* reshape_and_cache_flash: cache layout [num_blocks, block_size, num_heads,
  * head_size], block_stride = key_cache.stride(0) (cache_kernels.cu:206-247). */
 int lvllm_reshape_and_cache_flash(
@@ -310,6 +322,14 @@ int lvllm_rotary_embedding_and_cache_ex(
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, void* stream);
+
+/* ... and over caches whose blocks are kv_block_stride cache elements apart (see lvllm_reshape_and_cache_strided). */
+int lvllm_rotary_embedding_and_cache_strided(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream);
 
 /* Causal varlen attention of prompt chunks over the paged cache: prefill, chunked prefill and
  * prefix-cache hits.  Replaces the reference's third-party call

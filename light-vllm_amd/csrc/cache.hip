@@ -27,7 +27,7 @@ __global__ void reshape_and_cache_kernel(
     const int64_t* __restrict__ slot_mapping, const int64_t num_chunks,
     const int chunks_per_head, const int num_heads, const int head_size,
     const int block_size, const int64_t key_stride, const int64_t value_stride,
-    const bool vec_ok, const int64_t num_slots) {
+    const bool vec_ok, const int64_t num_slots, const int64_t block_stride) {
   using vec_t = uint4;
   static_assert(sizeof(store_t) * X == 16, "chunk must be 16 bytes");
   const int chunks_per_token = chunks_per_head * num_heads;
@@ -44,14 +44,11 @@ __global__ void reshape_and_cache_kernel(
 
     const store_t* ksrc = key + token * key_stride + head * head_size + x_idx * X;
     const store_t* vsrc = value + token * value_stride + head * head_size + x_idx * X;
-    store_t* kdst = key_cache +
-                    ((block_idx * num_heads + head) * chunks_per_head + x_idx) *
-                        (int64_t)block_size * X +
-                    block_off * X;
-    store_t* vdst = value_cache +
-                    ((block_idx * num_heads + head) * head_size + x_idx * X) *
-                        (int64_t)block_size +
-                    block_off;
+    // (block_stride: elements between blocks -- num_heads * head_size * block_size, or more when the caller pads)
+    store_t* kdst = key_cache + block_idx * block_stride +
+                    ((int64_t)head * chunks_per_head + x_idx) * (int64_t)block_size * X + block_off * X;
+    store_t* vdst = value_cache + block_idx * block_stride +
+                    ((int64_t)head * head_size + x_idx * X) * (int64_t)block_size + block_off;
     store_t kv[X], vv[X];
     if (vec_ok) {
       *reinterpret_cast<vec_t*>(kv) = *reinterpret_cast<const vec_t*>(ksrc);
@@ -80,7 +77,8 @@ __global__ void reshape_and_cache_fp8_kernel(
     uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
     const int64_t* __restrict__ slot_mapping, const int64_t num_chunks, const int chunks_per_head,
     const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
-    const int64_t value_stride, const float k_scale, const float v_scale, const int64_t num_slots) {
+    const int64_t value_stride, const float k_scale, const float v_scale, const int64_t num_slots,
+    const int64_t block_stride) {
   const int chunks_per_token = chunks_per_head * num_heads;
   auto quant4 = [](float a, float b, float c, float d, float scale) { return fp8_kv_quant4(a, b, c, d, scale); };
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < num_chunks;
@@ -106,11 +104,11 @@ __global__ void reshape_and_cache_fp8_kernel(
     kq.y = quant4(kf[4], kf[5], kf[6], kf[7], k_scale);
     kq.z = quant4(kf[8], kf[9], kf[10], kf[11], k_scale);
     kq.w = quant4(kf[12], kf[13], kf[14], kf[15], k_scale);
-    uint8_t* kdst = key_cache + ((block_idx * num_heads + head) * chunks_per_head + x_idx) * (int64_t)block_size * 16 +
-                    block_off * 16;
+    uint8_t* kdst = key_cache + block_idx * block_stride +
+                    ((int64_t)head * chunks_per_head + x_idx) * (int64_t)block_size * 16 + block_off * 16;
     *reinterpret_cast<uint4*>(kdst) = kq;
-    uint8_t* vdst = value_cache + ((block_idx * num_heads + head) * head_size + x_idx * 16) * (int64_t)block_size +
-                    block_off;
+    uint8_t* vdst = value_cache + block_idx * block_stride +
+                    ((int64_t)head * head_size + x_idx * 16) * (int64_t)block_size + block_off;
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
       const uint32_t w = quant4(vf[i], vf[i + 1], vf[i + 2], vf[i + 3], v_scale);
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_tile_kernel(
     const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, uint16_t* __restrict__ key_cache,
     uint16_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, const int num_tokens,
     const int num_heads, const int head_size, const int block_size, const int64_t key_stride,
-    const int64_t value_stride, const int64_t num_slots) {
+    const int64_t value_stride, const int64_t num_slots, const int64_t block_stride) {
   constexpr int TT = kTileTokens;
   constexpr int KROW = TT + 1;  // 16-byte units per d8 row of the K tile (odd: conflict-free transposed writes)
   constexpr int VROW = TT + 2;  // elements per d row of the V tile
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_tile_kernel(
     if (s < 0) continue;
     const int64_t b = s / block_size;
     const int o = (int)(s - b * block_size);
-    uint16_t* dst = key_cache + (((b * num_heads + head) * cph + j) * (int64_t)block_size + o) * 8;
+    uint16_t* dst = key_cache + b * block_stride + ((((int64_t)head * cph + j) * (int64_t)block_size + o) * 8);
     *reinterpret_cast<uint4*>(dst) = kt[j * KROW + tok];
   }
   // V out: thread (d, group), group fastest
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_tile_kernel(
     const int64_t s = slots[ts];
     const int64_t b = s / block_size;
     const int o = (int)(s - b * block_size);
-    uint16_t* dst = value_cache + ((b * num_heads + head) * (int64_t)head_size + d) * block_size + o;
+    uint16_t* dst = value_cache + b * block_stride + (((int64_t)head * head_size + d) * block_size + o);
     const uint16_t* src = vt + d * VROW + ts;
     if (len == 8) {
       alignas(16) uint16_t e[8];
@@ -296,14 +294,28 @@ extern "C" int lvllm_reshape_and_cache(
     const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
     int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
     int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, void* stream) {
+  return lvllm_reshape_and_cache_strided(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads,
+                                         head_size, block_size, x, key_stride, value_stride, dtype, kv_dtype, k_scale,
+                                         v_scale, kv_cache_bytes, (int64_t)num_heads * head_size * block_size, stream);
+}
+
+extern "C" int lvllm_reshape_and_cache_strided(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int x, int64_t key_stride, int64_t value_stride, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream) {
   LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
   if (num_tokens == 0) return 0;
   const int esize = dtype == LVLLM_F32 ? 4 : 2;
   LV_CHECK(num_heads > 0 && head_size > 0 && block_size > 0, "num_heads, head_size, block_size must be positive");
+  LV_CHECK(kv_block_stride >= (int64_t)num_heads * head_size * block_size,
+           "kv_block_stride is smaller than one block");
+  LV_CHECK((kv_block_stride * (kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : esize)) % 16 == 0,
+           "kv_block_stride must be a multiple of 16 bytes");
   // slots the caches hold, from the extent the caller states (0: not stated): a slot beyond it is skipped
   // like a padding slot instead of being written outside the allocation
   const int64_t cache_esize = kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : esize;
-  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_heads * head_size * cache_esize)
+  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / (kv_block_stride * cache_esize) * block_size
                                                : INT64_MAX;
   LV_CHECK(dtype == LVLLM_F32 || dtype == LVLLM_F16 || dtype == LVLLM_BF16, "unsupported dtype");
   if (kv_dtype == LVLLM_KV_FP8_E4M3) {
@@ -319,7 +331,7 @@ extern "C" int lvllm_reshape_and_cache(
         (reshape_and_cache_fp8_kernel<scalar_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
         (const typename scalar_t::store_t*)key, (const typename scalar_t::store_t*)value, (uint8_t*)key_cache,
         (uint8_t*)value_cache, slot_mapping, num_chunks, chunks_per_head, num_heads, head_size, block_size,
-        key_stride, value_stride, k_scale, v_scale, num_slots));
+        key_stride, value_stride, k_scale, v_scale, num_slots, kv_block_stride));
     LV_LAUNCH_CHECK();
     return 0;
   }
@@ -345,7 +357,7 @@ extern "C" int lvllm_reshape_and_cache(
     hipLaunchKernelGGL(reshape_and_cache_tile_kernel, dim3((num_tokens + kTileTokens - 1) / kTileTokens, num_heads),
                        dim3(256), smem, s, (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
                        (uint16_t*)value_cache, slot_mapping, num_tokens, num_heads, head_size, block_size,
-                       key_stride, value_stride, num_slots);
+                       key_stride, value_stride, num_slots, kv_block_stride);
     LV_LAUNCH_CHECK();
     return 0;
   }
@@ -353,12 +365,14 @@ extern "C" int lvllm_reshape_and_cache(
     hipLaunchKernelGGL((reshape_and_cache_kernel<uint16_t, 8>), dim3(grid), dim3(threads), 0, s,
                        (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)key_cache,
                        (uint16_t*)value_cache, slot_mapping, num_chunks, chunks_per_head,
-                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots);
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots,
+                       kv_block_stride);
   } else {
     hipLaunchKernelGGL((reshape_and_cache_kernel<float, 4>), dim3(grid), dim3(threads), 0, s,
                        (const float*)key, (const float*)value, (float*)key_cache,
                        (float*)value_cache, slot_mapping, num_chunks, chunks_per_head,
-                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots);
+                       num_heads, head_size, block_size, key_stride, value_stride, vec_ok, num_slots,
+                       kv_block_stride);
   }
   LV_LAUNCH_CHECK();
   return 0;

@@ -109,7 +109,7 @@ __global__ void rotary_embedding_and_cache_kernel(
     void* __restrict__ value_cache_v, const int64_t* __restrict__ slot_mapping,
     const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
     const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale,
-    const int64_t num_slots) {
+    const int64_t num_slots, const int64_t block_stride) {  // block_stride: cache elements between blocks
   LVLLM_TRACE_BEGIN();
   using S = typename T::store_t;
   using V = Vec16<T>;
@@ -129,8 +129,8 @@ __global__ void rotary_embedding_and_cache_kernel(
   const int64_t block_off = slot >= 0 ? slot % block_size : 0;
   // 8 elements of head `head` starting at d (a multiple of 8) -> their 8 bytes inside the x = 16 chunk
   auto store_k8 = [&](const V& x, const int head, const int d) {
-    uint8_t* dst = key_cache8 + ((block_idx * num_kv_heads + head) * (head_size / 16) + d / 16) *
-                                    (int64_t)block_size * 16 + block_off * 16 + (d % 16);
+    uint8_t* dst = key_cache8 + block_idx * block_stride +
+                   ((int64_t)head * (head_size / 16) + d / 16) * (int64_t)block_size * 16 + block_off * 16 + (d % 16);
     uint2 q;
     q.x = fp8_kv_quant4(T::to_float(x.v[0]), T::to_float(x.v[1]), T::to_float(x.v[2]), T::to_float(x.v[3]), k_scale);
     q.y = fp8_kv_quant4(T::to_float(x.v[4]), T::to_float(x.v[5]), T::to_float(x.v[6]), T::to_float(x.v[7]), k_scale);
@@ -147,7 +147,7 @@ __global__ void rotary_embedding_and_cache_kernel(
       const int head = j / rot_units, u = j - head * rot_units;
       S* base = is_k ? key + token * key_stride + (int64_t)head * head_size
                      : query + token * query_stride + (int64_t)head * head_size;
-      S* kc = key_cache + ((block_idx * num_kv_heads + head) * cph) * (int64_t)block_size * N + block_off * N;
+      S* kc = key_cache + block_idx * block_stride + ((int64_t)head * cph) * (int64_t)block_size * N + block_off * N;
       if constexpr (IS_NEOX) {
         V x = *reinterpret_cast<const V*>(base + u * N);
         V y = *reinterpret_cast<const V*>(base + embed_dim + u * N);
@@ -184,7 +184,8 @@ __global__ void rotary_embedding_and_cache_kernel(
       const int head = j / cph, ch = j - head * cph;
       const V v = *reinterpret_cast<const V*>(value + token * value_stride + (int64_t)head * head_size + ch * N);
       if constexpr (KV8) {
-        uint8_t* vdst = value_cache8 + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
+        uint8_t* vdst = value_cache8 + block_idx * block_stride +
+                        ((int64_t)head * head_size + ch * N) * (int64_t)block_size + block_off;
 #pragma unroll
         for (int e = 0; e < N; e += 4) {
           const uint32_t w = fp8_kv_quant4(T::to_float(v.v[e]), T::to_float(v.v[e + 1]), T::to_float(v.v[e + 2]),
@@ -195,7 +196,8 @@ __global__ void rotary_embedding_and_cache_kernel(
           vdst[(int64_t)(e + 3) * block_size] = (uint8_t)(w >> 24);
         }
       } else {
-        S* vdst = value_cache + ((block_idx * num_kv_heads + head) * head_size + ch * N) * (int64_t)block_size + block_off;
+        S* vdst = value_cache + block_idx * block_stride + ((int64_t)head * head_size + ch * N) * (int64_t)block_size +
+                  block_off;
 #pragma unroll
         for (int e = 0; e < N; ++e) vdst[(int64_t)e * block_size] = v.v[e];
       }
@@ -272,7 +274,23 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, void* stream) {
+  return lvllm_rotary_embedding_and_cache_strided(positions, query, key, value, num_tokens, num_heads, num_kv_heads,
+                                                  head_size, rot_dim, query_stride, key_stride, value_stride,
+                                                  cos_sin_cache, is_neox, key_cache, value_cache, slot_mapping,
+                                                  block_size, dtype, kv_dtype, k_scale, v_scale, kv_cache_bytes,
+                                                  (int64_t)num_kv_heads * head_size * block_size, stream);
+}
+
+extern "C" int lvllm_rotary_embedding_and_cache_strided(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream) {
   if (num_tokens == 0) return 0;
+  LV_CHECK(kv_block_stride >= (int64_t)num_kv_heads * head_size * block_size &&
+               (kv_block_stride * (kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : 2)) % 16 == 0,
+           "kv_block_stride: at least one block, a multiple of 16 bytes");
   LV_CHECK(kv_dtype == LVLLM_KV_AUTO || kv_dtype == LVLLM_KV_FP8_E4M3, "unsupported kv_cache_dtype");
   const bool kv8 = kv_dtype == LVLLM_KV_FP8_E4M3;
   LV_CHECK(kv8 ? (k_scale > 0.f && v_scale > 0.f) : (k_scale == 1.f && v_scale == 1.f),
@@ -285,7 +303,7 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
     set_error("lvllm_rotary_embedding_and_cache: arguments outside the fused kernel's envelope");
     return 3;
   }
-  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / ((int64_t)num_kv_heads * head_size * (kv8 ? 1 : 2))
+  const int64_t num_slots = kv_cache_bytes > 0 ? kv_cache_bytes / (kv_block_stride * (kv8 ? 1 : 2)) * block_size
                                                : INT64_MAX;
   const int units = (num_heads + num_kv_heads) * (is_neox ? head_size / 16 : head_size / 8) + num_kv_heads * head_size / 8;
   int threads = ((units + 63) / 64) * 64;
@@ -295,7 +313,7 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
                      (hipStream_t)stream, positions, (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value, \
                      (const uint16_t*)cos_sin_cache, key_cache, value_cache, slot_mapping, query_stride,      \
                      key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size, k_scale, v_scale, \
-                     num_slots)
+                     num_slots, kv_block_stride)
 #define LV_RC_N(T_)                                   \
   do {                                                \
     if (is_neox) {                                    \

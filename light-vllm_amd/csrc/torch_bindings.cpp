@@ -56,6 +56,18 @@ int64_t cache_extent_bytes(const torch::Tensor& key_cache, const torch::Tensor& 
   return k < v ? k : v;
 }
 
+// A paged cache as the kernels address it: every block dense ([KVH, D/x, BS, x] or [KVH, D, BS] contiguous), blocks
+// stride(0) elements apart -- the dense product, or more when the allocation pads its blocks.
+bool blocks_are_dense(const torch::Tensor& t) {
+  if (t.dim() < 2) return t.is_contiguous();
+  int64_t expect = 1;
+  for (int64_t d = t.dim() - 1; d >= 1; --d) {
+    if (t.size(d) != 1 && t.stride(d) != expect) return false;
+    expect *= t.size(d);
+  }
+  return t.stride(0) >= expect;
+}
+
 void* current_stream(const torch::Tensor& t) {
   return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
@@ -181,7 +193,11 @@ void swap_blocks(torch::Tensor& src, torch::Tensor& dst, const torch::Tensor& bl
   TORCH_CHECK(block_mapping.device().is_cpu(), "block_mapping must be on CPU");
   TORCH_CHECK(block_mapping.scalar_type() == at::kLong, "block_mapping must be int64");
   auto bm = block_mapping.contiguous();
-  const int64_t block_bytes = src.element_size() * src[0].numel();
+  // a block and its padding, if the allocation pads (both sides must pad alike: runs of blocks move as one copy)
+  TORCH_CHECK(blocks_are_dense(src) && blocks_are_dense(dst) && src.dim() >= 1 && dst.dim() >= 1 &&
+                  src.stride(0) == dst.stride(0) && src.element_size() == dst.element_size(),
+              "swap_blocks: src and dst must have dense blocks and the same block stride");
+  const int64_t block_bytes = src.element_size() * src.stride(0);
   const torch::Tensor& dev_t = src_dev ? src : dst;
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(dev_t));
   check(lvllm_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr<int64_t>(), (int)bm.size(0),
@@ -227,7 +243,13 @@ void copy_blocks(std::vector<torch::Tensor> const& key_caches,
   }
   // the kernel reads block_mapping on the device (csrc/cache_kernels.cu:79-80)
   torch::Tensor bm = block_mapping.to(dev, torch::kInt64, /*non_blocking=*/true).contiguous();
-  const int64_t block_bytes = key_caches[0].element_size() * key_caches[0][0].numel();
+  // (a block and its padding, if the allocation pads: every layer's caches pad alike)
+  for (int l = 0; l < num_layers; ++l)
+    TORCH_CHECK(blocks_are_dense(key_caches[l]) && blocks_are_dense(value_caches[l]) &&
+                    key_caches[l].stride(0) == key_caches[0].stride(0) &&
+                    value_caches[l].stride(0) == key_caches[0].stride(0),
+                "copy_blocks: dense blocks, one block stride for every cache");
+  const int64_t block_bytes = key_caches[0].element_size() * key_caches[0].stride(0);
   const int64_t* base = table.dev.data_ptr<int64_t>();
   check(lvllm_copy_blocks((const void* const*)base, (const void* const*)(base + num_layers),
                           bm.data_ptr<int64_t>(), num_layers, num_pairs, block_bytes,
@@ -240,18 +262,20 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value, torch::Tensor& 
                        const double v_scale) {
   LV_CHECK_DEVICE(key);
   TORCH_CHECK(slot_mapping.scalar_type() == at::kLong, "slot_mapping must be int64");
-  TORCH_CHECK(key_cache.is_contiguous() && value_cache.is_contiguous(),
-              "key_cache / value_cache must be contiguous");
+  TORCH_CHECK(blocks_are_dense(key_cache) && blocks_are_dense(value_cache) &&
+                  key_cache.stride(0) == value_cache.stride(0),
+              "key_cache / value_cache: dense blocks, the same block stride");
   check_cache_dtype(key_cache, key, kv_dtype_code(kv_cache_dtype), "reshape_and_cache");
   check_cache_dtype(value_cache, key, kv_dtype_code(kv_cache_dtype), "reshape_and_cache");
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(key));
-  check(lvllm_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
-                                value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
-                                (int)key.size(0), (int)key.size(1), (int)key.size(2),
-                                (int)key_cache.size(3), (int)key_cache.size(4), key.stride(0),
-                                value.stride(0), dtype_code(key, "reshape_and_cache"),
-                                kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale,
-                                cache_extent_bytes(key_cache, value_cache), current_stream(key)));
+  check(lvllm_reshape_and_cache_strided(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
+                                        value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
+                                        (int)key.size(0), (int)key.size(1), (int)key.size(2),
+                                        (int)key_cache.size(3), (int)key_cache.size(4), key.stride(0),
+                                        value.stride(0), dtype_code(key, "reshape_and_cache"),
+                                        kv_dtype_code(kv_cache_dtype), (float)k_scale, (float)v_scale,
+                                        cache_extent_bytes(key_cache, value_cache), key_cache.stride(0),
+                                        current_stream(key)));
 }
 
 void reshape_and_cache_flash(torch::Tensor& key, torch::Tensor& value, torch::Tensor& key_cache,
@@ -483,13 +507,16 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
   check_cache_dtype(value_cache, query, kv_code, "rotary_embedding_and_cache");
   const int64_t num_tokens = query.numel() / query.size(-1);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(query));
-  const int rc = lvllm_rotary_embedding_and_cache_ex(
+  TORCH_CHECK(blocks_are_dense(key_cache) && blocks_are_dense(value_cache) &&
+                  key_cache.stride(0) == value_cache.stride(0),
+              "key_cache / value_cache: dense blocks, the same block stride");
+  const int rc = lvllm_rotary_embedding_and_cache_strided(
       positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(), (int)num_tokens,
       (int)(query.size(-1) / head_size), (int)(key.size(-1) / head_size), (int)head_size,
       (int)cos_sin_cache.size(1), query.stride(-2), key.stride(-2), value.stride(-2), cos_sin_cache.data_ptr(),
       is_neox ? 1 : 0, key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
       (int)value_cache.size(3), dtype_code(query, "rotary_embedding_and_cache"), kv_code, (float)k_scale,
-      (float)v_scale, cache_extent_bytes(key_cache, value_cache), current_stream(query));
+      (float)v_scale, cache_extent_bytes(key_cache, value_cache), key_cache.stride(0), current_stream(query));
   if (rc == 3) return false;
   check(rc);
   return true;

@@ -31,11 +31,28 @@ class CacheEngine:
         self.cpu_cache = self._allocate(self.num_cpu_blocks, torch.device("cpu"))
 
     def _allocate(self, num_blocks: int, where: torch.device) -> List[torch.Tensor]:
+        """One [2, num_blocks, block elements] tensor per layer (the reference's shape, cache_engine.py:69-86), each a
+        view of a buffer whose rows are `block_pad_bytes` longer: the ops address blocks by the tensors' strides, the
+        CPU side pads alike so that runs of blocks swap as single copies."""
         shape = self.attn_backend.get_kv_cache_shape(num_blocks, self.block_size, self.num_kv_heads, self.head_size)
         on_host = where.type == "cpu"
         pinned = on_host and num_blocks > 0 and torch.cuda.is_available()  # swaps are async DMA
-        return [torch.zeros(shape, dtype=self.dtype, device=where, pin_memory=pinned)
-                for _ in range(self.num_attention_layers)]
+        pad = self.block_pad_elements(self.cache_config, self.dtype)
+        out = []
+        for _ in range(self.num_attention_layers):
+            if pad == 0:
+                out.append(torch.zeros(shape, dtype=self.dtype, device=where, pin_memory=pinned))
+            else:
+                buf = torch.zeros(shape[0], shape[1], shape[2] + pad, dtype=self.dtype, device=where, pin_memory=pinned)
+                out.append(buf[:, :, :shape[2]])
+        return out
+
+    @staticmethod
+    def block_pad_elements(cache_config: CacheConfig, dtype: torch.dtype) -> int:
+        pad_bytes = getattr(cache_config, "block_pad_bytes", 0) or 0
+        if pad_bytes % 16 != 0 or pad_bytes < 0:
+            raise ValueError("block_pad_bytes must be a non-negative multiple of 16")
+        return pad_bytes // torch.empty((), dtype=dtype).element_size()
 
     # ---- block movement: [n, 2] (source block, destination block) pairs ----
     def _swap(self, src: List[torch.Tensor], dst: List[torch.Tensor], pairs: torch.Tensor) -> None:
@@ -67,3 +84,10 @@ class CacheEngine:
                     model_config.num_key_value_heads * model_config.head_dim)
         dtype = CacheEngine.kv_cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
         return elements * torch.empty((), dtype=dtype).element_size()
+
+    @staticmethod
+    def get_cache_block_footprint(cache_config: CacheConfig, model_config: ModelConfig) -> int:
+        """Bytes of memory a block costs: the reference's figure above + the padding behind the block in both planes of
+        every layer (CacheConfig.block_pad_bytes).  What the worker divides the free memory by."""
+        pad = 2 * model_config.num_hidden_layers * (getattr(cache_config, "block_pad_bytes", 0) or 0)
+        return CacheEngine.get_cache_block_size(cache_config, model_config) + pad

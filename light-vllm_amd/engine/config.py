@@ -64,6 +64,12 @@ class CacheConfig:
     num_cpu_blocks: Optional[int] = None
     sliding_window: Optional[int] = None
     enable_prefix_caching: bool = False
+    # bytes between the end of a block and the start of the next in each K / V plane (a multiple of 16).  Blocks a power
+    # of two apart (32 KiB for 8 kv heads x 128 x 16 tokens of bf16) put tile t of EVERY sequence of a freshly
+    # filled cache on the same HBM channels -- sequence i's blocks start i x 2 MiB in -- and the decode attention
+    # launch runs 12 % slower than over scattered blocks; 1 KiB of padding (3 % of the cache) removes that
+    # (profiles/r03_tuning.md section 9).  The ops take the stride from the tensors; 0 = the reference's dense layout.
+    block_pad_bytes: int = 1024
 
 
 @dataclass

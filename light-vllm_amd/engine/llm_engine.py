@@ -166,7 +166,7 @@ class Worker:
         self.profile_run(scheduler_config)
         torch.cuda.synchronize(self.device)
         free_after_profile, total = torch.cuda.mem_get_info(self.device)
-        block_bytes = CacheEngine.get_cache_block_size(self.cache_config, self.model_config)
+        block_bytes = CacheEngine.get_cache_block_footprint(self.cache_config, self.model_config)
         out = self.kv_blocks_from_profile(total, self.init_gpu_memory, free_after_load, free_after_profile,
                                           self.cache_config.gpu_memory_utilization, scheduler_config.scheduling,
                                           block_bytes, self.cache_config.swap_space_bytes,

@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--head-size", type=int, default=128)
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--ncaches", type=int, default=10)
+    ap.add_argument("--contiguous", action="store_true",
+                    help="sequence i owns blocks i * nblk .. (what a block manager hands out at prefill) instead of a random permutation")
+    ap.add_argument("--block-pad", type=int, default=0,
+                    help="bytes added to the block stride of the caches (a strided view; the kernels take the stride)")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv", default="auto", choices=["auto", "fp8"])
@@ -43,7 +47,18 @@ def main():
         else:
             kc = (torch.randn(NB, KVH, D // x, BS, x, device=dev) * 0.5).to(dt)
             vc = (torch.randn(NB, KVH, D, BS, device=dev) * 0.5).to(dt)
-        bt = torch.randperm(NB, device=dev)[: B * nblk].view(B, nblk).to(torch.int32)
+        if a.block_pad:
+            def padded(t):
+                per = t[0].numel()
+                pad = a.block_pad // t.element_size()
+                buf = torch.empty(NB, per + pad, dtype=t.dtype, device=dev)
+                buf[:, :per] = t.reshape(NB, per)
+                return buf[:, :per].view(t.shape)  # stride(0) = per + pad
+            kc, vc = padded(kc), padded(vc)
+        if a.contiguous:
+            bt = torch.arange(B * nblk, device=dev).view(B, nblk).to(torch.int32)
+        else:
+            bt = torch.randperm(NB, device=dev)[: B * nblk].view(B, nblk).to(torch.int32)
         caches.append((kc, vc, bt))
     q = (torch.randn(B, H, D, device=dev) * 0.5).to(dt)
     seq_lens = torch.full((B,), L, dtype=torch.int32, device=dev)
