@@ -61,6 +61,10 @@ __device__ __forceinline__ g_f32x4_t gemm_mfma_fp8(uint32_t a0, uint32_t a1, uin
 }
 
 constexpr int kGemmWaves = 8;
+// diagnosis builds (tools/ab_gemm_tile_pad.py): bytes between the 16-row tiles of a packed weight beyond their size
+#ifndef LVLLM_GEMM_TILE_PAD
+#define LVLLM_GEMM_TILE_PAD 0
+#endif
 #ifdef LVLLM_GEMM_TRACE  // diagnosis build only (tools/trace_gemm.py): per-workgroup phase timestamps
 __device__ unsigned long long g_gemm_trace[8 * 4096];
 #define GEMM_TRACE(p)                                                                     \
@@ -119,14 +123,14 @@ __global__ __launch_bounds__(kGemmWaves * 64, 2) void skinny_gemm_kernel(
   nvalid = nvalid < 0 ? 0 : (nvalid > steps_per_wave ? steps_per_wave : nvalid);
 
   g_u32x4_t xf[MT][KSTEPS];  // filled after the first weight loads have been issued (below)
-  __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)N * K * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)w, 0, (int)((int64_t)N * K * 2 + (PACKED ? (int64_t)(N / 16) * LVLLM_GEMM_TILE_PAD : 0)), 0x00020000);
   // byte offset of this lane inside a 16-row tile at k-step step0, the byte stride between
   // k-steps, and between tiles
   const unsigned lane_off = PACKED ? (unsigned)(lane * 16 + step0 * 1024)
                                    : (unsigned)(((int64_t)c * K + (int64_t)step0 * 32 + 8 * g) * 2);
   const unsigned step_stride = PACKED ? 1024u : 64u;
-  const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2);
+  const unsigned tile_stride = (unsigned)((int64_t)16 * K * 2) + (PACKED ? LVLLM_GEMM_TILE_PAD : 0);
 
   // Which n-tiles this workgroup owns.  Plain: tile blockIdx.x + i * gridDim.x for local index i.
   // glu (act == 2, W = [gate rows | up rows]): the workgroup owns PAIRS -- local tiles 2j and 2j+1
@@ -1027,7 +1031,7 @@ __global__ void pack_weight_kernel(uint4* __restrict__ dst, const uint4* __restr
   const int64_t t = ts / steps;
   const int s = (int)(ts - t * steps);
   const int64_t n = t * 16 + c, k = (int64_t)s * 32 + g * 8;
-  dst[i] = src[(n * K + k) >> 3];
+  dst[i + t * (LVLLM_GEMM_TILE_PAD / 16)] = src[(n * K + k) >> 3];
 }
 
 }  // namespace lvllm
