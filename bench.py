@@ -702,6 +702,7 @@ def main():
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
     blocks = B * slots * ((max_len + bs - 1) // bs + 1) + 64
+    from light_vllm_amd.engine.cache_engine import CacheEngine
     cache_cfg = CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0, cache_dtype=a.kv_cache_dtype)
     if a.kv_block_pad_bytes is not None:
         cache_cfg.block_pad_bytes = a.kv_block_pad_bytes
@@ -832,7 +833,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
                                    f"decode bs={B} per step, context {ctx} at the first step growing to {int(ctx_end)}, "
-                                   f"block_size 16 (blocks {engine.cache_config.block_pad_bytes} bytes apart beyond their "
+                                   f"block_size 16 (blocks {CacheEngine.block_pad_bytes(engine.cache_config, engine.model_config)} bytes apart beyond their "
                                    f"size), {a.scheduling} scheduling ({on_the_fly} batches in flight, one stream "
                                    f"each), {k} model steps per engine step"
                                    + (" (advance_step on the device between them)" if k > 1 else "") +

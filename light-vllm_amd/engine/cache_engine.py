@@ -37,7 +37,7 @@ class CacheEngine:
         shape = self.attn_backend.get_kv_cache_shape(num_blocks, self.block_size, self.num_kv_heads, self.head_size)
         on_host = where.type == "cpu"
         pinned = on_host and num_blocks > 0 and torch.cuda.is_available()  # swaps are async DMA
-        pad = self.block_pad_elements(self.cache_config, self.dtype)
+        pad = self.block_pad_bytes(self.cache_config, self.model_config) // torch.empty((), dtype=self.dtype).element_size()
         out = []
         for _ in range(self.num_attention_layers):
             if pad == 0:
@@ -48,11 +48,17 @@ class CacheEngine:
         return out
 
     @staticmethod
-    def block_pad_elements(cache_config: CacheConfig, dtype: torch.dtype) -> int:
-        pad_bytes = getattr(cache_config, "block_pad_bytes", 0) or 0
-        if pad_bytes % 16 != 0 or pad_bytes < 0:
+    def block_pad_bytes(cache_config: CacheConfig, model_config: ModelConfig) -> int:
+        """Bytes between a block and the next in a plane (CacheConfig.block_pad_bytes; None: 1/32 of the block)."""
+        pad = getattr(cache_config, "block_pad_bytes", 0)
+        if pad is None:
+            dtype = CacheEngine.kv_cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
+            plane = (cache_config.block_size * model_config.num_key_value_heads * model_config.head_dim *
+                     torch.empty((), dtype=dtype).element_size())
+            pad = ((plane // 32 + 255) // 256) * 256
+        if pad % 16 != 0 or pad < 0:
             raise ValueError("block_pad_bytes must be a non-negative multiple of 16")
-        return pad_bytes // torch.empty((), dtype=dtype).element_size()
+        return pad
 
     # ---- block movement: [n, 2] (source block, destination block) pairs ----
     def _swap(self, src: List[torch.Tensor], dst: List[torch.Tensor], pairs: torch.Tensor) -> None:
@@ -89,5 +95,5 @@ class CacheEngine:
     def get_cache_block_footprint(cache_config: CacheConfig, model_config: ModelConfig) -> int:
         """Bytes of memory a block costs: the reference's figure above + the padding behind the block in both planes of
         every layer (CacheConfig.block_pad_bytes).  What the worker divides the free memory by."""
-        pad = 2 * model_config.num_hidden_layers * (getattr(cache_config, "block_pad_bytes", 0) or 0)
+        pad = 2 * model_config.num_hidden_layers * CacheEngine.block_pad_bytes(cache_config, model_config)
         return CacheEngine.get_cache_block_size(cache_config, model_config) + pad

@@ -68,8 +68,10 @@ class CacheConfig:
     # of two apart (32 KiB for 8 kv heads x 128 x 16 tokens of bf16) put tile t of EVERY sequence of a freshly
     # filled cache on the same HBM channels -- sequence i's blocks start i x 2 MiB in -- and the decode attention
     # launch runs 12 % slower than over scattered blocks; 1 KiB of padding (3 % of the cache) removes that
-    # (profiles/r03_tuning.md section 9).  The ops take the stride from the tensors; 0 = the reference's dense layout.
-    block_pad_bytes: int = 1024
+    # (profiles/r03_tuning.md section 9).  The ops take the stride from the tensors; 0 = the reference's dense layout;
+    # None = 1/32 of a block's bytes in one plane, in multiples of 256 (1 KiB for the shapes above, 512 bytes for their
+    # fp8 cache, where 512 measured as well as 1 024).
+    block_pad_bytes: Optional[int] = None
 
 
 @dataclass

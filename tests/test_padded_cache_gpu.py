@@ -162,7 +162,8 @@ def test_copy_and_swap_of_padded_blocks(ops):
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_engine_tokens_do_not_depend_on_the_padding(graph):
-    """The engine with block_pad_bytes = 1024 (as shipped) and 0 (the reference's dense layout): same greedy tokens, with
+    """The engine with block_pad_bytes = 1024 (what None resolves to for an 8B model's bf16 blocks), with the default
+    and with 0 (the reference's dense layout): same greedy tokens, with
     prompts, decode steps, chunked prefill and swap-outs in the run (22 blocks for 6 sequences)."""
     import light_vllm_amd  # noqa: F401
     from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
@@ -176,7 +177,8 @@ def test_engine_tokens_do_not_depend_on_the_padding(graph):
                                         chunked_prefill_enabled=True, preemption_mode="swap", max_num_on_the_fly=2),
                         device=DEV, use_hip_graph=graph, seed=0)
         kv = eng.worker.cache_engine.gpu_cache[0]
-        assert kv.stride(1) * kv.element_size() == 2 * 64 * 16 * 2 + pad  # tiny model: 2 kv heads x 64 x 16 tokens of bf16
+        # tiny model: blocks of 2 kv heads x 64 x 16 tokens of bf16 = 4 KiB; None = 1/32 of that, in multiples of 256
+        assert kv.stride(1) * kv.element_size() == 2 * 64 * 16 * 2 + (256 if pad is None else pad)
         return run_to_completion(eng, max_tokens=40)
 
-    assert run(1024) == run(0)
+    assert run(1024) == run(0) == run(None)
