@@ -714,6 +714,7 @@ def main():
                        device=dev, use_hip_graph=not a.no_graph,
                        decode_version=None if a.attn_version == "auto" else a.attn_version, seed=rank)
     engine.step_returns_outputs = False
+    block_pad = CacheEngine.block_pad_bytes(engine.cache_config, engine.model_config)
     if a.gemm_partials_ksplit is not None:
         torch.ops._C_amd.set_tuning("gemm_partials_ksplit", a.gemm_partials_ksplit)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -833,7 +834,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Llama-3-8B shapes (L32 H32 KVH8 D128 hidden4096 inter14336 vocab128256), "
                                    f"decode bs={B} per step, context {ctx} at the first step growing to {int(ctx_end)}, "
-                                   f"block_size 16 (blocks {CacheEngine.block_pad_bytes(engine.cache_config, engine.model_config)} bytes apart beyond their "
+                                   f"block_size 16 (blocks {block_pad} bytes apart beyond their "
                                    f"size), {a.scheduling} scheduling ({on_the_fly} batches in flight, one stream "
                                    f"each), {k} model steps per engine step"
                                    + (" (advance_step on the device between them)" if k > 1 else "") +
