@@ -129,8 +129,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void paged_prefill_chunk_kernel(con
 
   int t0 = 0, t1 = khi;
   if (sc.tmp_out != nullptr) {
+    // (the last partition is open-ended: a context longer than the caller's max_seq_len is walked, not cut off)
     t0 = part * sc.part_tokens;
-    t1 = min(khi, t0 + sc.part_tokens);
+    t1 = part + 1 == sc.num_parts ? khi : min(khi, t0 + sc.part_tokens);
     if (t0 >= khi) return;  // no row of this workgroup reaches the partition: the reduce never reads it
   }
   const int ntiles = (t1 - t0 + 15) >> 4;

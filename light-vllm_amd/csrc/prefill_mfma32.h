@@ -153,7 +153,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   int j0 = 0;
   if (sc.tmp_out != nullptr) {
     j0 = part * (sc.part_tokens / KT);
-    ntiles = min(ntiles, j0 + sc.part_tokens / KT);
+    // (the last partition is open-ended: a context longer than the caller's max_seq_len is walked, not cut off)
+    if (part + 1 < sc.num_parts) ntiles = min(ntiles, j0 + sc.part_tokens / KT);
     my_ntiles = min(my_ntiles, ntiles);
     if (j0 >= ntiles) return;
   }

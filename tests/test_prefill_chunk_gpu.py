@@ -172,3 +172,11 @@ def test_workspace_rule(ops):
     assert f(2, 64, 32, 32, 8, 128, 4096) > 0       # chunks only: the 32x32 body, which cuts its walk too
     assert f(64, 2048, 32, 32, 8, 128, 4096) == 0   # ... unless the launch fills the CUs by itself
     assert f(2, 3, 2, 32, 8, 128, 4096) > 0
+
+
+def test_partitioned_walk_with_an_understated_bound_still_walks_every_key(ops):
+    """max_seq_len is the caller's promise; a context longer than it is still walked to its end (the last partition is
+    open-ended)."""
+    inp = make_prefill_inputs(8, 2, 128, 16, [2080, 1500, 900], [2, 1, 1], dtype=torch.bfloat16, seed=13)
+    out = run_hip(ops, inp, max_seq_len=1024)  # half the real length
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))

@@ -265,3 +265,16 @@ def test_partitioned_key_walk_ignores_garbage_past_the_sequences(ops):
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
+
+
+def test_partitioned_key_walk_with_an_understated_bound_still_walks_every_key(ops):
+    """max_seq_len is the caller's promise; a context longer than it (a graph captured for shorter ones) is still walked
+    to its end -- the last partition is open-ended."""
+    inp = make_prefill_inputs(8, 2, 128, 16, [2080, 1500], [32, 20], dtype=torch.bfloat16, seed=13)
+    d = to_dev(inp)
+    out = torch.full_like(d["query"], float("nan"))
+    ops.paged_prefill_attention(out, d["query"], d["key_cache"], d["value_cache"], 2, inp["scale"], d["block_tables"],
+                                d["seq_lens"], d["query_start_loc"], inp["max_query_len"], 16, None, 0, 0.0, "auto",
+                                True, 1.0, 1.0, 1024)  # half the real length
+    torch.cuda.synchronize()
+    check_attention(out, run_oracle(inp), dense_prefill_fp64(inp))
