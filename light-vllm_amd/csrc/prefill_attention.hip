@@ -114,6 +114,9 @@ extern "C" int lvllm_paged_prefill_attention_ws(
 // ---- dense varlen attention: pack K/V into paged tiles in the workspace, then the kernel above ----
 namespace lvllm {
 
+#ifndef LVLLM_VARLEN_BLOCK_PAD
+#define LVLLM_VARLEN_BLOCK_PAD 1
+#endif
 constexpr int kVarlenBS = 16;  // block size of the scratch tiles (16: every K/V tile load of the kernel is one contiguous KiB)
 
 // Sequence s owns the scratch blocks cu_seqlens[s] / BS + s + i, i < ceil(len_s / BS): consecutive
@@ -128,7 +131,7 @@ constexpr int kVarlenBS = 16;  // block size of the scratch tiles (16: every K/V
 __global__ __launch_bounds__(256) void varlen_pack_kernel(
     const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, uint16_t* __restrict__ key_cache,
     uint16_t* __restrict__ value_cache, const int32_t* __restrict__ cu_seqlens, const int num_kv_heads,
-    const int head_size, const int64_t key_stride, const int64_t value_stride) {
+    const int head_size, const int64_t key_stride, const int64_t value_stride, const int64_t block_stride) {
   extern __shared__ __attribute__((aligned(16))) uint16_t vt[];  // [head_size][kVarlenBS + 8] (padded rows)
   constexpr int ROW = kVarlenBS + 8;
   const int seq = blockIdx.z, head = blockIdx.y, blk = blockIdx.x;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void varlen_pack_kernel(
   if (tok0 >= len) return;
   const int chunks_per_head = head_size >> 3;
   const int64_t block = beg / kVarlenBS + seq + blk;
-  uint16_t* ktile = key_cache + (block * num_kv_heads + head) * (int64_t)head_size * kVarlenBS;
-  uint16_t* vtile = value_cache + (block * num_kv_heads + head) * (int64_t)head_size * kVarlenBS;
+  uint16_t* ktile = key_cache + block * block_stride + (int64_t)head * head_size * kVarlenBS;
+  uint16_t* vtile = value_cache + block * block_stride + (int64_t)head * head_size * kVarlenBS;
   const int nchunks = chunks_per_head * kVarlenBS;
   // K: destination order (d8, tok)
   for (int i = threadIdx.x; i < nchunks; i += blockDim.x) {
@@ -169,6 +172,8 @@ __global__ __launch_bounds__(256) void varlen_pack_kernel(
 
 struct VarlenLayout {
   int64_t cache_elems, off_v, total;
+  int64_t block_stride;  // elements between scratch blocks: one block + 1/32 of it (see CacheConfig.block_pad_bytes:
+                         // equal-length sequences start a power of two apart otherwise)
   int max_blocks_per_seq, num_blocks;
 };
 static VarlenLayout varlen_layout(int num_tokens, int num_seqs, int max_seq_len, int num_kv_heads,
@@ -177,7 +182,9 @@ static VarlenLayout varlen_layout(int num_tokens, int num_seqs, int max_seq_len,
   L.max_blocks_per_seq = (max_seq_len + kVarlenBS - 1) / kVarlenBS;
   if (L.max_blocks_per_seq < 1) L.max_blocks_per_seq = 1;
   L.num_blocks = num_tokens / kVarlenBS + num_seqs + 1;
-  L.cache_elems = (int64_t)L.num_blocks * kVarlenBS * num_kv_heads * head_size;
+  const int64_t block_elems = (int64_t)kVarlenBS * num_kv_heads * head_size;
+  L.block_stride = block_elems + (LVLLM_VARLEN_BLOCK_PAD ? ((block_elems / 32 + 127) / 128) * 128 : 0);
+  L.cache_elems = (int64_t)L.num_blocks * L.block_stride;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
   L.off_v = up(L.cache_elems * 2);
   L.total = L.off_v + up(L.cache_elems * 2);
@@ -215,12 +222,12 @@ extern "C" int lvllm_varlen_attention(
   const size_t smem = (size_t)head_size * (kVarlenBS + 8) * 2;
   hipLaunchKernelGGL(varlen_pack_kernel, dim3(L.max_blocks_per_seq, num_kv_heads, num_seqs), dim3(256), smem, s,
                      (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache,
-                     cu_seqlens, num_kv_heads, head_size, k_stride, v_stride);
+                     cu_seqlens, num_kv_heads, head_size, k_stride, v_stride, L.block_stride);
   LV_LAUNCH_CHECK();
   const int64_t head_stride = (int64_t)head_size * kVarlenBS;
   // block_tables = seq_lens = nullptr: arithmetic placement, context == chunk
   return lvllm_paged_prefill_attention(
       out, query, k_cache, v_cache, num_seqs, num_heads, head_size, num_kv_heads, scale, nullptr, nullptr,
       cu_seqlens, max_seq_len, kVarlenBS, L.max_blocks_per_seq, alibi_slopes, causal, sliding_window,
-      softcap, q_stride, out_stride, head_stride * num_kv_heads, head_stride, dtype, LVLLM_KV_AUTO, stream);
+      softcap, q_stride, out_stride, L.block_stride, head_stride, dtype, LVLLM_KV_AUTO, stream);
 }
