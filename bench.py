@@ -489,7 +489,7 @@ def fp8_config_leg(a, dev, B, ctx, steps=32):
     decode_region(eng, B, k * fly, k, fly)  # warm-up: one burst per slot
     toks, el = decode_region(eng, B, steps, k, fly)
     assert toks == steps * B, (toks, steps, B)
-    kl = kernel_leg(eng, B, 96, seq_len=ctx)
+    kl = kernel_leg(eng, B, a.kernel_iters, seq_len=ctx)
     gm = gemm_leg(eng, B) if B <= 64 else None
     L = cfg.num_hidden_layers
     kv_step = 2 * B * ctx * cfg.num_key_value_heads * cfg.head_dim * 1 * L
