@@ -44,6 +44,8 @@ struct SamplerParams {  // one per state slot; 128 bytes; the host writes it, th
 static_assert(sizeof(SamplerParams) == LVLLM_SAMPLER_PARAMS_BYTES, "include/lvllm_hip.h states the size");
 
 constexpr int kSamplerThreads = 1024;
+constexpr int kSamplerMaxParts = 8;      // workgroups that share the first pass of a row
+constexpr int kSamplerRowTail = 3 * kSamplerMaxParts + 8;  // (maxima | indices | counter | XCD ids)  // floats of a scratch row behind the (4-aligned) vocabulary
 constexpr float kSamplingEps = 1e-5f;  // sampling_params.py:14 (_SAMPLING_EPS)
 
 __device__ __forceinline__ uint32_t order_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
@@ -80,16 +82,17 @@ __device__ __forceinline__ float logit_to_float<F16Bits>(F16Bits v) { return F16
 // one is used.  One workgroup walks a whole row: a loop that waits for each 2- or 4-byte load in turn runs at the
 // memory latency (30 us for a 128 k row of bf16), so the passes below move 16-byte groups and keep several in flight.
 template <int U, typename LOAD, typename F>
-__device__ __forceinline__ void for_each_in_row(const int n, LOAD&& load, F&& f) {
-  int i = threadIdx.x;
-  for (; i + (U - 1) * kSamplerThreads < n; i += U * kSamplerThreads) {
+__device__ __forceinline__ void for_each_in_row(const int n, LOAD&& load, F&& f, const int first = 0) {
+  const int end = first + n;
+  int i = first + threadIdx.x;
+  for (; i + (U - 1) * kSamplerThreads < end; i += U * kSamplerThreads) {
     decltype(load(0)) v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = load(i + u * kSamplerThreads);
 #pragma unroll
     for (int u = 0; u < U; ++u) f(v[u], i + u * kSamplerThreads);
   }
-  for (; i < n; i += kSamplerThreads) f(load(i), i);
+  for (; i < end; i += kSamplerThreads) f(load(i), i);
 }
 
 template <typename V>
@@ -116,17 +119,19 @@ __device__ __forceinline__ Group<V> load_group(const V* __restrict__ row, const 
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// f(value, index) for every value of a row
+// f(value, index) for every value of a row -- or of its 16-byte groups [g0, g0 + ng) (ng < 0: all)
 template <typename V, typename F>
-__device__ __forceinline__ void for_each_value(const V* __restrict__ row, const int n, F&& f) {
+__device__ __forceinline__ void for_each_value(const V* __restrict__ row, const int n, F&& f, const int g0 = 0,
+                                               const int ng = -1) {
   constexpr int N = Group<V>::N;
   const bool al = aligned16(row);
-  for_each_in_row<4>((n + N - 1) / N, [&](int g) { return load_group<V>(row, g, n, al, V{}); },
+  const int groups = (n + N - 1) / N;
+  for_each_in_row<4>(ng < 0 ? groups : ng, [&](int g) { return load_group<V>(row, g, n, al, V{}); },
                      [&](const Group<V>& v, int g) {
 #pragma unroll
                        for (int e = 0; e < N; ++e)
                          if (g * N + e < n) f(v.v[e], g * N + e);
-                     });
+                     }, ng < 0 ? 0 : g0);
 }
 
 // (value, index) arg-max of the block, ties to the smaller index; result in every thread
@@ -312,15 +317,77 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   const int tid = threadIdx.x;
   const LT* lrow = logits + (int64_t)row * logits_stride;
   const int sid = state_slot != nullptr ? state_slot[row] : -1;
+  // gridDim.y workgroups share the FIRST pass of a row (its 16-byte groups cut into gridDim.y ranges): one workgroup
+  // = one CU does ~12 vector operations per element and pass whatever the memory delivers, 10-30 us for a 128 k row.
+  // Each leaves its partial arg-max in the row's tail of `scratch`; the one that arrives last (an atomic counter
+  // there, no waiting) merges them and carries on alone with the passes that need the whole row's maximum.
+  // The workgroups of a row meet through ONE L2: the launcher asks for the split only when rows % 8 == 0, so that
+  // workgroup (row, part) = linear id row + rows * part lands on XCD row % 8 for every part (workgroups go to the
+  // XCDs round-robin); stores reach that L2 (the L1 writes through), nothing is flushed or invalidated -- as
+  // device-scope fences the meeting cost 60 us (every workgroup wrote back and invalidated a whole L2).  Every part
+  // records the XCD it ran on; if they ever differ the last workgroup does the whole pass again by itself.
+  const int W = gridDim.y, part = blockIdx.y;
+  constexpr int NL = Group<LT>::N;
+  const int lgroups = (vocab + NL - 1) / NL;
+  const int share = (lgroups + W - 1) / W;
+  int g0 = part * share, ng = max(0, min(share, lgroups - g0));
+  float* tail = W > 1 ? scratch + (int64_t)row * scratch_stride + ((vocab + 3) & ~3) : nullptr;
+  __shared__ int s_last;
+  // 0: this workgroup is done; 1: it is the last one and (bv, bi) are the row's; 2: the last one, but the parts did
+  // not share an L2 -- run the pass again over the whole row (g0, ng reset)
+  auto merge_parts = [&](float& bv, int& bi) __attribute__((always_inline)) -> int {
+    if (W == 1) return 1;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the L2
+    __syncthreads();
+    if (tid == 0) {
+      tail[part] = bv;
+      reinterpret_cast<int*>(tail)[kSamplerMaxParts + part] = bi;
+      reinterpret_cast<int*>(tail)[2 * kSamplerMaxParts + 1 + part] = (int)(xcc & 0xf);
+      __builtin_amdgcn_s_waitcnt(0);
+      s_last = __hip_atomic_fetch_add(reinterpret_cast<int*>(tail) + 2 * kSamplerMaxParts, 1, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT) == W - 1;
+    }
+    __syncthreads();
+    if (!s_last) return 0;
+    if (tid == 0) reinterpret_cast<int*>(tail)[2 * kSamplerMaxParts] = 0;  // for the next launch
+    bv = -INFINITY;
+    bi = 0x7fffffff;
+    bool same_l2 = true;
+    for (int w = 0; w < W; ++w) {
+      const float v = __hip_atomic_load(tail + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int i = __hip_atomic_load(reinterpret_cast<int*>(tail) + kSamplerMaxParts + w, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+      const int x = __hip_atomic_load(reinterpret_cast<int*>(tail) + 2 * kSamplerMaxParts + 1 + w, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+      same_l2 = same_l2 && x == (int)(xcc & 0xf);
+      if (i != 0x7fffffff && (v > bv || (v == bv && i < bi) || bi == 0x7fffffff)) { bv = v; bi = i; }
+    }
+    if (same_l2) return 1;
+    g0 = 0;
+    ng = lgroups;
+    return 2;
+  };
 
   if (sid < 0 || sid >= num_slots) {  // plain greedy row: arg-max of the logits as they are
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for_each_value<LT>(lrow, vocab, [&](LT v, int i) {
-      const float x = logit_to_float<LT>(v);
-      if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
-    });
-    block_argmax(bv, bi, sv, si);
+    float bv;
+    int bi;
+    bool redo = false;
+    do {
+      bv = -INFINITY;
+      bi = 0x7fffffff;
+      for_each_value<LT>(lrow, vocab, [&](LT v, int i) {
+        const float x = logit_to_float<LT>(v);
+        if (x > bv || (x == bv && i < bi) || bi == 0x7fffffff) { bv = x; bi = i; }
+      }, g0, ng);
+      block_argmax(bv, bi, sv, si);
+      if (redo) break;  // (the second round covered the whole row)
+      const int r = merge_parts(bv, bi);
+      if (r == 0) return;
+      redo = r == 2;
+    } while (redo);
     if (processed_out != nullptr)
       for (int i = tid; i < vocab; i += kSamplerThreads)
         processed_out[(int64_t)row * processed_stride + i] = logit_to_float<LT>(lrow[i]);
@@ -339,13 +406,17 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   const float temp = greedy ? 1.f : P.temperature;  // sampling_metadata.py: greedy rows divide by 1
 
   // ---- pass A: ban, penalties, temperature; the row's maximum ----
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
+  float bv;
+  int bi;
+  bool redo = false;
+  do {
+    bv = -INFINITY;
+    bi = 0x7fffffff;
   {
     constexpr int N = Group<LT>::N;  // 8 logits of 16 bits (4 of fp32) = N / 4 groups of counts and of working values
     struct Item { Group<LT> l; Group<int32_t> c[N / 4]; };
     const bool l_al = aligned16(lrow), c_al = aligned16(crow), x_al = aligned16(x_row);
-    for_each_in_row<2>((vocab + N - 1) / N, [&](int g) {
+    for_each_in_row<2>(ng, [&](int g) {
       Item it;
       it.l = load_group<LT>(lrow, g, vocab, l_al, LT{});
 #pragma unroll
@@ -382,9 +453,14 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
             if (i0 + e4 < vocab) x_row[i0 + e4] = o.v[e4];
         }
       }
-    });
+    }, g0);
   }
-  block_argmax(bv, bi, sv, si);
+    block_argmax(bv, bi, sv, si);
+    if (redo) break;  // (the second round covered the whole row)
+    const int r = merge_parts(bv, bi);
+    if (r == 0) return;
+    redo = r == 2;
+  } while (redo);
   const float m = bv;
   int token = bi;
 
@@ -490,8 +566,23 @@ extern "C" int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_
   LV_CHECK(counts == nullptr || counts_stride >= vocab, "count rows shorter than the vocabulary");
   hipStream_t s = (hipStream_t)stream;
   auto* pp = (SamplerParams*)params;
+  // workgroups per row for the first pass: as many as leave no CU idle, when the scratch rows have the tail for their
+  // partial results (zero-initialised by the caller once; the kernel leaves it zeroed)
+  static const int num_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  int W = 1;
+  // (rows % 8 == 0: the workgroups of a row then share an XCD and its L2, see the kernel)
+  if (scratch != nullptr && scratch_stride >= ((vocab + 3) & ~3) + kSamplerRowTail && vocab >= 8192 &&
+      num_rows % 8 == 0) {
+    W = num_cus / num_rows;
+    W = W < 1 ? 1 : (W > kSamplerMaxParts ? kSamplerMaxParts : W);
+  }
 #define LV_SAMPLE(LT)                                                                                              \
-  hipLaunchKernelGGL(sampler_kernel<LT>, dim3(num_rows), dim3(kSamplerThreads), 0, s, tokens_out, (const LT*)logits, \
+  hipLaunchKernelGGL(sampler_kernel<LT>, dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out, (const LT*)logits, \
                      logits_stride, vocab, state_slot, pp, counts, counts_stride, num_slots, scratch, scratch_stride, \
                      processed_out, processed_stride, update_state)
   switch (logits_dtype) {

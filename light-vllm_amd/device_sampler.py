@@ -109,10 +109,16 @@ class DeviceSampler:
         return s
 
     # ---- sampling ----
+    def new_scratch(self, rows: int, device=None) -> torch.Tensor:
+        """Working rows of a launch: the vocabulary (4-aligned) + the 32-float tail in which the workgroups that share a
+        row's first pass meet (include/lvllm_hip.h, lvllm_sample_rows) -- zeroed once, the kernel leaves it zeroed.
+        One per launch in flight (per captured graph): launches must not share it."""
+        return torch.zeros(rows, ((self.vocab_size + 3) & ~3) + 32, dtype=torch.float32, device=device or self.device)
+
     def scratch_for(self, rows: int) -> torch.Tensor:
         t = self._scratch.get(rows)
         if t is None:
-            t = self._scratch[rows] = torch.empty(rows, self.vocab_size, dtype=torch.float32, device=self.device)
+            t = self._scratch[rows] = self.new_scratch(rows)
         return t
 
     def sample(self, logits: torch.Tensor, state_slot: torch.Tensor, tokens_out: Optional[torch.Tensor] = None,
@@ -123,7 +129,7 @@ class DeviceSampler:
         if tokens_out is None:
             tokens_out = torch.empty(rows, dtype=torch.long, device=logits.device)
         if scratch is None:
-            scratch = torch.empty(rows, self.vocab_size, dtype=torch.float32, device=logits.device)
+            scratch = self.new_scratch(rows, logits.device)
         torch.ops._C_amd.sample_rows(tokens_out, logits, state_slot, self.params, self.counts, scratch, processed_out,
                                      update_state)
         return tokens_out

@@ -57,6 +57,8 @@ class DecodeGraph:
         # multi-step decode: the tokens of model step j of a burst land in row j, on the device and (one copy
         # per burst) in a pinned twin
         self._scratch = None  # this graph's own paged_attention_v2 scratch (see PagedAttnMetadata.decode_scratch)
+        # this graph's own working rows of the sampling launch (allocated and zeroed once, outside the capture)
+        self._sampler_scratch = sampler.new_scratch(batch_size, dev) if sampler is not None else None
         self.token_log: Optional[torch.Tensor] = None
         self._host_logs: List[torch.Tensor] = []
         self._host_logs_next = 0
@@ -101,7 +103,8 @@ class DecodeGraph:
     def _step(self):
         hidden = self.model.forward(self.input_ids, self.positions, self.kv_caches, self._metadata())
         if self.sampler is not None:  # logits -> one sampling launch, still inside the captured step
-            return hidden, self.sampler.sample(self.model.compute_logits(hidden), self.state_slots)
+            return hidden, self.sampler.sample(self.model.compute_logits(hidden), self.state_slots,
+                                               scratch=self._sampler_scratch)
         return hidden, self.model.greedy_tokens(hidden)  # greedy sampling stays on the device
 
     def capture(self, stream: Optional[torch.cuda.Stream] = None) -> None:

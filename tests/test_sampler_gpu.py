@@ -234,3 +234,37 @@ def test_an_evicted_slot_is_rebuilt_to_the_same_state():
     s0b = ds.ensure(10, sp[0], *hist[0], None)
     torch.cuda.synchronize()
     assert torch.equal(ds.params[s0b].cpu(), rec0) and torch.equal(ds.counts[s0b].cpu(), cnt0)  # same seed, same counts
+
+
+def test_first_pass_shared_by_workgroups_gives_the_same_tokens_and_state():
+    """With the tail behind the vocabulary in its scratch rows (DeviceSampler.new_scratch) and a multiple of 8 rows, up to
+    8 workgroups share a row's first pass and meet through one L2; without the tail one workgroup does it all.  Same
+    tokens, same processed logits, same device state, launch after launch (the meeting counter is left at zero)."""
+    V, R = 128256, 16
+    g = torch.Generator().manual_seed(7)
+    logits = [(torch.randn(R, V, generator=g) * 3).to(torch.bfloat16).to(DEV) for _ in range(3)]
+    kinds = [dict(temperature=0.8, top_k=40, top_p=0.9), dict(temperature=0.0, repetition_penalty=1.3),
+             dict(temperature=1.1, min_p=0.02, frequency_penalty=0.4, presence_penalty=0.2), dict(temperature=0.6)]
+    prompts = [torch.randint(0, V, (60,), generator=g).tolist() for _ in range(R)]
+    results = []
+    for shared in (True, False):
+        ds, slots = make_sampler(V, [_params(**kinds[i % 4]) for i in range(R)], prompts=prompts,
+                                 seeds=[100 + i for i in range(R)])
+        slots[3] = -1  # plain greedy rows among them
+        slots[12] = -1
+        scratch = ds.new_scratch(R) if shared else torch.empty(R, V, dtype=torch.float32, device=DEV)
+        toks, procs = [], []
+        for step in range(3):
+            processed = torch.full((R, V), float("nan"), dtype=torch.float32, device=DEV)
+            toks.append(ds.sample(logits[step], slots, scratch=scratch, processed_out=processed, update_state=True).cpu())
+            procs.append(processed.cpu())
+        torch.cuda.synchronize()
+        if shared:
+            assert not scratch[:, ((V + 3) & ~3) + 16].view(torch.int32).any()  # the arrival counter is back at zero
+        results.append((toks, procs, ds.counts.cpu(), ds.params.cpu()))
+    (ta, pa, ca, qa), (tb, pb, cb, qb) = results
+    for a, b in zip(ta, tb):
+        assert torch.equal(a, b)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(ca, cb) and torch.equal(qa, qb)

@@ -28,7 +28,7 @@ for name, kw in cases.items():
     else:
         slots = torch.tensor([ds.ensure(i, SamplingParams(seed=i, **kw), list(range(100)), list(range(50)), None) for i in range(B)],
                              dtype=torch.int32, device=dev)
-    scratch = torch.empty(B, V, dtype=torch.float32, device=dev)
+    scratch = ds.new_scratch(B)
     out = torch.empty(B, dtype=torch.long, device=dev)
     for _ in range(5):
         ds.sample(logits, slots, tokens_out=out, scratch=scratch, update_state=False)
