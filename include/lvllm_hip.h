@@ -435,10 +435,10 @@ int lvllm_advance_step_ex(int num_seqs, int num_queries, int block_size, int64_t
  *       the output so far (lvllm_sampler_init_row fills it from the histories).
  * update_state != 0: the drawn token is added to the slot's counts and output_len += 1 on the device, so the model
  * steps of a multi-step burst need no host round trip.  scratch: float [num_rows, scratch_stride >= vocab] working
- * copy of the rows (needed when state_slot is given).  With scratch_stride >= ((vocab + 3) & ~3) + 32 and the floats
- * behind the vocabulary ZERO when the buffer is first used, up to 8 workgroups share the first pass of a row (launches
- * of a multiple of 8 rows)
- * (penalties, temperature, the row's maximum) and meet in that tail -- the kernel leaves its arrival counter at zero; such a buffer belongs
+ * copy of the rows (needed when state_slot is given).  With scratch_stride >= ((vocab + 3) & ~3) + 64 and the floats
+ * behind the vocabulary ZERO when the buffer is first used, up to 8 workgroups share the first pass of a row
+ * (penalties, temperature, the row's maximum) and -- as a second launch -- its draw (launches of a multiple of 8
+ * rows), and meet in that tail -- the kernel leaves its arrival counter at zero; such a buffer belongs
  * to one launch at a time (launches in flight on different streams bring their own).  processed_out (nullable) float [num_rows, processed_stride]:
  * the logits as they stand before the draw (-inf = filtered out), for tests.  temperature < 1e-5 = greedy on the
  * penalised logits.  Random numbers: Philox4x32-10, key = seed, counter = (vocabulary index / 4, output_len).

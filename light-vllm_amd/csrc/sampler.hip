@@ -45,7 +45,9 @@ static_assert(sizeof(SamplerParams) == LVLLM_SAMPLER_PARAMS_BYTES, "include/lvll
 
 constexpr int kSamplerThreads = 1024;
 constexpr int kSamplerMaxParts = 8;      // workgroups that share the first pass of a row
-constexpr int kSamplerRowTail = 3 * kSamplerMaxParts + 8;  // (maxima | indices | counter | XCD ids)  // floats of a scratch row behind the (4-aligned) vocabulary
+// the tail of a scratch row behind the (4-aligned) vocabulary: [0, 25) the meeting of the first pass (maxima | indices |
+// counter | XCD ids), [28, 32) what the draw launch needs (maximum, cut, mode, arg-max), [32, 57) the meeting of the draw
+constexpr int kSamplerRecord = 28, kSamplerDrawArea = 32, kSamplerRowTail = 64;  // floats of a scratch row behind the (4-aligned) vocabulary
 constexpr float kSamplingEps = 1e-5f;  // sampling_params.py:14 (_SAMPLING_EPS)
 
 __device__ __forceinline__ uint32_t order_key(float x) {  // monotone: a < b  <=>  key(a) < key(b)
@@ -299,7 +301,85 @@ __device__ __forceinline__ uint32_t select_key(const float* __restrict__ x_row, 
   return lo;
 }
 
-template <typename LT>
+// Where the workgroups that share a pass of a row meet: `area` = 25 words of the row's scratch tail (8 values, 8
+// indices, the arrival counter, 8 XCD ids).  Every workgroup leaves its partial arg-max (larger value wins, ties to
+// the smaller index; index 0x7fffffff = nothing) and returns 0 -- except the one that arrives last, which gets the
+// merged (value, index) and returns 1, or 2 when the parts did not all run on its XCD (it must then redo the pass
+// alone: the others' stores were only pushed as far as THEIR L2).  No fence wider than the workgroup is issued.
+__device__ __forceinline__ int meet_parts(float* area, const int W, const int part, float& bv, int& bi, int* s_last) {
+  if (W == 1) return 1;
+  const int tid = threadIdx.x;
+  int* iarea = reinterpret_cast<int*>(area);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the L2
+  __syncthreads();
+  if (tid == 0) {
+    area[part] = bv;
+    iarea[kSamplerMaxParts + part] = bi;
+    iarea[2 * kSamplerMaxParts + 1 + part] = (int)(xcc & 0xf);
+    __builtin_amdgcn_s_waitcnt(0);
+    *s_last = __hip_atomic_fetch_add(iarea + 2 * kSamplerMaxParts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W - 1;
+  }
+  __syncthreads();
+  if (!*s_last) return 0;
+  if (tid == 0) iarea[2 * kSamplerMaxParts] = 0;  // for the next launch
+  bv = -INFINITY;
+  bi = 0x7fffffff;
+  bool same_l2 = true;
+  for (int w = 0; w < W; ++w) {
+    const float v = __hip_atomic_load(area + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int i = __hip_atomic_load(iarea + kSamplerMaxParts + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int x = __hip_atomic_load(iarea + 2 * kSamplerMaxParts + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    same_l2 = same_l2 && x == (int)(xcc & 0xf);
+    if (i != 0x7fffffff && (v > bv || (v == bv && i < bi) || bi == 0x7fffffff)) { bv = v; bi = i; }
+  }
+  return same_l2 ? 1 : 2;
+}
+
+// The draw over the 4-value groups [first, first + n) of a working row: min-p, then the arg-max over the kept tokens of
+// (x - m) - log(q), q ~ Exp(1) (Philox4x32-10, counter = (group, step)); partial result in (best, besti).
+__device__ __forceinline__ void draw_range(const float* __restrict__ x_row, const int vocab, const int first, const int n,
+                                           const float m, const uint32_t cut_key, const float min_p, const uint64_t seed,
+                                           const uint32_t step, float* __restrict__ prow, float& best, int& besti) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const bool x_al = aligned16(x_row);
+  for_each_in_row<4>(n, [&](int i4) { return load_group<float>(x_row, i4, vocab, x_al, -INFINITY); },
+                     [&](Group<float> f, int i4) {
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i4 * 4 + e;
+      float x = f.v[e];
+      bool keep = order_key(x) >= cut_key && x > -INFINITY;
+      if (keep && min_p > 0.f) keep = !(expf(x - m) < min_p);
+      if (!keep) x = -INFINITY;
+      if (prow != nullptr && i < vocab) prow[i] = x;
+      f.v[e] = x;
+      any = any || keep;
+    }
+    if (!any) return;  // random numbers only where a token is still in the race (top-k 50: 50 of 128 k)
+    uint32_t r[4];
+    philox4x32_10((uint32_t)i4, step, k0, k1, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (f.v[e] > -INFINITY) {
+        // arg-max of p_i / q_i, q_i = -ln(u_i) ~ Exp(1), as x_i - ln(q_i); the hardware logarithm (v_log_f32) is
+        // this kernel's own definition of its random stream: nothing outside compares these bits
+        const float u = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
+        const float q = -__logf(u);
+        const float sc = (f.v[e] - m) - __logf(q);
+        const int i = i4 * 4 + e;
+        if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
+      }
+    }
+  }, first);
+}
+
+// SPLIT_DRAW: the draw is a launch of its own (sampler_draw_kernel), shared by the workgroups of a row like the first
+// pass; this kernel leaves (maximum, cut, arg-max) of the rows that need one in the row's tail.
+template <typename LT, bool SPLIT_DRAW>
 __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
     int64_t* __restrict__ tokens_out, const LT* __restrict__ logits, const int64_t logits_stride, const int vocab,
     const int32_t* __restrict__ state_slot, SamplerParams* __restrict__ params, int32_t* __restrict__ counts,
@@ -333,42 +413,10 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   int g0 = part * share, ng = max(0, min(share, lgroups - g0));
   float* tail = W > 1 ? scratch + (int64_t)row * scratch_stride + ((vocab + 3) & ~3) : nullptr;
   __shared__ int s_last;
-  // 0: this workgroup is done; 1: it is the last one and (bv, bi) are the row's; 2: the last one, but the parts did
-  // not share an L2 -- run the pass again over the whole row (g0, ng reset)
   auto merge_parts = [&](float& bv, int& bi) __attribute__((always_inline)) -> int {
-    if (W == 1) return 1;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the L2
-    __syncthreads();
-    if (tid == 0) {
-      tail[part] = bv;
-      reinterpret_cast<int*>(tail)[kSamplerMaxParts + part] = bi;
-      reinterpret_cast<int*>(tail)[2 * kSamplerMaxParts + 1 + part] = (int)(xcc & 0xf);
-      __builtin_amdgcn_s_waitcnt(0);
-      s_last = __hip_atomic_fetch_add(reinterpret_cast<int*>(tail) + 2 * kSamplerMaxParts, 1, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT) == W - 1;
-    }
-    __syncthreads();
-    if (!s_last) return 0;
-    if (tid == 0) reinterpret_cast<int*>(tail)[2 * kSamplerMaxParts] = 0;  // for the next launch
-    bv = -INFINITY;
-    bi = 0x7fffffff;
-    bool same_l2 = true;
-    for (int w = 0; w < W; ++w) {
-      const float v = __hip_atomic_load(tail + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int i = __hip_atomic_load(reinterpret_cast<int*>(tail) + kSamplerMaxParts + w, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-      const int x = __hip_atomic_load(reinterpret_cast<int*>(tail) + 2 * kSamplerMaxParts + 1 + w, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-      same_l2 = same_l2 && x == (int)(xcc & 0xf);
-      if (i != 0x7fffffff && (v > bv || (v == bv && i < bi) || bi == 0x7fffffff)) { bv = v; bi = i; }
-    }
-    if (same_l2) return 1;
-    g0 = 0;
-    ng = lgroups;
-    return 2;
+    const int r = meet_parts(tail, W, part, bv, bi, &s_last);
+    if (r == 2) { g0 = 0; ng = lgroups; }
+    return r;
   };
 
   if (sid < 0 || sid >= num_slots) {  // plain greedy row: arg-max of the logits as they are
@@ -392,7 +440,7 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
       for (int i = tid; i < vocab; i += kSamplerThreads)
         processed_out[(int64_t)row * processed_stride + i] = logit_to_float<LT>(lrow[i]);
     if (tid == 0) tokens_out[row] = bi;
-    return;
+    return;  // (no state slot: sampler_draw_kernel skips the row by that)
   }
 
   __shared__ SamplerParams P;  // one copy per workgroup (its banned[] list is indexed dynamically)
@@ -484,43 +532,20 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
       if (cut_key < kth_key) cut_key = kth_key;
       __syncthreads();
     }
-    // ---- min-p + the draw: arg-max over the kept tokens of (x - m) - log(q), q ~ Exp(1) ----
-    const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
-    const uint32_t step = (uint32_t)P.output_len;
+    if constexpr (SPLIT_DRAW) {  // the draw is the next launch's: leave it what it needs
+      if (tid == 0) {
+        tail[kSamplerRecord + 0] = m;
+        reinterpret_cast<uint32_t*>(tail)[kSamplerRecord + 1] = cut_key;
+        reinterpret_cast<int*>(tail)[kSamplerRecord + 2] = 1;
+        reinterpret_cast<int*>(tail)[kSamplerRecord + 3] = bi;
+      }
+      return;
+    }
+    // ---- min-p + the draw ----
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    float* prow = processed_out != nullptr ? processed_out + (int64_t)row * processed_stride : nullptr;
-    const bool x_al = aligned16(x_row);
-    for_each_in_row<4>((vocab + 3) / 4, [&](int i4) { return load_group<float>(x_row, i4, vocab, x_al, -INFINITY); },
-                       [&](Group<float> f, int i4) {
-      bool any = false;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = i4 * 4 + e;
-        float x = f.v[e];
-        bool keep = order_key(x) >= cut_key && x > -INFINITY;
-        if (keep && P.min_p > 0.f) keep = !(expf(x - m) < P.min_p);
-        if (!keep) x = -INFINITY;
-        if (prow != nullptr && i < vocab) prow[i] = x;
-        f.v[e] = x;
-        any = any || keep;
-      }
-      if (!any) return;  // random numbers only where a token is still in the race (top-k 50: 50 of 128 k)
-      uint32_t r[4];
-      philox4x32_10((uint32_t)i4, step, k0, k1, r);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (f.v[e] > -INFINITY) {
-          // arg-max of p_i / q_i, q_i = -ln(u_i) ~ Exp(1), as x_i - ln(q_i); the hardware logarithm (v_log_f32) is
-          // this kernel's own definition of its random stream: nothing outside compares these bits
-          const float u = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
-          const float q = -__logf(u);
-          const float sc = (f.v[e] - m) - __logf(q);
-          const int i = i4 * 4 + e;
-          if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
-        }
-      }
-    });
+    draw_range(x_row, vocab, 0, (vocab + 3) / 4, m, cut_key, P.min_p, P.seed, (uint32_t)P.output_len,
+               processed_out != nullptr ? processed_out + (int64_t)row * processed_stride : nullptr, best, besti);
     block_argmax(best, besti, sv, si);
     token = besti != 0x7fffffff ? besti : bi;
   } else if (processed_out != nullptr) {
@@ -528,10 +553,60 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
   }
 
   if (tid == 0) {
+    if constexpr (SPLIT_DRAW) reinterpret_cast<int*>(tail)[kSamplerRecord + 2] = 0;  // (a greedy row: nothing to draw)
     tokens_out[row] = token;
     if (update_state) {  // the drawn token joins the request's output history
       crow[token] += 1;
       params[sid].output_len = P.output_len + 1;
+    }
+  }
+}
+
+// The draw of the rows sampler_kernel<.., true> left one for: gridDim.y workgroups per row, met like the first pass.
+__global__ __launch_bounds__(kSamplerThreads) void sampler_draw_kernel(
+    int64_t* __restrict__ tokens_out, const int vocab, const int32_t* __restrict__ state_slot,
+    SamplerParams* __restrict__ params, int32_t* __restrict__ counts, const int64_t counts_stride, const int num_slots,
+    float* __restrict__ scratch, const int64_t scratch_stride, float* __restrict__ processed_out,
+    const int64_t processed_stride, const int update_state) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  __shared__ int s_last;
+  const int row = blockIdx.x, W = gridDim.y, part = blockIdx.y, tid = threadIdx.x;
+  const int sid = state_slot[row];
+  if (sid < 0 || sid >= num_slots) return;
+  float* x_row = scratch + (int64_t)row * scratch_stride;
+  float* tail = x_row + ((vocab + 3) & ~3);
+  if (reinterpret_cast<const int*>(tail)[kSamplerRecord + 2] != 1) return;
+  const float m = tail[kSamplerRecord + 0];
+  const uint32_t cut_key = reinterpret_cast<const uint32_t*>(tail)[kSamplerRecord + 1];
+  const int bi = reinterpret_cast<const int*>(tail)[kSamplerRecord + 3];
+  const float min_p = params[sid].min_p;
+  const uint64_t seed = params[sid].seed;
+  const int output_len = params[sid].output_len;
+  const int groups = (vocab + 3) / 4;
+  const int share = (groups + W - 1) / W;
+  int g0 = part * share, ng = max(0, min(share, groups - g0));
+  float* prow = processed_out != nullptr ? processed_out + (int64_t)row * processed_stride : nullptr;
+  float best;
+  int besti;
+  bool redo = false;
+  do {
+    best = -INFINITY;
+    besti = 0x7fffffff;
+    draw_range(x_row, vocab, g0, ng, m, cut_key, min_p, seed, (uint32_t)output_len, prow, best, besti);
+    block_argmax(best, besti, sv, si);
+    if (redo) break;  // (the second round covered the whole row)
+    const int r = meet_parts(tail + kSamplerDrawArea, W, part, best, besti, &s_last);
+    if (r == 0) return;
+    redo = r == 2;
+    if (redo) { g0 = 0; ng = groups; }
+  } while (redo);
+  if (tid == 0) {
+    const int token = besti != 0x7fffffff ? besti : bi;
+    tokens_out[row] = token;
+    if (update_state) {
+      counts[(int64_t)sid * counts_stride + token] += 1;
+      params[sid].output_len = output_len + 1;
     }
   }
 }
@@ -581,10 +656,19 @@ extern "C" int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_
     W = num_cus / num_rows;
     W = W < 1 ? 1 : (W > kSamplerMaxParts ? kSamplerMaxParts : W);
   }
-#define LV_SAMPLE(LT)                                                                                              \
-  hipLaunchKernelGGL(sampler_kernel<LT>, dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out, (const LT*)logits, \
-                     logits_stride, vocab, state_slot, pp, counts, counts_stride, num_slots, scratch, scratch_stride, \
-                     processed_out, processed_stride, update_state)
+  // the draw as a launch of its own, shared like the first pass, when rows may need one
+  const bool split_draw = W > 1 && state_slot != nullptr;
+#define LV_SAMPLE(LT)                                                                                                 \
+  do {                                                                                                                \
+    if (split_draw)                                                                                                   \
+      hipLaunchKernelGGL((sampler_kernel<LT, true>), dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out,      \
+                         (const LT*)logits, logits_stride, vocab, state_slot, pp, counts, counts_stride, num_slots,  \
+                         scratch, scratch_stride, processed_out, processed_stride, update_state);                    \
+    else                                                                                                              \
+      hipLaunchKernelGGL((sampler_kernel<LT, false>), dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out,     \
+                         (const LT*)logits, logits_stride, vocab, state_slot, pp, counts, counts_stride, num_slots,  \
+                         scratch, scratch_stride, processed_out, processed_stride, update_state);                    \
+  } while (0)
   switch (logits_dtype) {
     case LVLLM_F32: LV_SAMPLE(float); break;
     case LVLLM_F16: LV_SAMPLE(F16Bits); break;
@@ -592,6 +676,10 @@ extern "C" int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_
     default: LV_CHECK(false, "unsupported logits dtype");
   }
 #undef LV_SAMPLE
+  if (split_draw)
+    hipLaunchKernelGGL(sampler_draw_kernel, dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out, vocab, state_slot,
+                       pp, counts, counts_stride, num_slots, scratch, scratch_stride, processed_out, processed_stride,
+                       update_state);
   LV_LAUNCH_CHECK();
   return 0;
 }

@@ -110,10 +110,10 @@ class DeviceSampler:
 
     # ---- sampling ----
     def new_scratch(self, rows: int, device=None) -> torch.Tensor:
-        """Working rows of a launch: the vocabulary (4-aligned) + the 32-float tail in which the workgroups that share a
+        """Working rows of a launch: the vocabulary (4-aligned) + the 64-float tail in which the workgroups that share a
         row's first pass meet (include/lvllm_hip.h, lvllm_sample_rows) -- zeroed once, the kernel leaves it zeroed.
         One per launch in flight (per captured graph): launches must not share it."""
-        return torch.zeros(rows, ((self.vocab_size + 3) & ~3) + 32, dtype=torch.float32, device=device or self.device)
+        return torch.zeros(rows, ((self.vocab_size + 3) & ~3) + 64, dtype=torch.float32, device=device or self.device)
 
     def scratch_for(self, rows: int) -> torch.Tensor:
         t = self._scratch.get(rows)

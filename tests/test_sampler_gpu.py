@@ -260,7 +260,8 @@ def test_first_pass_shared_by_workgroups_gives_the_same_tokens_and_state():
             procs.append(processed.cpu())
         torch.cuda.synchronize()
         if shared:
-            assert not scratch[:, ((V + 3) & ~3) + 16].view(torch.int32).any()  # the arrival counter is back at zero
+            Vp = (V + 3) & ~3
+            assert not scratch[:, [Vp + 16, Vp + 48]].view(torch.int32).any()  # the arrival counters are back at zero
         results.append((toks, procs, ds.counts.cpu(), ds.params.cpu()))
     (ta, pa, ca, qa), (tb, pb, cb, qb) = results
     for a, b in zip(ta, tb):
