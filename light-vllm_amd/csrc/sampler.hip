@@ -28,6 +28,8 @@
 // the random stream is Philox, not torch's generator -- seeded requests repeat themselves, they do not repeat torch.
 #include <float.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace lvllm {
@@ -121,19 +123,24 @@ __device__ __forceinline__ Group<V> load_group(const V* __restrict__ row, const 
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// f(value, index) for every value of a row -- or of its 16-byte groups [g0, g0 + ng) (ng < 0: all)
+// f(value, index) for every value of a row -- or of its 16-byte groups [g0, g0 + ng) (ng < 0: all).  Only the ragged
+// last group is checked element by element (a guard per element was a branch per element: these passes are bound by
+// the instructions one CU can issue).
 template <typename V, typename F>
 __device__ __forceinline__ void for_each_value(const V* __restrict__ row, const int n, F&& f, const int g0 = 0,
                                                const int ng = -1) {
   constexpr int N = Group<V>::N;
   const bool al = aligned16(row);
-  const int groups = (n + N - 1) / N;
-  for_each_in_row<4>(ng < 0 ? groups : ng, [&](int g) { return load_group<V>(row, g, n, al, V{}); },
-                     [&](const Group<V>& v, int g) {
+  const int groups = (n + N - 1) / N, full = n / N;
+  const int first = ng < 0 ? 0 : g0, end = ng < 0 ? groups : g0 + ng;
+  const int end_full = end < full ? end : full;
+  if (end_full > first)
+    for_each_in_row<4>(end_full - first, [&](int g) { return load_group<V>(row, g, n, al, V{}); },
+                       [&](const Group<V>& v, int g) {
 #pragma unroll
-                       for (int e = 0; e < N; ++e)
-                         if (g * N + e < n) f(v.v[e], g * N + e);
-                     }, ng < 0 ? 0 : g0);
+                         for (int e = 0; e < N; ++e) f(v.v[e], g * N + e);
+                       }, first);
+  if (end > full && full >= first && threadIdx.x < n - full * N) f(row[full * N + threadIdx.x], full * N + (int)threadIdx.x);
 }
 
 // (value, index) arg-max of the block, ties to the smaller index; result in every thread
@@ -176,8 +183,8 @@ __device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t* red) {
 // Histogram search by wave 0: the first bin -- walking down from the last one (DESC) or up from bin 0 -- at which the
 // running total reaches `target` (STRICT: exceeds it).  Writes the bin and the total accumulated before it; bin = -1
 // when no bin qualifies.
-template <int NBINS, bool DESC, bool STRICT>
-__device__ inline void find_bin(const uint64_t* hist, uint64_t target, int* bin_out, uint64_t* before_out) {
+template <int NBINS, bool DESC, bool STRICT, typename H>
+__device__ inline void find_bin(const H* hist, uint64_t target, int* bin_out, uint64_t* before_out) {
   if (threadIdx.x < 64) {
     constexpr int PER = NBINS / 64;
     const int lane = threadIdx.x;
@@ -233,25 +240,43 @@ __device__ __forceinline__ int lin_bin(float m, float x) {
 
 template <bool MASS>
 __device__ __forceinline__ uint32_t select_key(const float* __restrict__ x_row, const int vocab, const float m,
-                                      const uint32_t floor_key, uint64_t target, const float drop_frac, uint64_t* hist,
+                                      const uint32_t floor_key, uint64_t target, const float drop_frac, uint64_t* hist64,
                                       uint64_t* red, int* s_bin, uint64_t* s_before, bool* found) {
   const int tid = threadIdx.x;
   *found = true;
+  // counts fit 32 bits (a wave-wide 32-bit LDS atomic moves half the bank words of a 64-bit one; the passes are bound
+  // by the one LDS unit of the CU they run on), mass needs its 2^-40 fixed point
+  using H = typename std::conditional<MASS, uint64_t, uint32_t>::type;
+  H* hist = reinterpret_cast<H*>(hist64);
   for (int b = tid; b < kLinBins; b += kSamplerThreads) hist[b] = 0;
   __syncthreads();
+  // (the last bin -- everything 32 or more below the maximum -- is not counted with atomics: mass is summed in
+  // registers, counts are what the other bins leave of the vocabulary)
   uint64_t tail = 0;
   for_each_value<float>(x_row, vocab, [&](float x, int) {
     if (MASS && order_key(x) < floor_key) return;
     const int b = lin_bin(m, x);
-    const uint64_t w = MASS ? (uint64_t)(expf(x - m) * 1099511627776.f) : 1ull;  // 2^40
-    if (b < kLinBins - 1) atomicAdd((unsigned long long*)&hist[b], (unsigned long long)w);
-    else tail += w;
+    if constexpr (MASS) {
+      // 2^-40 fixed point; below e^-27.8 the product is < 1 and truncates to 0: no exponential for those (most of a
+      // real vocabulary)
+      const uint64_t w = x - m < -27.8f ? 0ull : (uint64_t)(expf(x - m) * 1099511627776.f);
+      if (b < kLinBins - 1) atomicAdd(&hist[b], (H)w);
+      else tail += w;
+    } else {
+      if (b < kLinBins - 1) atomicAdd(&hist[b], (H)1);
+    }
   });
-  tail = block_sum_u64(tail, red);
-  if (tid == 0) hist[kLinBins - 1] = tail;
+  if constexpr (MASS) {
+    tail = block_sum_u64(tail, red);
+  } else {
+    __syncthreads();
+    const uint64_t counted = block_sum_u64((uint64_t)hist[tid] + (tid + kSamplerThreads < kLinBins - 1 ? (uint64_t)hist[tid + kSamplerThreads] : 0), red);
+    tail = (uint64_t)vocab - counted;
+  }
+  if (tid == 0) hist[kLinBins - 1] = (H)tail;
   __syncthreads();
   if (MASS) {
-    const uint64_t z = block_sum_u64(hist[tid] + hist[tid + kSamplerThreads], red);
+    const uint64_t z = block_sum_u64((uint64_t)hist[tid] + (uint64_t)hist[tid + kSamplerThreads], red);
     target = (uint64_t)((double)drop_frac * (double)z);
   }
   if (MASS) find_bin<kLinBins, true, true>(hist, target, s_bin, s_before);   // from the smallest values up
@@ -265,8 +290,10 @@ __device__ __forceinline__ uint32_t select_key(const float* __restrict__ x_row, 
   target -= *s_before;
   // keys the bin can hold: its value bounds widened by more than the rounding of (m - x) and of the bounds themselves
   const float slack = (fabsf(m) + 32.f) * 1e-6f;
-  uint32_t lo = lb == kLinBins - 1 ? 0u : order_key((m - (float)(lb + 1) / kLinPerUnit) - slack);
-  const uint32_t hi = order_key((m - (float)lb / kLinPerUnit) + slack);
+  const float flo = lb == kLinBins - 1 ? -INFINITY : (m - (float)(lb + 1) / kLinPerUnit) - slack;
+  const float fhi = (m - (float)lb / kLinPerUnit) + slack;
+  uint32_t lo = lb == kLinBins - 1 ? 0u : order_key(flo);
+  const uint32_t hi = order_key(fhi);
   if (hi < lo) lo = 0;
   int bits = 32 - __clz((int)((hi - lo) | 1u));
   __syncthreads();
@@ -276,12 +303,14 @@ __device__ __forceinline__ uint32_t select_key(const float* __restrict__ x_row, 
     for (int b = tid; b < 2048; b += kSamplerThreads) hist[b] = 0;
     __syncthreads();
     for_each_value<float>(x_row, vocab, [&](float x, int) {
+      // (two float compares turn nearly every element away before any integer work: the values of one bin)
+      if (!(x >= flo && x <= fhi)) return;
       const uint32_t key = order_key(x);
       if (MASS && key < floor_key) return;
       const uint32_t d = key - lo;
       if (key < lo || ((uint64_t)d >> bits) != 0 || lin_bin(m, x) != lb) return;
       const uint64_t w = MASS ? (uint64_t)(expf(x - m) * 1099511627776.f) : 1ull;
-      atomicAdd((unsigned long long*)&hist[d >> shift], (unsigned long long)w);
+      atomicAdd(&hist[d >> shift], (H)w);
     });
     __syncthreads();
     if (MASS) find_bin<2048, false, true>(hist, target, s_bin, s_before);
