@@ -149,6 +149,12 @@ constexpr int kSrdFlags = 0x00020000;
 #ifndef LVLLM_ATTN_MIN_WAVES_PER_SIMD
 #define LVLLM_ATTN_MIN_WAVES_PER_SIMD 2
 #endif
+// ROPE instantiation: 1 = the rotation of Q is shared by the waves (wave j rotates fragment pair j once, everybody
+// reads the result from LDS after the prologue's barrier); 0 = every wave rotates all of Q (round 2: ~800 vector
+// instructions per wave, eight times over, before the first tile)
+#ifndef LVLLM_ATTN_ROPE_SHARED_Q
+#define LVLLM_ATTN_ROPE_SHARED_Q 1
+#endif
 // 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale).
 // scale == 1 (`scaled` false, the common case): gfx950 converts two fp8 straight to two bf16 / f16 in ONE instruction
 // (v_cvt_scalef32_pk_{bf16,f16}_fp8 with a scale of 1.0) -- exact, every e4m3 value is a bf16 and an f16 value -- half
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   if constexpr (ROPE) first_loads();  // (without the prologue the Q loads go first, as before: 25.0 against 25.4 us)
 
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
+  constexpr bool kSharedQ = LVLLM_ATTN_ROPE_SHARED_Q != 0 && NSQ / 2 <= NWAVES && NSQ >= 2;
   u32x4_t qf[NSQ];
   {
     const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + c) * D;
@@ -341,7 +348,9 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       // bf16/f16 cache: d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8 above)
       const int d0 = KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g;
       qf[j] = u32x4_t{0, 0, 0, 0};
-      if (c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
+      // (shared rotation: wave w loads the pair it rotates, fragments w and w + NSQ/2)
+      const bool mine = !(ROPE && kSharedQ) || (j % (NSQ / 2 > 0 ? NSQ / 2 : 1)) == wave;
+      if (mine && c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
     }
   }
   // ---- ROPE: rotate Q in registers; one wave rotates the new K, stores K and V to the caches and to LDS ----
@@ -380,14 +389,27 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
           y[e] = T::from_float(__fadd_rn(yc, xs));
         }
       };
-      if (c < nh) {
-        // 16-bit cache: fragment j holds d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8)
+      // 16-bit cache: fragment j holds d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8)
+      if constexpr (kSharedQ) {
+        // wave j < NSQ/2 rotates pair (j, j + NSQ/2) and leaves both fragments in LDS, [fragment][lane] x 16 bytes
+        u32x4_t* sm_q = reinterpret_cast<u32x4_t*>(sm_vnew + D);
+#pragma unroll
+        for (int j = 0; j < NSQ / 2; ++j) {
+          if (wave == j) {
+            if (c < nh) rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
+            sm_q[j * 64 + lane] = qf[j];
+            sm_q[(j + NSQ / 2) * 64 + lane] = qf[j + NSQ / 2];
+          }
+        }
+      } else if (c < nh) {
 #pragma unroll
         for (int j = 0; j < NSQ / 2; ++j)
           rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
       }
       owns_new_token = !p.partitioned || t1 == seq_len;
-      if (owns_new_token && wave == 0) {
+      // (the new K / V row is the job of a wave that rotates no Q, when there is one)
+      constexpr int kKvWave = kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0;
+      if (owns_new_token && wave == kKvWave) {
         // lanes 0 .. D/16-1: one (x, y) chunk pair of the key row each; lanes 0 .. D/8-1: one chunk of the value row
         int64_t slot = p.slot_mapping[seq];
         if (slot >= p.num_slots) slot = -1;
@@ -458,6 +480,13 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       }
     }
     __syncthreads();  // the stash is visible to the wave that owns the last tile
+    if constexpr (kSharedQ) {
+      if (seq_len > 0) {
+        const u32x4_t* sm_q = reinterpret_cast<const u32x4_t*>(sm_vnew + D);
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j) qf[j] = sm_q[j * 64 + lane];
+      }
+    }
   }
   // fp8 caches: scales other than 1 take their own instantiation (SCALED).  As a run-time flag the choice became a
   // branch around EVERY conversion of the unrolled loop -- two arms with an s_waitcnt vmcnt(0) in each, 32 branches
@@ -657,7 +686,8 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   constexpr int DPAD = ((D + 15) / 16) * 16;
   const size_t smem = (size_t)NWAVES * 16 * 2 * sizeof(float) +
                       (size_t)NWAVES * nh_lds * DPAD * sizeof(float) +
-                      (p.positions != nullptr ? (size_t)2 * D * 2 : 0);  // ROPE: the new token's k and v
+                      (p.positions != nullptr ? (size_t)2 * D * 2 + (size_t)2 * ((D + 31) / 32) * 1024 : 0);  // ROPE: the new
+                                                                  // token's k and v, the rotated Q fragments (<= 2 NS KiB)
   auto launch = [&](auto kern) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
