@@ -73,8 +73,8 @@ def parse():
                     help="rope + cache write as their own launch in front of attention (A/B of the fused kernel)")
     ap.add_argument("--no-fp8-activations-once", action="store_true",
                     help="A/B (W8A8): every projection quantises its own activations again (round 2's path)")
-    ap.add_argument("--rope-in-attention-fp8", action="store_true",
-                    help="A/B: the fused rope + cache write + attention launch over an fp8 KV cache as well")
+    ap.add_argument("--no-rope-in-attention-fp8", dest="rope_in_attention_fp8", action="store_false",
+                    help="A/B: over an fp8 KV cache rope, cache write and attention as three launches (round 2's path)")
     ap.add_argument("--o-proj-partials-min-rows", type=int, default=None,
                     help="A/B: decode steps of at least this many rows split o_proj's K over workgroups (default 33)")
     ap.add_argument("--gemm-partials-ksplit", type=int, default=None,

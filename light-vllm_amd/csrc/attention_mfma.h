@@ -155,6 +155,18 @@ constexpr int kSrdFlags = 0x00020000;
 #ifndef LVLLM_ATTN_ROPE_SHARED_Q
 #define LVLLM_ATTN_ROPE_SHARED_Q 1
 #endif
+// timing-diagnosis builds of the ROPE instantiation (WRONG results; tools/ab_rope_attn.sh): 1 = no rotation arithmetic,
+// 2 = no cache stores, 4 = no new-token work at all (loads, rotation, stores, stash), 8 = no cos / sin loads
+// 1: the new token's K / V row goes into the caches AFTER the key walk (from the LDS stash), not in the prologue: vmcnt
+// retires in issue order, so every tile load the writing wave issued after those stores (128 scattered 2-byte
+// writes of the V row among them) waited for their acknowledgement, and the workgroup's merge for that wave -- 2.5 us
+// of a 26 us launch (diagnosis builds, profiles/r03_tuning.md section 10)
+#ifndef LVLLM_ATTN_ROPE_LATE_STORES
+#define LVLLM_ATTN_ROPE_LATE_STORES 1
+#endif
+#ifndef LVLLM_ATTN_ROPE_DIAG
+#define LVLLM_ATTN_ROPE_DIAG 0
+#endif
 // 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale).
 // scale == 1 (`scaled` false, the common case): gfx950 converts two fp8 straight to two bf16 / f16 in ONE instruction
 // (v_cvt_scalef32_pk_{bf16,f16}_fp8 with a scale of 1.0) -- exact, every e4m3 value is a bf16 and an f16 value -- half
@@ -340,6 +352,9 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
 
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
   constexpr bool kSharedQ = LVLLM_ATTN_ROPE_SHARED_Q != 0 && NSQ / 2 <= NWAVES && NSQ >= 2;
+  // (ROPE: the new K / V row is the job of a wave that rotates no Q, when there is one)
+  constexpr int kKvWave = kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0;
+  constexpr bool kLateStores = ROPE && LVLLM_ATTN_ROPE_LATE_STORES != 0;
   u32x4_t qf[NSQ];
   {
     const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + c) * D;
@@ -371,8 +386,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       const S* cosp = (const S*)p.cos_sin_cache + pos * D;
       const S* sinp = cosp + D / 2;
       auto rot8 = [&](u32x4_t& xv, u32x4_t& yv, const int d0) __attribute__((always_inline)) {
+        if constexpr (LVLLM_ATTN_ROPE_DIAG & 8) return;
         const u32x4_t cv = *reinterpret_cast<const u32x4_t*>(cosp + d0);
         const u32x4_t sv = *reinterpret_cast<const u32x4_t*>(sinp + d0);
+        if constexpr (LVLLM_ATTN_ROPE_DIAG & 1) { xv.x ^= cv.x & sv.x & 1u; return; }
         S* x = reinterpret_cast<S*>(&xv);
         S* y = reinterpret_cast<S*>(&yv);
         const S* cc = reinterpret_cast<const S*>(&cv);
@@ -407,12 +424,11 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
           rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
       }
       owns_new_token = !p.partitioned || t1 == seq_len;
-      // (the new K / V row is the job of a wave that rotates no Q, when there is one)
-      constexpr int kKvWave = kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0;
-      if (owns_new_token && wave == kKvWave) {
+      if (owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 4)) {
         // lanes 0 .. D/16-1: one (x, y) chunk pair of the key row each; lanes 0 .. D/8-1: one chunk of the value row
         int64_t slot = p.slot_mapping[seq];
         if (slot >= p.num_slots) slot = -1;
+        if constexpr (LVLLM_ATTN_ROPE_DIAG & 2) slot = -1;
         const int64_t blk = slot >= 0 ? slot / BS : 0;
         const int boff = slot >= 0 ? (int)(slot - blk * BS) : 0;
         if (lane < D / 16) {
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
             uint8_t* sk = reinterpret_cast<uint8_t*>(sm_knew);
             *reinterpret_cast<u32x2_t*>(sk + 8 * lane) = qx;
             *reinterpret_cast<u32x2_t*>(sk + D / 2 + 8 * lane) = qy;
-            if (slot >= 0) {
+            if (slot >= 0 && !kLateStores) {
               uint8_t* kc8 = (uint8_t*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 16;
               const int dx = 8 * lane, dy = D / 2 + 8 * lane;
               *reinterpret_cast<u32x2_t*>(kc8 + (int64_t)(dx / 16) * BS * 16 + (dx % 16)) = qx;
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
           } else {
             *reinterpret_cast<u32x4_t*>(sm_knew + 8 * lane) = kx;
             *reinterpret_cast<u32x4_t*>(sm_knew + D / 2 + 8 * lane) = ky;
-            if (slot >= 0) {
+            if (slot >= 0 && !kLateStores) {
               S* kc = (S*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 8;
               *reinterpret_cast<u32x4_t*>(kc + (int64_t)lane * BS * 8) = kx;
               *reinterpret_cast<u32x4_t*>(kc + (int64_t)(D / 16 + lane) * BS * 8) = ky;
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
             qv.y = fp8_kv_quant4(T::to_float(ve[4]), T::to_float(ve[5]), T::to_float(ve[6]), T::to_float(ve[7]), p.v_scale);
             uint8_t* sv = reinterpret_cast<uint8_t*>(sm_vnew);
             *reinterpret_cast<u32x2_t*>(sv + 8 * lane) = qv;
-            if (slot >= 0) {
+            if (slot >= 0 && !kLateStores) {
               uint8_t* vc8 = (uint8_t*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
                              (int64_t)(8 * lane) * BS + boff;
               const uint8_t* qb = reinterpret_cast<const uint8_t*>(&qv);
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
             }
           } else {
             *reinterpret_cast<u32x4_t*>(sm_vnew + 8 * lane) = vv;
-            if (slot >= 0) {
+            if (slot >= 0 && !kLateStores) {
               S* vc = (S*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
                       (int64_t)(8 * lane) * BS + boff;
 #pragma unroll
@@ -616,6 +632,53 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
         load_tile(kset[s], vset[s], j + u + NBUF - 1, bnr[s]);
         bnr[s] = block_number(j + u + 2 * NBUF - 1);
         compute_tile(kset[u], vset[u], j + u);
+      }
+    }
+  }
+
+  // ---- ROPE: the new token's rows go into the caches now, from the stash (see LVLLM_ATTN_ROPE_LATE_STORES) ----
+  if constexpr (kLateStores) {
+    if (owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
+      int64_t slot = p.slot_mapping[seq];
+      if (slot >= p.num_slots) slot = -1;
+      if (slot >= 0) {
+        const int64_t blk = slot / BS;
+        const int boff = (int)(slot - blk * BS);
+        if constexpr (KV8) {
+          const uint8_t* sk = reinterpret_cast<const uint8_t*>(sm_knew);
+          const uint8_t* sv = reinterpret_cast<const uint8_t*>(sm_vnew);
+          if (lane < D / 16) {
+            uint8_t* kc8 = (uint8_t*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 16;
+            const int dx = 8 * lane, dy = D / 2 + 8 * lane;
+            *reinterpret_cast<u32x2_t*>(kc8 + (int64_t)(dx / 16) * BS * 16 + (dx % 16)) =
+                *reinterpret_cast<const u32x2_t*>(sk + 8 * lane);
+            *reinterpret_cast<u32x2_t*>(kc8 + (int64_t)(dy / 16) * BS * 16 + (dy % 16)) =
+                *reinterpret_cast<const u32x2_t*>(sk + D / 2 + 8 * lane);
+          }
+          if (lane < D / 8) {
+            uint8_t* vc8 = (uint8_t*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
+                           (int64_t)(8 * lane) * BS + boff;
+            const u32x2_t qv = *reinterpret_cast<const u32x2_t*>(sv + 8 * lane);
+            const uint8_t* qb = reinterpret_cast<const uint8_t*>(&qv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vc8[(int64_t)e * BS] = qb[e];
+          }
+        } else {
+          if (lane < D / 16) {
+            S* kc = (S*)p.k_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) + boff * 8;
+            *reinterpret_cast<u32x4_t*>(kc + (int64_t)lane * BS * 8) = *reinterpret_cast<const u32x4_t*>(sm_knew + 8 * lane);
+            *reinterpret_cast<u32x4_t*>(kc + (int64_t)(D / 16 + lane) * BS * 8) =
+                *reinterpret_cast<const u32x4_t*>(sm_knew + D / 2 + 8 * lane);
+          }
+          if (lane < D / 8) {
+            S* vc = (S*)p.v_cache + (blk * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) +
+                    (int64_t)(8 * lane) * BS + boff;
+            const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(sm_vnew + 8 * lane);
+            const S* ve = reinterpret_cast<const S*>(&vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vc[(int64_t)e * BS] = ve[e];
+          }
+        }
       }
     }
   }

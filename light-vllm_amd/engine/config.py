@@ -25,7 +25,8 @@ class ModelConfig:
     fuse_decode_ops: bool = True    # rope+cache write in one launch, split-K sum inside add+norm
     # the individual fused launches of a decode step (each bit-identical to what it replaces; off = A/B runs)
     rope_in_attention: bool = True  # rotary_embedding + reshape_and_cache inside the attention launch
-    rope_in_attention_fp8: bool = False  # the same over an fp8 KV cache (bit-identical too; measured, profiles/r03_tuning.md)
+    rope_in_attention_fp8: bool = True   # the same over an fp8 KV cache (bit-identical too; +2 % on config 5 once the
+                                         # new token's cache stores left the prologue, profiles/r03_tuning.md section 10)
     swiglu_epilogue: bool = True    # silu_and_mul in the gate_up projection's epilogue
     argmax_epilogue: bool = True    # greedy arg-max in the lm_head projection's epilogue
     stream_gemm_max_rows: int = 256  # 65..this many rows: projections through lvllm_stream_gemm where it wins

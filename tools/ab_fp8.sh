@@ -16,6 +16,6 @@ print('$1', d['value'], d['ms_per_step'], 'in flight 3:', d['other_settings']['m
 for round in ${ROUNDS:-1 2}; do
   python bench.py $F 2>/dev/null | line once >> $O
   python bench.py $F --no-fp8-activations-once 2>/dev/null | line each >> $O
-  python bench.py $F --rope-in-attention-fp8 2>/dev/null | line rope >> $O
+  python bench.py $F --no-rope-in-attention-fp8 2>/dev/null | line norope >> $O
 done
 cat $O
