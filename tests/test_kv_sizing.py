@@ -93,3 +93,22 @@ def test_rocm_platform_answers_on_the_gpu():
     assert RocmPlatform.has_device_capability((8, 0)) and not RocmPlatform.has_device_capability((99, 0))
     assert isinstance(RocmPlatform.get_device_name(), str) and RocmPlatform.get_device_name()
     assert RocmPlatform.get_device_total_memory() > 100 << 30
+
+
+def test_block_padding_is_sized_and_validated():
+    """CacheConfig.block_pad_bytes: None = 1/32 of a block's bytes in one plane (multiples of 256), 0 = the reference's
+    dense layout; the worker sizes the cache with the padded footprint while get_cache_block_size stays the reference's
+    figure (the golden above)."""
+    mc = ModelConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, num_hidden_layers=32,
+                     dtype=torch.bfloat16)
+    dense = CacheEngine.get_cache_block_size(CacheConfig(block_size=16, block_pad_bytes=0), mc)
+    assert dense == 2 * 32 * 16 * 8 * 128 * 2
+    assert CacheEngine.get_cache_block_footprint(CacheConfig(block_size=16, block_pad_bytes=0), mc) == dense
+    auto = CacheConfig(block_size=16)
+    assert CacheEngine.block_pad_bytes(auto, mc) == 1024  # 32 KiB blocks
+    assert CacheEngine.get_cache_block_size(auto, mc) == dense
+    assert CacheEngine.get_cache_block_footprint(auto, mc) == dense + 2 * 32 * 1024
+    assert CacheEngine.block_pad_bytes(CacheConfig(block_size=16, cache_dtype="fp8"), mc) == 512  # 16 KiB blocks
+    assert CacheEngine.block_pad_bytes(CacheConfig(block_size=16, block_pad_bytes=4096), mc) == 4096
+    with pytest.raises(ValueError):
+        CacheEngine.block_pad_bytes(CacheConfig(block_size=16, block_pad_bytes=100), mc)
