@@ -531,6 +531,41 @@ def fp8_config_leg(a, dev, B, ctx, steps=32):
     return out
 
 
+def sampled_decode_leg(a, dev, B, ctx, steps=32):
+    """The headline workload with SAMPLED requests (temperature 0.8, top-k 50, top-p 0.95, per-request seeds) instead of
+    greedy ones: every step ends with the lm_head's logits and the device-side sampler (csrc/sampler.hip) inside the
+    captured graph and the multi-step burst.  Its own engine; same counting as the headline."""
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    k = largest_divisor_at_most(steps, 8)
+    fly = 2
+    max_len = ctx + steps // fly + 6 * k + 8
+    bs = 16
+    blocks = B * fly * ((max_len + bs - 1) // bs + 1) + 64
+    eng = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0),
+                    SchedulerConfig(max_num_batched_tokens=max(8192, B), max_num_seqs=B,
+                                    max_model_len=(max_len + 511) // 512 * 512, scheduling="async", max_num_on_the_fly=fly,
+                                    use_v2_block_manager=True, num_scheduler_steps=k), device=dev, seed=11)
+    eng.step_returns_outputs = False
+    g = torch.Generator().manual_seed(123)
+    for i in range(B * fly):
+        sp = SamplingParams(temperature=0.8, top_k=50, top_p=0.95, seed=1000 + i, max_tokens=4 * steps + 100, ignore_eos=True)
+        eng.add_request(str(i), torch.randint(0, cfg.vocab_size, (ctx,), generator=g).tolist(), sampling_params=sp)
+    eng.prefill_synthetic(seed=11)
+    eng.capture_decode_graphs(B)
+    decode_region(eng, B, k * fly, k, fly)  # warm-up: one burst per slot (captures the sampler flavour of the graph)
+    toks, el = decode_region(eng, B, steps, k, fly)
+    assert toks == steps * B, (toks, steps, B)
+    eng.shutdown()
+    del eng
+    return {"value": round(toks / el, 1), "unit": "tokens/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+            "config": f"the headline workload (bf16, bs={B}, ctx={ctx}, {fly} in flight, {k} model steps per engine step) with every "
+                      "request sampled: temperature 0.8, top-k 50, top-p 0.95, seeded; lm_head logits + the device-side sampler "
+                      "inside the captured step"}
+
+
 def chunked_prefill_leg(a, dev, num_prompts=96, input_len=512, output_len=512, budget=64):
     """BASELINE config 3 beside the headline: the reference's benchmarks/benchmark_chunked_prefill_throughput.py
     workload (:176-201: 512-token prompts, 512 output tokens, chunked prefill, max_num_batched_tokens = max_num_seqs
@@ -817,7 +852,8 @@ def main():
         torch.cuda.empty_cache()
         for key, leg in (("config3_chunked_prefill", lambda: chunked_prefill_leg(a, dev)),
                          ("config5_fp8_weights_fp8_kv", lambda: fp8_config_leg(a, dev, B, ctx)),
-                         ("config4_encode_only", lambda: encode_only_leg(a, dev))):
+                         ("config4_encode_only", lambda: encode_only_leg(a, dev)),
+                         ("sampled_decode", lambda: sampled_decode_leg(a, dev, B, ctx))):
             other[key] = leg()
             gc.collect()
             torch.cuda.empty_cache()

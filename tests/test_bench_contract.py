@@ -132,8 +132,10 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
         assert set(f8["roofline_projections"]["per_shape"]) == {"qkv", "o", "gate_up", "down"}
         m = o["config4_encode_only"]["mfma"]
         assert m["peak"] == 2500.0 and m["unit"] == "TFLOP/s" and 0 < m["frac"] < 1
+        sd = o["sampled_decode"]  # the headline workload with sampled requests (the device-side sampler in the step)
+        assert sd["value"] > 0 and sd["unit"] == "tokens/s" and sd["ms_per_step"] > 0 and "top-p" in sd["config"]
     else:
-        assert not any(k.startswith("config") for k in line.get("other_settings", {}))
+        assert not any(k.startswith("config") or k == "sampled_decode" for k in line.get("other_settings", {}))
     assert line["cpu_baseline"]["value"] > 0
     ops = line["ops_baseline"]["ops"]
     assert set(ops) == {"reshape_and_cache", "rms_norm", "fused_add_rms_norm", "rotary_embedding", "silu_and_mul"}
