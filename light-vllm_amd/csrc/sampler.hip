@@ -415,6 +415,9 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
     const int64_t counts_stride, const int num_slots, float* __restrict__ scratch, const int64_t scratch_stride,
     float* __restrict__ processed_out, const int64_t processed_stride, const int update_state) {
   __shared__ uint64_t hist[2048];
+  constexpr int kSurvivors = 2048;  // values >= the k-th largest that top-p walks from LDS
+  __shared__ __attribute__((aligned(16))) float survivors[kSurvivors];
+  __shared__ int s_count;
   __shared__ float sv[16];
   __shared__ int si[16];
   __shared__ uint64_t red[16];
@@ -553,7 +556,27 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(
     // ---- top-p: the smallest key whose mass from the bottom (inside the top-k set) exceeds (1 - p) Z ----
     uint32_t cut_key = kth_key;
     if (P.top_p < 1.f) {
-      const uint32_t c = select_key<true>(x_row, vocab, m, kth_key, 0, 1.f - P.top_p, hist, red, &s_bin, &s_before,
+      // With top-k in front, top-p only concerns the few values >= the k-th: one pass collects them in LDS (any order:
+      // the selection sums integers) and the three histogram passes walk that list instead of the vocabulary.  More
+      // survivors than the list holds (ties at the k-th value, a huge k): the passes walk the row as before.
+      const float* src = x_row;
+      int n_src = vocab;
+      if (kth_key != 0) {
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for_each_value<float>(x_row, vocab, [&](float x, int) {
+          if (order_key(x) >= kth_key) {
+            const int at = atomicAdd(&s_count, 1);
+            if (at < kSurvivors) survivors[at] = x;
+          }
+        });
+        __syncthreads();
+        if (s_count <= kSurvivors) {
+          src = survivors;
+          n_src = s_count;
+        }
+      }
+      const uint32_t c = select_key<true>(src, n_src, m, kth_key, 0, 1.f - P.top_p, hist, red, &s_bin, &s_before,
                                           &s_found);
       const uint32_t max_key = order_key(m);
       cut_key = s_found ? c : max_key;  // nothing exceeds the target: only the largest survives ("at least one")
