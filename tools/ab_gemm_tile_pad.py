@@ -15,13 +15,19 @@ M, COPIES, TRAIN, TRAINS = 32, 8, 32, 8
 
 
 def load(pad):
-    path = os.path.join(ROOT, "light-vllm_amd", "lib", "liblvllm_hip.so") if pad == 0 else \
-        os.path.join(ROOT, "variants", f"tilepad{pad}", "liblvllm_hip.so")
+    """pad: bytes (a -DLVLLM_GEMM_TILE_PAD build under variants/tilepad<bytes>/), 0 = the shipped library, or the name
+    of any other diagnosis build under variants/tilepad_<name>/ (same weight layout as shipped; results may be wrong)"""
+    if pad == 0:
+        path = os.path.join(ROOT, "light-vllm_amd", "lib", "liblvllm_hip.so")
+    elif isinstance(pad, str):
+        path = os.path.join(ROOT, "variants", f"tilepad_{pad}", "liblvllm_hip.so")
+    else:
+        path = os.path.join(ROOT, "variants", f"tilepad{pad}", "liblvllm_hip.so")
     return ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
 
 
 def main():
-    pads = [int(p) for p in sys.argv[1:]] or [0]
+    pads = [int(p) if p.lstrip('-').isdigit() else p for p in sys.argv[1:]] or [0]
     dev = "cuda:0"
     torch.manual_seed(0)
     libs = {p: load(p) for p in pads}
@@ -34,7 +40,7 @@ def main():
         for rnd in range(2):
             for p in pads:
                 lib = libs[p]
-                nbytes = N * K * 2 + (N // 16) * p
+                nbytes = N * K * 2 + (N // 16) * (p if isinstance(p, int) else 0)
                 packed = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(COPIES)]
                 stream = torch.cuda.current_stream().cuda_stream
                 for b in packed:
@@ -54,7 +60,7 @@ def main():
                     launch(i)
                 torch.cuda.synchronize()
                 err = float((y.float() - want).abs().max() / want.abs().max())
-                assert err < 2e-2, (name, p, err)
+                assert isinstance(p, str) or err < 2e-2, (name, p, err)
                 ts = []
                 for _ in range(TRAINS):
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -69,7 +75,7 @@ def main():
     for p in pads:
         line = "  ".join(f"{n} {'/'.join(f'{t:.2f}' for t in res[p][n])} us ({SHAPES[n][0] * SHAPES[n][1] * 2 / min(res[p][n]) / 1e6:.2f} TB/s)"
                          for n in SHAPES)
-        print(f"tile pad {p:5d}: {line}")
+        print(f"{p!s:>10}: {line}")
 
 
 if __name__ == "__main__":
