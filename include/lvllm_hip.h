@@ -424,7 +424,8 @@ int lvllm_advance_step_ex(int num_seqs, int num_queries, int block_size, int64_t
 /* ---- device-side sampler (replaces the torch sequence of light_vllm/decoding/backends/sampler.py:90-200:
  * _apply_min_tokens_penalty :238-277, _apply_penalties :281-301, _apply_top_k_top_p :304-330, _apply_min_p :333-347,
  * _greedy_sample / _multinomial :350-454) ----
- * One launch per step: tokens_out[row] int64 <- the token drawn for row `row` of `logits` [num_rows, vocab]
+ * One call per step (one launch, or two -- see `scratch`): tokens_out[row] int64 <- the token drawn for row `row` of
+ * `logits` [num_rows, vocab]
  * (row stride logits_stride elements, element type `logits_dtype` = enum lvllm_dtype).
  * state_slot (nullable) int32 [num_rows]: the request's slot in the device-resident sampler state, or < 0 for a
  * plain greedy row (arg-max of the logits, ties to the smaller index -- torch.argmax).  A slot is
