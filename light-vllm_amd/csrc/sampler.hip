@@ -1,5 +1,6 @@
 // Device-side sampler: everything between the lm_head's logits and the next token ids of a decode step, in one call
-// (one launch, or two: selection, then a draw shared by several workgroups per row), so that a step with sampled (non-greedy) requests stays inside the captured graph and the multi-step burst.
+// (one launch, or two: selection, then a draw shared by several workgroups per row), so that a step with sampled
+// (non-greedy) requests stays inside the captured graph and the multi-step burst.
 //
 // WHAT (reference: light_vllm/decoding/backends/sampler.py:90-200 forward; :238-277 _apply_min_tokens_penalty;
 // :281-301 _apply_penalties; :304-330 _apply_top_k_top_p; :333-347 _apply_min_p; :434-454 _multinomial):
