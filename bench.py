@@ -88,6 +88,12 @@ def parse():
                          "weights + fp8 KV cache); each builds its own engine after the headline region")
     ap.add_argument("--skip-prefill-roofline", action="store_true",
                     help="no roofline_prefill object (one 16k-token prompt through the prefill kernel)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="the timed region (EXACTLY --steps model steps, barrier + synchronize on both sides) is run this "
+                         "many times back to back and `value` is the MEDIAN region; 0 = auto: min(5, 100 // steps), i.e. "
+                         "one region at the default 64 steps, five when a caller passes --steps 20 (a 68 ms region moves "
+                         "+-1 % from run to run)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the rank to its GPU's NUMA cores")
     ap.add_argument("--kernel-iters", type=int, default=224)  # 20 warm-up + 200 timed launches
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check)")
     ap.add_argument("--replica-backend", default=None, choices=["nccl", "gloo"],
@@ -181,6 +187,86 @@ def kernel_leg(engine, B, iters, seq_len=None):
     pairs = len(seqs) * KVH * ((H // KVH + 15) // 16)
     nsplit = max(1, min(P, (2048 + 8 * pairs - 1) // (8 * pairs), ((max_len + 15) // 16) // 4))
     return dict(avg_s=avg, min_s=min(ts), algo_bytes=algo_bytes, lens=lens, partitions=P, nsplit=nsplit)
+
+
+def in_step_attention_leg(engine, B, seq_len, trains=6):
+    """The launch a decode step of the engine really makes: rotary_embedding + reshape_and_cache + paged_attention_v2
+    as ONE kernel (the ROPE instantiation of paged_attn_mfma_kernel, `_C_amd.rope_cache_paged_attention`), timed like
+    `kernel_leg` -- trains of one launch per layer cache between a HIP event pair on the launch stream -- with the new
+    token at position seq_len - 1 of every sequence (it is rotated, written to the caches and attended to).  Each train
+    is a captured graph of the 32 launches, so the host's dispatch cost is not in the figure.  None when the engine's
+    configuration is outside the fused launch's envelope."""
+    from light_vllm_amd.paged_attn import PagedAttention
+    cfg = engine.model_config
+    dev = engine.device
+    H, KVH, D, BS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, engine.cache_config.block_size
+    kv = engine.cache_config.cache_dtype
+    model = engine.worker.model
+    if not hasattr(torch.ops._C_amd, "rope_cache_paged_attention") or getattr(model, "cos_sin_cache", None) is None:
+        return None
+    bm = engine.scheduler.block_manager
+    seqs = [g.seqs[0] for g in list(engine.scheduler.running)[:B]]
+    if not seqs or min(s.get_len() for s in seqs) < seq_len:
+        return None
+    tables = [bm.get_block_table(s) for s in seqs]
+    width = max(len(t) for t in tables)
+    bt = torch.zeros(len(seqs), width, dtype=torch.int32)
+    for i, t in enumerate(tables):
+        bt[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    slots = (bt[:, (seq_len - 1) // BS].long() * BS + (seq_len - 1) % BS).to(dev)
+    bt = bt.to(dev)
+    sl = torch.full((len(seqs),), seq_len, dtype=torch.int32, device=dev)
+    pos = torch.full((len(seqs),), seq_len - 1, dtype=torch.int64, device=dev)
+    qkv = (torch.randn(len(seqs), (H + 2 * KVH) * D, device=dev) * 0.5).to(cfg.dtype)
+    qv, kv_, vv = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
+    out = torch.empty(len(seqs), H, D, dtype=cfg.dtype, device=dev)
+    P = (seq_len + 511) // 512
+    tmp = torch.empty(len(seqs), H, P, D, dtype=cfg.dtype, device=dev)
+    es = torch.empty(len(seqs), H, P, dtype=torch.float32, device=dev)
+    ml = torch.empty_like(es)
+    caches = [PagedAttention.split_kv_cache(c, KVH, D) for c in engine.worker.cache_engine.gpu_cache]
+    cos_sin = model.cos_sin_cache
+
+    def launch(i):
+        kc, vc = caches[i % len(caches)]
+        return torch.ops._C_amd.rope_cache_paged_attention(out, es, ml, tmp, pos, qv, kv_, vv, D, cos_sin, True, kc, vc,
+                                                           slots, KVH, D ** -0.5, bt, sl, BS, seq_len, kv, 1.0, 1.0)
+    if not launch(0):
+        return None
+    for i in range(len(caches)):
+        launch(i)
+    torch.cuda.synchronize(dev)
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for i in range(len(caches)):
+                launch(i)
+    torch.cuda.synchronize(dev)
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(trains)]
+    for a_, b_ in evs:
+        a_.record()
+        graph.replay()
+        b_.record()
+    torch.cuda.synchronize(dev)
+    ts = [a_.elapsed_time(b_) * 1e-3 / len(caches) for a_, b_ in evs]
+    avg = sum(ts) / len(ts)
+    kv_fp8 = kv != "auto"
+    n = len(seqs)
+    plain = (2 * n * seq_len * KVH * D * (1 if kv_fp8 else 2) + 2 * n * H * D * 2 + n * ((seq_len + BS - 1) // BS) * 4 + n * 4)
+    # what the fused launch moves besides: the new key / value rows in, their cache rows out, one cos / sin row, the
+    # position and the slot of every sequence
+    own = plain + 2 * n * KVH * D * 2 + 2 * n * KVH * D * (1 if kv_fp8 else 2) + n * D * 2 + n * 16
+    return {"kernel": "paged_attn_mfma_kernel<..., ROPE = true> (rotary_embedding + reshape_and_cache + "
+                      "paged_attention_v2 in one launch: the attention launch of the engine's decode step)",
+            "avg_launch_us": round(avg * 1e6, 2), "min_launch_us": round(min(ts) * 1e6, 2),
+            "algorithmic_bytes_per_launch": own, "achieved": round(own / avg / 1e9, 1), "unit": "GB/s",
+            "frac": round(own / avg / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_on_plain_bytes": round(plain / avg / 1e9 / HBM_PEAK_GBS, 4),
+            "timing": f"HIP events around {trains} replays of a captured train of {len(caches)} launches (one per layer "
+                      f"cache), seq_lens = {seq_len}"}
 
 
 def gemm_leg(engine, B):
@@ -490,6 +576,7 @@ def fp8_config_leg(a, dev, B, ctx, steps=32):
     toks, el = decode_region(eng, B, steps, k, fly)
     assert toks == steps * B, (toks, steps, B)
     kl = kernel_leg(eng, B, a.kernel_iters, seq_len=ctx)
+    in_step = in_step_attention_leg(eng, B, ctx)
     gm = gemm_leg(eng, B) if B <= 64 else None
     L = cfg.num_hidden_layers
     kv_step = 2 * B * ctx * cfg.num_key_value_heads * cfg.head_dim * 1 * L
@@ -505,7 +592,7 @@ def fp8_config_leg(a, dev, B, ctx, steps=32):
                                   "achieved": round(kl["algo_bytes"] / kl["avg_s"] / 1e9, 1), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(kl["algo_bytes"] / kl["avg_s"] / 1e9 / HBM_PEAK_GBS, 4),
                                   "algorithmic_bytes_per_launch": kl["algo_bytes"],
-                                  "avg_launch_us": round(kl["avg_s"] * 1e6, 2)}}
+                                  "avg_launch_us": round(kl["avg_s"] * 1e6, 2), "in_step": in_step}}
     try:
         with open(os.path.join(ROOT, "profiles", "r03_pmc_attn_fp8.json")) as f:
             out["roofline_attention"]["traffic"] = int(json.load(f)["traffic_over_algorithmic"] * kl["algo_bytes"])
@@ -703,6 +790,10 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_replicas(a))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: before this process touches its GPU it pins itself to its GPU's NUMA cores, cut among the ranks that share
+    # the node (a call, not a re-exec): eight Python schedulers on one host are the scaling risk SURVEY 8e names
+    from light_vllm_amd.engine.replicas import pin_to_gpu_numa
+    pin = pin_to_gpu_numa() if (a.gpus > 1 and not a.no_pin) else {"pinned": False, "reason": "one replica"}
     dev = "cuda:0" if a.single_device else f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
 
@@ -732,7 +823,8 @@ def main():
     if a.o_proj_partials_min_rows is not None:
         cfg.o_proj_partials_min_rows = a.o_proj_partials_min_rows
     cfg.quantization = a.quantization
-    total_steps = a.steps + a.warmup
+    reps = a.repeats if a.repeats > 0 else max(1, min(5, 100 // max(1, a.steps)))
+    total_steps = a.steps * reps + a.warmup
     max_len = ctx + total_steps // on_the_fly + (a.steps + 2 * k) // max(1, slots) + 2 * k_max + 8
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
@@ -788,18 +880,24 @@ def main():
 
     if a.warmup > 0:
         run(a.warmup, kw)
-    torch.cuda.synchronize(dev)
-    group.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    tokens = run(a.steps, k)
-    torch.cuda.synchronize(dev)
-    group.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    assert tokens == a.steps * B, (tokens, a.steps, B)
-    elapsed = group.max(elapsed)            # slowest replica's clock
-    value = group.sum(tokens) / elapsed      # whole-job tokens/s
+    # The timed region: EXACTLY --steps model steps between barrier + synchronize on both sides, the clock the
+    # slowest rank's.  Run `reps` times back to back (each an empty pipeline on both sides); the line reports the
+    # MEDIAN region and lists them all -- a 20-step region lasts 68 ms and moves +-1 % from run to run.
+    regions = []
+    for _ in range(reps):
+        torch.cuda.synchronize(dev)
+        group.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        tokens = run(a.steps, k)
+        torch.cuda.synchronize(dev)
+        group.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        assert tokens == a.steps * B, (tokens, a.steps, B)
+        el = group.max(el)                          # slowest replica's clock
+        regions.append((group.sum(tokens) / el, el))  # whole-job tokens/s of this region
+    value, elapsed = sorted(regions)[len(regions) // 2]
     # More steps in flight (a SchedulerConfig setting of the reference; BASELINE.md quotes the headline at 2): B more
     # sequences per extra step are admitted at the same context, one burst per slot warms the new pipeline depth,
     # then the same number of model steps is timed again.  Reported beside the headline, never as `value`.
@@ -821,6 +919,7 @@ def main():
                                                 "ms_per_step": round(el2 / a.steps * 1e3, 4),
                                                 "sequences_resident": B * extra}
     kl = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
+    in_step = in_step_attention_leg(engine, B, ctx) if rank == 0 else None
     gm = gemm_leg(engine, B) if B <= 64 else None
     cpu = ops_base = None
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
@@ -878,6 +977,8 @@ def main():
                                    "random-init weights, synthetic KV",
                        "global_batch": B * world, "seq_len": ctx, "parallelism": f"dp{world} (independent replicas)",
                        "num_scheduler_steps": k, "max_num_on_the_fly": on_the_fly},
+            "timed_regions": {"count": reps, "value": "median", "tokens_per_s": [round(v, 1) for v, _ in regions],
+                              "ms_per_step": [round(e / a.steps * 1e3, 4) for _, e in regions]},
             "roofline": {"bound": "hbm", "kernel": "paged_attention_v2 (paged_attn_mfma_kernel): "
                                                       + ("single pass, nsplit = 1 -- the batch alone fills the GPU, no "
                                                          "reduce launch, scratch untouched" if kl["nsplit"] == 1 else
@@ -889,9 +990,12 @@ def main():
                                            "separate passes of the same kernel at seq = 1024: 2*FETCH_SIZE + WRITE_SIZE per "
                                            "launch, scaled by this launch's algorithmic bytes; a recording, not this run)",
                          "algorithmic_bytes_per_launch": kl["algo_bytes"],
-                         "avg_launch_us": round(kl["avg_s"] * 1e6, 2), "min_launch_us": round(kl["min_s"] * 1e6, 2)},
+                         "avg_launch_us": round(kl["avg_s"] * 1e6, 2), "min_launch_us": round(kl["min_s"] * 1e6, 2),
+                         "in_step": in_step},
             "cpu_baseline": cpu,
         }
+        if world > 1:
+            line["affinity_rank0"] = pin
         if other:
             line["other_settings"] = other
         if ops_base is not None:

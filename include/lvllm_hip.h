@@ -454,6 +454,11 @@ int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_t logits_st
 int lvllm_sampler_init_row(int32_t* counts_row, int vocab, const int64_t* prompt_tokens, int n_prompt,
                            const int64_t* output_tokens, int n_output, void* stream);
 
+/* Test hook for the draw's arithmetic: out float [n, 3] <- { u, q = -ln(u), ln(q) } for the 32-bit random words
+ * r [n] (device pointers), computed by the device code the draw itself runs: u = ((r >> 9) + 0.5) * 2^-23 lies
+ * strictly inside (0, 1), so q > 0 and the race score x - ln(q) is finite for every r. */
+int lvllm_sampler_draw_probe(const uint32_t* r, float* out, int n, void* stream);
+
 /* convert_fp8: csrc/cache_kernels.cu:334-410, torch_bindings.cpp:261-264 ("only for testing" there).
  * to_fp8 != 0: dst (bytes) = fp8(float(src) / scale); else dst = T(float(fp8 src) * scale).  `dtype` is the
  * element type of the non-fp8 side; contiguous buffers of num_elems elements. */

@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional, Tuple, Type
 import numpy as np
 import torch
 
-from ..paged_attn import PagedAttention
+from ..paged_attn import PagedAttention, num_compute_units
 
 PAD_SLOT_ID = -1  # backends/utils.py:13
 
@@ -337,7 +337,7 @@ class PagedAttnImpl:
             max_len = decode_meta.max_decode_seq_len
             force = self.decode_version
             use_v1 = (force == "v1") if force else PagedAttention.use_v1(
-                dq.shape[0], self.num_kv_heads, self.num_heads, max_len)
+                dq.shape[0], self.num_kv_heads, self.num_heads, max_len, num_compute_units(dq.device))
             scratch = None if use_v1 else (decode_meta.decode_scratch or self._v2_scratch(dq.shape[0], max_len, dq))
             alibi = self.alibi_slopes
             if alibi is not None and alibi.device != dq.device:
@@ -392,8 +392,8 @@ class PagedAttnImpl:
             return pair if pair is not None else (self.decode_attention(query, key_cache, value_cache, attn_metadata), None)
         max_len = md.max_decode_seq_len
         force = self.decode_version
-        use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads,
-                                                                      self.num_heads, max_len)
+        use_v1 = (force == "v1") if force else PagedAttention.use_v1(dq.shape[0], self.num_kv_heads, self.num_heads,
+                                                                      max_len, num_compute_units(dq.device))
         scratch = None if use_v1 else (md.decode_scratch or self._v2_scratch(dq.shape[0], max_len, dq))
         alibi = self.alibi_slopes
         if alibi is not None and alibi.device != dq.device:

@@ -346,15 +346,22 @@ __device__ __forceinline__ int meet_parts(float* area, const int W, const int pa
   __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been acknowledged by the L2
   __syncthreads();
   if (tid == 0) {
-    area[part] = bv;
-    iarea[kSamplerMaxParts + part] = bi;
-    iarea[2 * kSamplerMaxParts + 1 + part] = (int)(xcc & 0xf);
-    __builtin_amdgcn_s_waitcnt(0);
+    // The record itself travels write-through (agent-scope stores = sc1: they leave this XCD's L2) and is read back
+    // with agent-scope loads after the reader's own atomic has returned, so the three words -- the XCD id among them
+    // -- are fresh wherever the parts ran; only the ROW's working values rely on the shared L2, and the ids say
+    // whether they may.  (With plain stores a part that ran on another XCD left its id in THAT L2 and the last
+    // workgroup compared against the id of an earlier launch: the fallback could not fire when it was needed.)
+    __hip_atomic_store(area + part, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(iarea + kSamplerMaxParts + part, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(iarea + 2 * kSamplerMaxParts + 1 + part, (int)(xcc & 0xf), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the arrival is counted
     *s_last = __hip_atomic_fetch_add(iarea + 2 * kSamplerMaxParts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W - 1;
   }
   __syncthreads();
   if (!*s_last) return 0;
-  if (tid == 0) iarea[2 * kSamplerMaxParts] = 0;  // for the next launch
+  if (tid == 0)  // for the next launch (an agent-scope store: the counter lives at the memory side)
+    __hip_atomic_store(iarea + 2 * kSamplerMaxParts, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bv = -INFINITY;
   bi = 0x7fffffff;
   bool same_l2 = true;
@@ -366,6 +373,18 @@ __device__ __forceinline__ int meet_parts(float* area, const int W, const int pa
     if (i != 0x7fffffff && (v > bv || (v == bv && i < bi) || bi == 0x7fffffff)) { bv = v; bi = i; }
   }
   return same_l2 ? 1 : 2;
+}
+
+// ln(q) of the exponential race: q = -ln(u), u uniform in the OPEN interval (0, 1).  23 random bits + 0.5 is exact in
+// fp32 (24 significant bits), so u lies in [2^-24, 1 - 2^-24]: with 24 bits, (r >> 8) + 0.5 = 16 777 215.5 rounded to
+// 2^24, u was 1.0 once in 2^24 draws, q = 0 and the score +inf -- that token won whatever its probability.
+// The clamp keeps the score finite whatever v_log_f32 returns at the ends.
+__device__ __forceinline__ float draw_uniform(const uint32_t r) {
+  return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f;  // 2^-23
+}
+__device__ __forceinline__ float draw_neg_log_q(const uint32_t r) {
+  const float q = fmaxf(-__logf(draw_uniform(r)), 1.17549435e-38f);
+  return __logf(q);
 }
 
 // The draw over the 4-value groups [first, first + n) of a working row: min-p, then the arg-max over the kept tokens of
@@ -397,9 +416,7 @@ __device__ __forceinline__ void draw_range(const float* __restrict__ x_row, cons
       if (f.v[e] > -INFINITY) {
         // arg-max of p_i / q_i, q_i = -ln(u_i) ~ Exp(1), as x_i - ln(q_i); the hardware logarithm (v_log_f32) is
         // this kernel's own definition of its random stream: nothing outside compares these bits
-        const float u = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
-        const float q = -__logf(u);
-        const float sc = (f.v[e] - m) - __logf(q);
+        const float sc = (f.v[e] - m) - draw_neg_log_q(r[e]);
         const int i = i4 * 4 + e;
         if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
       }
@@ -733,6 +750,26 @@ extern "C" int lvllm_sample_rows(int64_t* tokens_out, const void* logits, int64_
     hipLaunchKernelGGL(sampler_draw_kernel, dim3(num_rows, W), dim3(kSamplerThreads), 0, s, tokens_out, vocab, state_slot,
                        pp, counts, counts_stride, num_slots, scratch, scratch_stride, processed_out, processed_stride,
                        update_state);
+  LV_LAUNCH_CHECK();
+  return 0;
+}
+
+// Test hook: out[3 i .. 3 i + 2] = { u, -ln(u) clamped, ln(q) } of the draw arithmetic for the random word r[i]
+// (draw_uniform / draw_neg_log_q above, the same device code the draw runs), so the ends of the range are checked on
+// the hardware logarithm itself (tests/test_sampler_gpu.py).
+__global__ void sampler_draw_probe_kernel(const uint32_t* __restrict__ r, float* __restrict__ out, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float u = draw_uniform(r[i]);
+  out[3 * i] = u;
+  out[3 * i + 1] = fmaxf(-__logf(u), 1.17549435e-38f);
+  out[3 * i + 2] = draw_neg_log_q(r[i]);
+}
+
+extern "C" int lvllm_sampler_draw_probe(const uint32_t* r, float* out, int n, void* stream) {
+  LV_CHECK(r != nullptr && out != nullptr && n >= 0, "bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sampler_draw_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, r, out, n);
   LV_LAUNCH_CHECK();
   return 0;
 }

@@ -52,7 +52,7 @@ class DeviceSampler:
         self._clock = 0
         self._rng = random.Random(seed)  # seeds of requests that did not bring one
         self._seeds: Dict[int, int] = {}
-        self._scratch: Dict[int, torch.Tensor] = {}
+        self._scratch: Dict[tuple, torch.Tensor] = {}
         self.evictions = 0
 
     # ---- slots ----
@@ -115,10 +115,15 @@ class DeviceSampler:
         One per launch in flight (per captured graph): launches must not share it."""
         return torch.zeros(rows, ((self.vocab_size + 3) & ~3) + 64, dtype=torch.float32, device=device or self.device)
 
-    def scratch_for(self, rows: int) -> torch.Tensor:
-        t = self._scratch.get(rows)
+    def scratch_for(self, rows: int, device=None) -> torch.Tensor:
+        """The eager path's working rows, kept per (rows, stream): a buffer belongs to one launch at a time, launches
+        on one stream are ordered, and steps in flight run on their own streams."""
+        device = device or self.device
+        stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        key = (rows, str(device), stream)
+        t = self._scratch.get(key)
         if t is None:
-            t = self._scratch[rows] = self.new_scratch(rows)
+            t = self._scratch[key] = self.new_scratch(rows, device)
         return t
 
     def sample(self, logits: torch.Tensor, state_slot: torch.Tensor, tokens_out: Optional[torch.Tensor] = None,
@@ -129,7 +134,7 @@ class DeviceSampler:
         if tokens_out is None:
             tokens_out = torch.empty(rows, dtype=torch.long, device=logits.device)
         if scratch is None:
-            scratch = self.new_scratch(rows, logits.device)
+            scratch = self.scratch_for(rows, logits.device)
         torch.ops._C_amd.sample_rows(tokens_out, logits, state_slot, self.params, self.counts, scratch, processed_out,
                                      update_state)
         return tokens_out

@@ -155,6 +155,22 @@ class Worker:
         step = per_layer * cfg.num_hidden_layers + rows * 4096 * 16 + (8 << 20)
         return 2 * self.num_slots * step
 
+    def sampler_state_slots(self, scheduler_config: SchedulerConfig) -> int:
+        """State slots of the device sampler: every sequence of every step in flight plus one step being built."""
+        return max(64, scheduler_config.max_num_seqs * (self.num_slots + 1))
+
+    def sampler_reserve_bytes(self, scheduler_config: SchedulerConfig) -> int:
+        """Device memory the device-side sampler takes once a request is not plain greedy (created lazily, after the
+        cache is sized: ADVICE r03): its state -- int32 [slots, vocab] counts + 128-byte records -- and, per step in
+        flight and captured batch size, the sampled graph flavour's working rows (fp32 [rows, vocab + 64]) and its
+        logits (model dtype and the fp32 copy the lm_head path may keep).  An upper bound, like the graph reserve."""
+        vocab = self.model_config.vocab_size
+        state = self.sampler_state_slots(scheduler_config) * (vocab * 4 + 128)
+        rows = min(scheduler_config.max_num_seqs, 64)
+        per_flavour = rows * ((((vocab + 3) & ~3) + 64) * 4 + vocab * (2 + 4))
+        flavours = 2 * self.num_slots if self.use_hip_graph else 1
+        return state + flavours * per_flavour
+
     def determine_num_available_blocks(self, scheduler_config: Optional[SchedulerConfig] = None) -> Tuple[int, int]:
         """(num_gpu_blocks, num_cpu_blocks) as gpu_worker.py:95-144 computes them: weights = free memory
         before the model minus free memory after; a profile forward with no KV cache; peak = everything the
@@ -170,7 +186,8 @@ class Worker:
         out = self.kv_blocks_from_profile(total, self.init_gpu_memory, free_after_load, free_after_profile,
                                           self.cache_config.gpu_memory_utilization, scheduler_config.scheduling,
                                           block_bytes, self.cache_config.swap_space_bytes,
-                                          self.graph_reserve_bytes(scheduler_config))
+                                          self.graph_reserve_bytes(scheduler_config)
+                                          + self.sampler_reserve_bytes(scheduler_config))
         self.profile = dict(total=total, init_free=self.init_gpu_memory, free_after_load=free_after_load,
                             free_after_profile=free_after_profile, block_bytes=block_bytes)
         import gc
@@ -576,7 +593,7 @@ class LLMEngine:
             return None
         if self.device_sampler is None:
             from ..device_sampler import DeviceSampler
-            n = max(64, self.scheduler_config.max_num_seqs * (self.num_slots + 1))
+            n = self.worker.sampler_state_slots(self.scheduler_config)  # reserved when the cache was sized
             self.device_sampler = self.worker.sampler = DeviceSampler(self.model_config.vocab_size, self.device, n,
                                                                       seed=self._sampler_seed)
 

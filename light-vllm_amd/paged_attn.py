@@ -16,7 +16,23 @@ import torch
 from . import _custom_ops as ops
 
 _PARTITION_SIZE = 512  # csrc/attention/attention_kernels.cu:850
-_NUM_CUS = 256
+_HIP_ATTR_MULTIPROCESSOR_COUNT = 63  # hipDeviceAttributeMultiprocessorCount (hip_runtime_api.h)
+_cu_count_of = {}
+
+
+def num_compute_units(device=None) -> int:
+    """CUs of the device a launch goes to, asked once per device through the reference's own utility op
+    (`_C_cuda_utils.get_device_attribute`, torch_bindings.cpp:271-274) -- the C side sizes its grids from the same
+    attribute; 256 on an MI355X."""
+    idx = torch.device(device).index if device is not None else None
+    if idx is None:
+        idx = torch.cuda.current_device()
+    n = _cu_count_of.get(idx)
+    if n is None:
+        n = _cu_count_of[idx] = int(ops.get_device_attribute(_HIP_ATTR_MULTIPROCESSOR_COUNT, idx))
+        if n <= 0:
+            raise RuntimeError(f"device {idx} reports {n} compute units")
+    return n
 
 
 @dataclass
@@ -64,13 +80,17 @@ class PagedAttention:
                               k_scale, v_scale)
 
     @staticmethod
-    def use_v1(num_seqs: int, num_kv_heads: int, num_heads: int, max_seq_len: int) -> bool:
+    def use_v1(num_seqs: int, num_kv_heads: int, num_heads: int, max_seq_len: int,
+               num_cus: Optional[int] = None) -> bool:
         """One pass (v1) when the (sequence, kv head, head group) grid alone fills the CUs or the
-        context fits a single partition; otherwise v2 cuts the contexts."""
+        context fits a single partition; otherwise v2 cuts the contexts.  `num_cus`: the CUs of the device the
+        launch goes to (default: asked of the current device)."""
         if _ceil_div(max_seq_len, _PARTITION_SIZE) == 1:
             return True
         groups_per_kv_head = _ceil_div(num_heads // num_kv_heads, 16)
-        return num_seqs * num_kv_heads * groups_per_kv_head >= _NUM_CUS
+        if num_cus is None:
+            num_cus = num_compute_units()
+        return num_seqs * num_kv_heads * groups_per_kv_head >= num_cus
 
     @staticmethod
     def forward_decode(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
@@ -92,7 +112,7 @@ class PagedAttention:
         common = (query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
                   value_cache.shape[3], max_seq_len, alibi_slopes)
         single_pass = (force_version == "v1") if force_version is not None else \
-            PagedAttention.use_v1(num_seqs, num_kv_heads, num_heads, max_seq_len)
+            PagedAttention.use_v1(num_seqs, num_kv_heads, num_heads, max_seq_len, num_compute_units(query.device))
         if single_pass:
             ops.paged_attention_v1(out, *common, *tail)
             return out

@@ -232,12 +232,29 @@ class DataParallelEncodeEngine:
             self.num_on_the_fly += 1
         if self.num_on_the_fly == 0:
             return outs
-        try:
-            res: ExecuteOutput = self.executor_out.get(timeout=self.step_timeout_s)
-        except queue.Empty:
-            dead = [i for i, p in enumerate(self.procs or []) if not p.is_alive()]
-            raise RuntimeError(f"no step completed within {self.step_timeout_s:.0f} s ({self.num_on_the_fly} in flight; "
-                               f"dead workers: {dead})")
+        # Wake up every second and look at the workers: one that died on a GPU fault or an out-of-memory kill after
+        # it took a step off the shared queue will never answer, and the queue does not say which step it held --
+        # so every outstanding step is failed at once, its requests leave the scheduler's books (as on the error
+        # path below) and the caller hears about it within a second, not after `step_timeout_s`.
+        res: Optional[ExecuteOutput] = None
+        waited = 0.0
+        while res is None:
+            try:
+                res = self.executor_out.get(timeout=min(1.0, self.step_timeout_s))
+            except queue.Empty:
+                waited += min(1.0, self.step_timeout_s)
+                dead = [(i, p.exitcode) for i, p in enumerate(self.procs or []) if not p.is_alive()]
+                if dead or waited >= self.step_timeout_s:
+                    lost = sorted(self._steps)
+                    for sid in lost:
+                        sched = self._steps.pop(sid)
+                        self.scheduler.requests.difference_update(r.request_id for r in sched.scheduled_requests)
+                    self.num_on_the_fly = 0
+                    if dead:
+                        raise RuntimeError(f"worker(s) died (rank, exit code): {dead}; steps {lost} failed and their "
+                                           f"requests were dropped")
+                    raise RuntimeError(f"no step completed within {self.step_timeout_s:.0f} s; steps {lost} failed and "
+                                       f"their requests were dropped")
         self.num_on_the_fly -= 1
         sched = self._steps.pop(res.step_id)
         if res.error is not None:  # the step's requests will never produce an output: they leave the books

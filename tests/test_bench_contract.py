@@ -114,6 +114,13 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     check_line(line, 8)
+    # 24-step regions are short: four of them, each exactly 24 model steps; `value` is the median one
+    tr = line["timed_regions"]
+    assert tr["count"] == 4 and len(tr["tokens_per_s"]) == 4 and tr["value"] == "median"
+    assert line["value"] == sorted(tr["tokens_per_s"])[2] and line["ms_per_step"] in tr["ms_per_step"]
+    # the launch the step really makes (rope + cache write + attention in one kernel) beside the plain one
+    ins = line["roofline"]["in_step"]
+    assert ins is None or (ins["avg_launch_us"] > 0 and "ROPE" in ins["kernel"] and 0 < ins["frac"] < 1.5)
     if "sync" not in extra:  # the headline at two steps in flight, three reported beside it
         assert line["config"]["max_num_on_the_fly"] == 2
         o = line["other_settings"]["max_num_on_the_fly=3"]

@@ -84,6 +84,24 @@ def test_a_failing_step_surfaces_and_its_requests_leave_the_books():
     assert not eng.has_unfinished_requests()
 
 
+def test_a_worker_that_dies_with_a_step_is_noticed_within_seconds():
+    """a worker process that dies after taking a step off the shared queue never answers.  The front end
+    looks at its workers every second, fails every outstanding step, drops their requests from the books and raises
+    -- long before the 600 s step timeout."""
+    import time
+    eng = make(FakeWorkerFactory([50], die_token=424242), dp=1, max_seqs=2, on_the_fly=2)
+    eng.step_timeout_s = 600.0
+    eng.add_request("a", [1, 2, 3])
+    eng.add_request("b", [4, 424242, 5])
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="died"):
+        while eng.has_unfinished_requests() or eng.num_on_the_fly > 0:
+            eng.step()
+    assert time.time() - t0 < 30
+    assert eng.num_on_the_fly == 0 and not eng.has_unfinished_requests()
+    eng.shutdown()
+
+
 def test_a_worker_that_fails_to_start_is_reported():
     eng = make(FakeWorkerFactory([50, 50], fail_start=1))
     eng.add_request("0", [1, 2, 3])

@@ -269,3 +269,36 @@ def test_first_pass_shared_by_workgroups_gives_the_same_tokens_and_state():
     for a, b in zip(pa, pb):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     assert torch.equal(ca, cb) and torch.equal(qa, qb)
+
+
+def test_the_uniform_of_the_draw_never_reaches_its_ends():
+    """with 24 random bits + 0.5 the sum 16 777 215.5 rounded to 2^24, u was exactly 1.0 once in
+    2^24 draws, q = -ln(1) = 0 and the race score +inf: that token won whatever its probability (~0.8 % of the draws
+    over a 128 k vocabulary).  The device arithmetic itself (lvllm_sampler_draw_probe = the draw's own helpers) at the
+    ends of the range and on random words: 0 < u < 1, q > 0, the score term finite."""
+    import ctypes
+    from light_vllm_amd import _native
+    lib = _native.load_hip_library()
+    lib.lvllm_sampler_draw_probe.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(5)
+    words = torch.cat([torch.tensor([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFDFF, 0xFFFFFE00, 0xFFFFFEFF,
+                                     0xFFFFFF00, 0xFFFFFFFE, 0xFFFFFFFF], dtype=torch.int64),
+                       torch.randint(0, 2**32, (4084,), generator=g, dtype=torch.int64)])
+    r = words & 0xFFFFFFFF
+    r32 = torch.from_numpy(r.numpy().astype(np.uint32).view(np.int32)).to(DEV)
+    out = torch.full((r32.numel(), 3), float("nan"), dtype=torch.float32, device=DEV)
+    rc = lib.lvllm_sampler_draw_probe(ctypes.c_void_p(r32.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                      ctypes.c_int(r32.numel()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.lvllm_last_error()
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    u, q, lq = o[:, 0], o[:, 1], o[:, 2]
+    want_u = ((r.numpy().astype(np.uint32) >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    assert np.array_equal(u, want_u)                       # exact: 23 bits + 0.5 fits fp32
+    assert u.min() > 0.0 and u.max() < 1.0, (u.min(), u.max())
+    assert u[11] == np.float32(1.0) - np.float32(2.0 ** -24) and u[0] == np.float32(2.0 ** -24)
+    assert np.isfinite(q).all() and (q > 0).all()
+    assert np.isfinite(lq).all(), lq[~np.isfinite(lq)]
+    # the round-3 form for comparison: it does reach 1.0 in fp32
+    old = (np.float32(0xFFFFFFFF >> 8) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    assert old == np.float32(1.0)

@@ -119,3 +119,17 @@ def test_sampling_params_validation_and_greedy_normalisation():
                 dict(presence_penalty=3.0), dict(max_tokens=0)):
         with pytest.raises(ValueError):
             _params(**bad)
+
+
+def test_the_draw_uniform_is_strictly_inside_the_unit_interval():
+    """The fp32 arithmetic of the device draw (csrc/sampler.hip draw_uniform), restated in numpy: 23 random bits + 0.5
+    scaled by 2^-23 is exact and stays in [2^-24, 1 - 2^-24]; the round-3 form (24 bits + 0.5, scaled by 2^-24)
+    rounds to 1.0 at the top word, which made -ln(u) = 0 and the race score infinite."""
+    import numpy as np
+    r = np.array([0, 1, 0x1FF, 0x200, 0xFFFFFE00, 0xFFFFFFFF], dtype=np.uint32)
+    u = ((r >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    assert u.dtype == np.float32 and u.min() == np.float32(2.0 ** -24) and u.max() == np.float32(1.0) - np.float32(2.0 ** -24)
+    q = -np.log(u.astype(np.float64))
+    assert (q > 0).all() and np.isfinite(np.log(q)).all()
+    old = ((r >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    assert old.max() == np.float32(1.0)
