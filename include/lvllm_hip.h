@@ -57,7 +57,8 @@ const char* lvllm_last_error(void);
 /* build identification: "lvllm_hip gfx950 <abi version>" */
 const char* lvllm_version(void);
 /* Launch-shape knobs for the host's concurrency level (process-wide): "gemm_workgroups" (default
- * 256; 128 when two steps run on two streams), "attn_waves" (8 | 4), "attn_splits" (paged_attention_v2:
+ * 256; 128 when two steps run on two streams), "gemm_balance" (1 | 0: a decode GEMM takes the fewest workgroups
+ * <= gemm_workgroups that need no more rounds of n-tiles than gemm_workgroups would), "attn_waves" (8 | 4), "attn_splits" (paged_attention_v2:
  * 0 = shares chosen per call, n >= 1 = n shares, -1 = the reference's 512-token partitions),
  * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used),
  * "prefill_mfma32_min_query" (paged_prefill_attention: plain launches -- head size 64 or 128, 16-bit cache -- whose

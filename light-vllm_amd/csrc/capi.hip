@@ -39,6 +39,8 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
   } else if (k == "gemm_partials_ksplit") {
     LV_CHECK(value >= 0 && value <= 16, "gemm_partials_ksplit must be in [0, 16]");
     lvllm::tuning().gemm_partials_ksplit = value;
+  } else if (k == "gemm_balance") {
+    lvllm::tuning().gemm_balance = value != 0;
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
@@ -76,6 +78,7 @@ extern "C" int lvllm_get_tuning(const char* key, int* value) {
   else if (k == "gemm_workgroups_wide") *value = t.gemm_workgroups_wide;
   else if (k == "gemm_wide_min_tiles") *value = t.gemm_wide_min_tiles;
   else if (k == "gemm_partials_ksplit") *value = t.gemm_partials_ksplit;
+  else if (k == "gemm_balance") *value = t.gemm_balance;
   else if (k == "attn_waves") *value = t.attn_waves;
   else if (k == "attn_splits") *value = t.attn_splits;
   else if (k == "swap_kernel_min_runs") *value = t.swap_kernel_min_runs;

@@ -20,6 +20,7 @@ void set_error(const std::string& msg);
 //   gemm_workgroups  workgroups of the decode GEMM's N split (default 256 = one per CU; an engine
 //                    that keeps two steps in flight on two streams sets 128: each GEMM then
 //                    leaves half the CUs to the other stream's kernel, +10 % tokens/s measured)
+//   gemm_balance     see Tuning
 //   attn_waves       waves per workgroup of the long-context decode attention (8 or 4)
 //   attn_splits      how paged_attention_v2 cuts contexts: 0 automatic, n >= 1 forced, -1 the reference's
 //                    512-token partitions (scratch contents then equal the reference's)
@@ -31,6 +32,9 @@ struct Tuning {
   int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
   int gemm_wide_min_tiles = 1024;  // 1024: gate_up and lm_head of an 8B model; 4096: lm_head only
   int gemm_partials_ksplit = 0;  // > 0: a projection that leaves split-K partials splits K at least this many ways
+  int gemm_balance = 1;  // 1: the launch takes the FEWEST workgroups (<= gemm_workgroups) that need no more rounds of n-tiles
+                         // than gemm_workgroups would -- 384 tiles on 256 workgroups are two rounds with half the
+                         // workgroups idle in the second, on 192 two full ones (round 4, profiles/r04_tuning.md); 0: all
   int attn_waves = 8;
   int attn_splits = 0;  // paged_attention_v2: 0 = shares chosen per call; n >= 1 = n shares; -1 = 512-token partitions
   int swap_kernel_min_runs = 3;  // swap_blocks: more contiguous runs than this (and a pinned host side) -> one kernel

@@ -1038,6 +1038,17 @@ __global__ void pack_weight_kernel(uint4* __restrict__ dst, const uint4* __restr
 
 using namespace lvllm;
 
+// Workgroups for `units` n-tiles (or SwiGLU pairs) handed out round-robin when at most `cap` may run: with
+// tuning().gemm_balance the fewest that need no more rounds than `cap` would, so that no workgroup idles through the
+// last round while others still stream (qkv of an 8B model: 384 tiles, 256 -> 192 workgroups, two full rounds).
+static inline int balanced_groups(int units, int cap) {
+  if (cap < 1) cap = 1;
+  if (units <= cap) return units < 1 ? 1 : units;
+  if (!tuning().gemm_balance) return cap;
+  const int rounds = (units + cap - 1) / cap;
+  return (units + rounds - 1) / rounds;
+}
+
 // Bytes of fp32 workspace lvllm_skinny_gemm needs for this shape (0 when K is not split over
 // workgroups).
 // k-steps one wave may own: its X fragments (MT * steps * 4 VGPRs) must stay in registers
@@ -1129,13 +1140,12 @@ extern "C" int lvllm_skinny_gemm_ex(void* y, const void* x, const void* w, const
                                                                             : tuning().gemm_workgroups;
   int groups = gemm_cus / ksplit;
   if (groups < 1) groups = 1;
-  if (groups > ntiles) groups = ntiles;
   const bool glu_reduce = act == 2 && ksplit > 1;  // K split over workgroups: SwiGLU inside the reduce pass
   if (act == 2) {  // SwiGLU: y is [M, N / 2]
     LV_CHECK(N % 32 == 0 && !partial_out, "the SwiGLU epilogue needs N % 32 == 0 and writes y itself");
     if (glu_reduce) act = 0;  // plain tiles into the fp32 partials
-    else if (groups > ntiles / 2) groups = ntiles / 2;
   }
+  groups = balanced_groups(act == 2 ? ntiles / 2 : ntiles, groups);  // (SwiGLU: (gate, up) pairs are handed out)
   void* const tokens_out = y;
   const bool amax_reduce = act == 3 && ksplit > 1;  // K split over workgroups: arg-max inside a reduce pass
   float* amax_cand = nullptr;
@@ -1286,11 +1296,8 @@ extern "C" int lvllm_skinny_gemm_w8a8_ex(void* y, const void* x, const void* w_p
   int groups = ((ntiles >= tuning().gemm_wide_min_tiles && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
                                                                       : tuning().gemm_workgroups) / ksplit;
   if (groups < 1) groups = 1;
-  if (groups > ntiles) groups = ntiles;
-  if (act == 2) {
-    LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
-    if (groups > ntiles / 2) groups = ntiles / 2;
-  }
+  if (act == 2) LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
+  groups = balanced_groups(act == 2 ? ntiles / 2 : ntiles, groups);
   void* const tokens_out = y;
   if (act == 3) {  // arg-max epilogue (see lvllm_skinny_gemm_argmax): y is int64 [M], candidates via `workspace`
     LV_CHECK(ksplit == 1 && bias == nullptr && M <= 32,
@@ -1384,11 +1391,8 @@ extern "C" int lvllm_skinny_gemm_w8a8_q(void* y, void* y_fp8, const float* y_fp8
   int groups = ((ntiles >= tuning().gemm_wide_min_tiles && tuning().gemm_workgroups_wide > 0) ? tuning().gemm_workgroups_wide
                                                                       : tuning().gemm_workgroups) / ksplit;
   if (groups < 1) groups = 1;
-  if (groups > ntiles) groups = ntiles;
-  if (act == 2) {
-    LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
-    if (groups > ntiles / 2) groups = ntiles / 2;
-  }
+  if (act == 2) LV_CHECK(N % 32 == 0 && ksplit == 1, "the SwiGLU epilogue needs N % 32 == 0 and K within one workgroup");
+  groups = balanced_groups(act == 2 ? ntiles / 2 : ntiles, groups);
   LV_CHECK(!leave_partials || (ksplit > 1 && bias == nullptr),
            "act = 4 needs K split over workgroups (lvllm_skinny_gemm_w8a8_workspace_bytes > 0) and no bias");
   float* partial = nullptr;
