@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--context", type=int, default=1024)
-    ap.add_argument("--scheduling", default="async", choices=["sync", "simple_async", "async"])
+    ap.add_argument("--scheduling", default="async", choices=["sync", "simple_async", "async", "double_buffer"],
+                    help="the reference's execute loops (core/executor.py:37-185): double_buffer = its third loop, whose "
+                         "default is three steps in flight (decoding/config.py:149-155) -- here the async pipeline at "
+                         "--on-the-fly 3 unless given; the headline (BASELINE config 2) is async")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
                     help="non-default runs only: fp8 = OCP e4m3fn KV cache (the headline is bf16)")
     ap.add_argument("--kv-block-pad-bytes", type=int, default=None,
@@ -781,6 +784,8 @@ def plan_steps(a):
     k = largest_divisor_at_most(a.steps, k_req)
     kw = largest_divisor_at_most(a.warmup, k_req) if a.warmup > 0 else 1
     on_the_fly = max(1, a.on_the_fly) if a.scheduling != "sync" else 1
+    if a.scheduling == "double_buffer" and "--on-the-fly" not in sys.argv:
+        on_the_fly = 3
     on_the_fly = max(1, min(on_the_fly, a.steps // k))
     return k, kw, on_the_fly
 
