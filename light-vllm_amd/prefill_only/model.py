@@ -29,6 +29,10 @@ class EncoderConfig:
     pad_token_id: int = 1
     dtype: torch.dtype = torch.bfloat16
     fused_layer_norm: bool = True  # residual add + LayerNorm in one launch (lvllm_add_layer_norm); off = A/B runs
+    # > 0: the MLP runs over row blocks of this many tokens (fc1 -> GELU -> fc2 per block), so that the block's
+    # intermediate [rows, intermediate] is still in the L2s / the Infinity Cache when GELU and fc2 read it instead of
+    # making two round trips through HBM (134 MB each way at 16 384 tokens); 0 = one pass over all tokens
+    mlp_block_tokens: int = 0
 
     @property
     def head_dim(self) -> int:
@@ -105,10 +109,22 @@ class EncoderModel:
             q, k, v = qkv.split([hid, hid, hid], dim=-1)  # strided views of the fused projection
             a = self.attn.forward(q, k, v, None, attn_metadata, attn_type=AttentionType.ENCODER)
             x = add_ln(x, F.linear(a, lw.out_w, lw.out_b), lw.attn_ln)
-            h = F.linear(x, lw.fc1_w, lw.fc1_b)
-            if fused and h.numel() % 8 == 0:
-                torch.ops._C_amd.gelu(h, h)  # exact GELU in place
+            blk = cfg.mlp_block_tokens
+            if blk > 0 and x.shape[0] > blk:
+                y = torch.empty_like(x)
+                for r0 in range(0, x.shape[0], blk):
+                    hb = F.linear(x[r0:r0 + blk], lw.fc1_w, lw.fc1_b)
+                    if fused and hb.numel() % 8 == 0:
+                        torch.ops._C_amd.gelu(hb, hb)
+                    else:
+                        hb = F.gelu(hb)
+                    torch.addmm(lw.fc2_b, hb, lw.fc2_w.t(), out=y[r0:r0 + blk])
             else:
-                h = F.gelu(h)
-            x = add_ln(x, F.linear(h, lw.fc2_w, lw.fc2_b), lw.out_ln)
+                h = F.linear(x, lw.fc1_w, lw.fc1_b)
+                if fused and h.numel() % 8 == 0:
+                    torch.ops._C_amd.gelu(h, h)  # exact GELU in place
+                else:
+                    h = F.gelu(h)
+                y = F.linear(h, lw.fc2_w, lw.fc2_b)
+            x = add_ln(x, y, lw.out_ln)
         return x

@@ -21,11 +21,13 @@ def main():
     ap.add_argument("--len", type=int, default=512)
     ap.add_argument("--max-num-seqs", type=int, default=32)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--mlp-block", type=int, default=0, help="EncoderConfig.mlp_block_tokens (A/B)")
     ap.add_argument("--gpus", type=int, default=0, help="N > 0: N worker processes behind one scheduler (queue-sharing DP)")
     ap.add_argument("--single-device", action="store_true", help="with --gpus: every worker on cuda:0")
     ap.add_argument("--ragged", action="store_true", help="prompt lengths uniform in [len/8, len] instead of all equal")
     a = ap.parse_args()
     cfg = EncoderConfig.tiny() if a.tiny else EncoderConfig.bge_m3()
+    cfg.mlp_block_tokens = a.mlp_block
     g = torch.Generator().manual_seed(0)
     lens = [int(torch.randint(max(1, a.len // 8), a.len + 1, (1,), generator=g)) if a.ragged else a.len
             for _ in range(a.num_prompts)]
