@@ -798,7 +798,12 @@ def main():
     # N > 1: before this process touches its GPU it pins itself to its GPU's NUMA cores, cut among the ranks that share
     # the node (a call, not a re-exec): eight Python schedulers on one host are the scaling risk SURVEY 8e names
     from light_vllm_amd.engine.replicas import pin_to_gpu_numa
-    pin = pin_to_gpu_numa() if (a.gpus > 1 and not a.no_pin) else {"pinned": False, "reason": "one replica"}
+    pin = {"pinned": False, "reason": "one replica"}
+    if a.gpus > 1 and not a.no_pin:
+        try:
+            pin = pin_to_gpu_numa()
+        except Exception as e:  # placement is an optimisation: a host that does not say where its GPUs hang runs unpinned
+            pin = {"pinned": False, "reason": f"{type(e).__name__}: {e}"}
     dev = "cuda:0" if a.single_device else f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
 

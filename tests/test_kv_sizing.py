@@ -66,10 +66,16 @@ def test_profile_run_sizes_the_cache_on_the_gpu():
     assert prof["init_free"] - prof["free_after_load"] > 0  # the weights
     assert n_cpu == (1 << 20) // prof["block_bytes"]
     sc_async = SchedulerConfig(max_num_batched_tokens=2048, max_num_seqs=16, max_model_len=2048, scheduling="async")
+    # (eager worker: no graph reserve; the device sampler's state and working rows are reserved -- it is created with
+    # the first request that is not plain greedy, after the cache has been sized: ADVICE r03)
+    reserve = w.sampler_reserve_bytes(sc)
+    assert reserve >= w.sampler_state_slots(sc) * mc.vocab_size * 4
     exp_sync = Worker.kv_blocks_from_profile(prof["total"], prof["init_free"], prof["free_after_load"],
-                                             prof["free_after_profile"], 0.05, "sync", prof["block_bytes"], 1 << 20)
+                                             prof["free_after_profile"], 0.05, "sync", prof["block_bytes"], 1 << 20,
+                                             reserve)
     exp_async = Worker.kv_blocks_from_profile(prof["total"], prof["init_free"], prof["free_after_load"],
-                                              prof["free_after_profile"], 0.05, "async", prof["block_bytes"], 1 << 20)
+                                              prof["free_after_profile"], 0.05, "async", prof["block_bytes"], 1 << 20,
+                                              reserve)
     assert n_sync == exp_sync[0]
     assert exp_sync[0] - exp_async[0] in (runtime // prof["block_bytes"], runtime // prof["block_bytes"] + 1)
     del w
