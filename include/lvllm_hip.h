@@ -332,6 +332,18 @@ int lvllm_rotary_embedding_and_cache_strided(
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream);
 
+/* The reduce pass of a QKV projection whose K was split over workgroups (lvllm_skinny_gemm_ex with partial_out: fp32
+ * slabs partials[num_partials][num_tokens][(num_heads + 2 num_kv_heads) * head_size], columns [q | k | v]) +
+ * rotary_embedding + reshape_and_cache in ONE launch: qkv [num_tokens, (num_heads + 2 num_kv_heads) * head_size]
+ * (contiguous, 16-bit) receives T(sum of the slabs + bias) with q and k rotated, the caches the rotated key and the value
+ * -- bit for bit what lvllm_skinny_gemm's own reduce pass followed by lvllm_rotary_embedding_and_cache_strided leaves
+ * (steps of 33..64 rows: one launch less per layer).  bias: [row] of T or NULL.  3 = outside the envelope. */
+int lvllm_rotary_embedding_and_cache_splitk(
+    const int64_t* positions, void* qkv, const float* partials, int num_partials, const void* bias, int num_tokens,
+    int num_heads, int num_kv_heads, int head_size, int rot_dim, const void* cos_sin_cache, int is_neox,
+    void* key_cache, void* value_cache, const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype,
+    float k_scale, float v_scale, int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream);
+
 /* Causal varlen attention of prompt chunks over the paged cache: prefill, chunked prefill and
  * prefix-cache hits.  Replaces the reference's third-party call
  *   flash_attn_varlen_func(q, key_cache, value_cache, cu_seqlens_q=query_start_loc,

@@ -101,7 +101,20 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
 // csrc/cache_kernels.cu:184-192).  rot_dim == head_size, 16-bit types, 16-byte aligned rows.
 // KV8: the caches hold fp8 (e4m3fn) with x = 16; the rotated key (already rounded to T, as the two
 // separate launches would see it) and the value are quantised with fp8_kv_quant4 on the way in.
-template <typename T, bool IS_NEOX, bool KV8>
+// SPLITK (the QKV projection of a step of 33..64 rows splits K over workgroups and leaves fp32 slabs, skinny_gemm.hip):
+// q, k and v are not read from `query` / `key` / `value` but summed from the slabs -- partials[s][token][column], the
+// projection's columns being [q | k | v] -- with the arithmetic of skinny_gemm_reduce_kernel (slab 0, then += slab 1 ...,
+// + bias, rounded to T), and the three buffers receive what the reduce launch followed by this kernel's plain form
+// would leave (rotated q and k, v as summed): one launch less per layer of a mixed step, bit for bit the same bytes.
+struct RopeSplitK {
+  const float* partials;   // [num_partials][num_tokens][row]  fp32
+  int num_partials;
+  int64_t partial_stride;  // floats between slabs
+  int64_t row;             // floats per token row of a slab = (num_heads + 2 num_kv_heads) * head_size
+  const void* bias;        // [row] of T or null
+};
+
+template <typename T, bool IS_NEOX, bool KV8, bool SPLITK = false>
 __global__ void rotary_embedding_and_cache_kernel(
     const int64_t* __restrict__ positions, typename T::store_t* __restrict__ query,
     typename T::store_t* __restrict__ key, const typename T::store_t* __restrict__ value,
@@ -109,11 +122,38 @@ __global__ void rotary_embedding_and_cache_kernel(
     void* __restrict__ value_cache_v, const int64_t* __restrict__ slot_mapping,
     const int64_t query_stride, const int64_t key_stride, const int64_t value_stride, const int num_heads,
     const int num_kv_heads, const int head_size, const int block_size, const float k_scale, const float v_scale,
-    const int64_t num_slots, const int64_t block_stride) {  // block_stride: cache elements between blocks
+    const int64_t num_slots, const int64_t block_stride,  // block_stride: cache elements between blocks
+    const RopeSplitK sk = RopeSplitK{}) {
   LVLLM_TRACE_BEGIN();
   using S = typename T::store_t;
   using V = Vec16<T>;
   constexpr int N = V::N;  // 8
+  // 8 values of this token starting at column `col` of the projection: from memory, or summed from the slabs
+  auto load8 = [&](const S* src, const int64_t col) -> V {
+    if constexpr (!SPLITK) {
+      (void)col;
+      return *reinterpret_cast<const V*>(src);
+    } else {
+      (void)src;
+      const float* p = sk.partials + (int64_t)blockIdx.x * sk.row + col;
+      float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+      for (int sp = 1; sp < sk.num_partials; ++sp) {
+        const float4* q4 = reinterpret_cast<const float4*>(p + sp * sk.partial_stride);
+        const float4 c = q4[0], d = q4[1];
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+      }
+      float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      V out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (sk.bias != nullptr) f[e] += T::to_float(reinterpret_cast<const S*>(sk.bias)[col + e]);
+        out.v[e] = T::from_float(f[e]);
+      }
+      return out;
+    }
+  };
+  const int64_t k_col0 = (int64_t)num_heads * head_size, v_col0 = k_col0 + (int64_t)num_kv_heads * head_size;
   S* key_cache = reinterpret_cast<S*>(key_cache_v);
   S* value_cache = reinterpret_cast<S*>(value_cache_v);
   uint8_t* key_cache8 = reinterpret_cast<uint8_t*>(key_cache_v);
@@ -148,9 +188,10 @@ __global__ void rotary_embedding_and_cache_kernel(
       S* base = is_k ? key + token * key_stride + (int64_t)head * head_size
                      : query + token * query_stride + (int64_t)head * head_size;
       S* kc = key_cache + block_idx * block_stride + ((int64_t)head * cph) * (int64_t)block_size * N + block_off * N;
+      const int64_t col = (is_k ? k_col0 : 0) + (int64_t)head * head_size;  // first column of this head
       if constexpr (IS_NEOX) {
-        V x = *reinterpret_cast<const V*>(base + u * N);
-        V y = *reinterpret_cast<const V*>(base + embed_dim + u * N);
+        V x = load8(base + u * N, col + u * N);
+        V y = load8(base + embed_dim + u * N, col + embed_dim + u * N);
         const V c = *reinterpret_cast<const V*>(cos_ptr + u * N);
         const V sn = *reinterpret_cast<const V*>(sin_ptr + u * N);
 #pragma unroll
@@ -167,7 +208,7 @@ __global__ void rotary_embedding_and_cache_kernel(
           }
         }
       } else {
-        V xy = *reinterpret_cast<const V*>(base + u * N);
+        V xy = load8(base + u * N, col + u * N);
 #pragma unroll
         for (int e = 0; e < N / 2; ++e) {
           const int r = u * (N / 2) + e;
@@ -179,10 +220,15 @@ __global__ void rotary_embedding_and_cache_kernel(
           else *reinterpret_cast<V*>(kc + (int64_t)u * block_size * N) = xy;
         }
       }
-    } else if (slot >= 0) {
+    } else if (slot >= 0 || SPLITK) {
       const int j = i - nq - nk;
       const int head = j / cph, ch = j - head * cph;
-      const V v = *reinterpret_cast<const V*>(value + token * value_stride + (int64_t)head * head_size + ch * N);
+      const S* vsrc = value + token * value_stride + (int64_t)head * head_size + ch * N;
+      const V v = load8(vsrc, v_col0 + (int64_t)head * head_size + ch * N);
+      if constexpr (SPLITK) {
+        *reinterpret_cast<V*>(const_cast<S*>(vsrc)) = v;  // the row the reduce launch would have written
+        if (slot < 0) continue;
+      }
       if constexpr (KV8) {
         uint8_t* vdst = value_cache8 + block_idx * block_stride +
                         ((int64_t)head * head_size + ch * N) * (int64_t)block_size + block_off;
@@ -281,12 +327,56 @@ extern "C" int lvllm_rotary_embedding_and_cache_ex(
                                                   (int64_t)num_kv_heads * head_size * block_size, stream);
 }
 
+extern "C" int lvllm_rotary_embedding_and_cache_splitk(
+    const int64_t* positions, void* qkv, const float* partials, int num_partials, const void* bias, int num_tokens,
+    int num_heads, int num_kv_heads, int head_size, int rot_dim, const void* cos_sin_cache, int is_neox,
+    void* key_cache, void* value_cache, const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype,
+    float k_scale, float v_scale, int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream);
+
+static int rope_cache_launch(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream, const RopeSplitK* sk);
+
 extern "C" int lvllm_rotary_embedding_and_cache_strided(
     const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
     int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
     int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
     const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
     int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream) {
+  return rope_cache_launch(positions, query, key, value, num_tokens, num_heads, num_kv_heads, head_size, rot_dim,
+                           query_stride, key_stride, value_stride, cos_sin_cache, is_neox, key_cache, value_cache,
+                           slot_mapping, block_size, dtype, kv_dtype, k_scale, v_scale, kv_cache_bytes, kv_block_stride,
+                           stream, nullptr);
+}
+
+// The QKV projection's reduce pass + rotary_embedding + reshape_and_cache in ONE launch (include/lvllm_hip.h).
+extern "C" int lvllm_rotary_embedding_and_cache_splitk(
+    const int64_t* positions, void* qkv, const float* partials, int num_partials, const void* bias, int num_tokens,
+    int num_heads, int num_kv_heads, int head_size, int rot_dim, const void* cos_sin_cache, int is_neox,
+    void* key_cache, void* value_cache, const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype,
+    float k_scale, float v_scale, int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream) {
+  LV_CHECK(partials != nullptr && num_partials >= 1 && num_partials <= 16, "partials: 1..16 fp32 slabs");
+  LV_CHECK((((uintptr_t)partials) & 15) == 0, "partials must be 16-byte aligned");
+  const int64_t row = (int64_t)(num_heads + 2 * num_kv_heads) * head_size;
+  const int esz = 2;
+  char* base = (char*)qkv;
+  RopeSplitK sk{partials, num_partials, (int64_t)num_tokens * row, row, bias};
+  return rope_cache_launch(positions, base, base + (int64_t)num_heads * head_size * esz,
+                           base + (int64_t)(num_heads + num_kv_heads) * head_size * esz, num_tokens, num_heads,
+                           num_kv_heads, head_size, rot_dim, row, row, row, cos_sin_cache, is_neox, key_cache, value_cache,
+                           slot_mapping, block_size, dtype, kv_dtype, k_scale, v_scale, kv_cache_bytes, kv_block_stride,
+                           stream, &sk);
+}
+
+static int rope_cache_launch(
+    const int64_t* positions, void* query, void* key, const void* value, int num_tokens, int num_heads,
+    int num_kv_heads, int head_size, int rot_dim, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, const void* cos_sin_cache, int is_neox, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping, int block_size, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int64_t kv_cache_bytes, int64_t kv_block_stride, void* stream, const RopeSplitK* sk) {
   if (num_tokens == 0) return 0;
   LV_CHECK(kv_block_stride >= (int64_t)num_kv_heads * head_size * block_size &&
                (kv_block_stride * (kv_dtype == LVLLM_KV_FP8_E4M3 ? 1 : 2)) % 16 == 0,
@@ -308,12 +398,16 @@ extern "C" int lvllm_rotary_embedding_and_cache_strided(
   const int units = (num_heads + num_kv_heads) * (is_neox ? head_size / 16 : head_size / 8) + num_kv_heads * head_size / 8;
   int threads = ((units + 63) / 64) * 64;
   threads = threads > 512 ? 512 : threads;
-#define LV_RC(T_, NEOX_, KV8_)                                                                              \
-  hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_, KV8_>), dim3(num_tokens), dim3(threads), 0, \
+#define LV_RC1(T_, NEOX_, KV8_, SK_)                                                                         \
+  hipLaunchKernelGGL((rotary_embedding_and_cache_kernel<T_, NEOX_, KV8_, SK_>), dim3(num_tokens), dim3(threads), 0, \
                      (hipStream_t)stream, positions, (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value, \
                      (const uint16_t*)cos_sin_cache, key_cache, value_cache, slot_mapping, query_stride,      \
                      key_stride, value_stride, num_heads, num_kv_heads, head_size, block_size, k_scale, v_scale, \
-                     num_slots, kv_block_stride)
+                     num_slots, kv_block_stride, sk != nullptr ? *sk : RopeSplitK{})
+#define LV_RC(T_, NEOX_, KV8_)                                   \
+  do {                                                           \
+    if (sk != nullptr) LV_RC1(T_, NEOX_, KV8_, true); else LV_RC1(T_, NEOX_, KV8_, false); \
+  } while (0)
 #define LV_RC_N(T_)                                   \
   do {                                                \
     if (is_neox) {                                    \
@@ -325,6 +419,7 @@ extern "C" int lvllm_rotary_embedding_and_cache_strided(
   if (dtype == LVLLM_BF16) LV_RC_N(BF16); else LV_RC_N(F16);
 #undef LV_RC_N
 #undef LV_RC
+#undef LV_RC1
   LV_LAUNCH_CHECK();
   return 0;
 }

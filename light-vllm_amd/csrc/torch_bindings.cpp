@@ -522,6 +522,42 @@ bool rotary_embedding_and_cache(torch::Tensor& positions, torch::Tensor& query, 
   return true;
 }
 
+// the QKV projection's split-K reduce + rope + cache write in one launch (include/lvllm_hip.h); false = outside the
+// fused kernel's envelope (nothing was done)
+bool rotary_embedding_and_cache_splitk(torch::Tensor& positions, torch::Tensor& qkv, const torch::Tensor& partials,
+                                       const std::optional<torch::Tensor>& bias, int64_t num_heads, int64_t num_kv_heads,
+                                       int64_t head_size, torch::Tensor& cos_sin_cache, bool is_neox,
+                                       torch::Tensor& key_cache, torch::Tensor& value_cache,
+                                       const torch::Tensor& slot_mapping, const std::string& kv_cache_dtype,
+                                       double k_scale, double v_scale) {
+  LV_CHECK_DEVICE(qkv);
+  TORCH_CHECK(positions.scalar_type() == at::kLong && slot_mapping.scalar_type() == at::kLong);
+  const int64_t row = (num_heads + 2 * num_kv_heads) * head_size;
+  TORCH_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == row, "qkv: contiguous [tokens, (H + 2 KVH) * D]");
+  TORCH_CHECK(partials.scalar_type() == at::kFloat && partials.is_contiguous() && partials.dim() == 3 &&
+                  partials.size(1) == qkv.size(0) && partials.size(2) == row && partials.device() == qkv.device(),
+              "partials: contiguous fp32 [slabs, tokens, (H + 2 KVH) * D] on qkv's device");
+  TORCH_CHECK(!bias.has_value() || (bias->numel() == row && bias->scalar_type() == qkv.scalar_type() && bias->is_contiguous()),
+              "bias: [(H + 2 KVH) * D] of qkv's type");
+  const int kv_code = kv_dtype_code(kv_cache_dtype);
+  check_cache_dtype(key_cache, qkv, kv_code, "rotary_embedding_and_cache_splitk");
+  check_cache_dtype(value_cache, qkv, kv_code, "rotary_embedding_and_cache_splitk");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_of(qkv));
+  TORCH_CHECK(blocks_are_dense(key_cache) && blocks_are_dense(value_cache) &&
+                  key_cache.stride(0) == value_cache.stride(0),
+              "key_cache / value_cache: dense blocks, the same block stride");
+  const int rc = lvllm_rotary_embedding_and_cache_splitk(
+      positions.data_ptr<int64_t>(), qkv.data_ptr(), partials.data_ptr<float>(), (int)partials.size(0),
+      bias.has_value() ? bias->data_ptr() : nullptr, (int)qkv.size(0), (int)num_heads, (int)num_kv_heads, (int)head_size,
+      (int)cos_sin_cache.size(1), cos_sin_cache.data_ptr(), is_neox ? 1 : 0, key_cache.data_ptr(), value_cache.data_ptr(),
+      slot_mapping.data_ptr<int64_t>(), (int)value_cache.size(3), dtype_code(qkv, "rotary_embedding_and_cache_splitk"),
+      kv_code, (float)k_scale, (float)v_scale, cache_extent_bytes(key_cache, value_cache), key_cache.stride(0),
+      current_stream(qkv));
+  if (rc == 3) return false;
+  check(rc);
+  return true;
+}
+
 // returns false when the arguments are outside the fused kernel's envelope (nothing was done)
 bool rope_cache_paged_attention(torch::Tensor& out, torch::Tensor& exp_sums, torch::Tensor& max_logits,
                                 torch::Tensor& tmp_out, const torch::Tensor& positions, const torch::Tensor& query,
@@ -1202,6 +1238,11 @@ TORCH_LIBRARY(_C_amd, amd) {
           "int head_size, Tensor cos_sin_cache, bool is_neox, Tensor! key_cache, Tensor! value_cache, "
           "Tensor slot_mapping, str kv_cache_dtype=\"auto\", float k_scale=1.0, float v_scale=1.0) -> bool");
   amd.impl("rotary_embedding_and_cache", torch::kCUDA, &rotary_embedding_and_cache);
+  amd.def("rotary_embedding_and_cache_splitk(Tensor positions, Tensor! qkv, Tensor partials, Tensor? bias, "
+          "int num_heads, int num_kv_heads, int head_size, Tensor cos_sin_cache, bool is_neox, Tensor! key_cache, "
+          "Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype=\"auto\", float k_scale=1.0, "
+          "float v_scale=1.0) -> bool");
+  amd.impl("rotary_embedding_and_cache_splitk", torch::kCUDA, &rotary_embedding_and_cache_splitk);
   amd.def("paged_prefill_attention(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, "
           "int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, Tensor query_start_loc, "
           "int max_query_len, int block_size, Tensor? alibi_slopes, int sliding_window, float softcap, "

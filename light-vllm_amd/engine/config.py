@@ -28,6 +28,9 @@ class ModelConfig:
     rope_in_attention_fp8: bool = True   # the same over an fp8 KV cache (bit-identical too; +2 % on config 5 once the
                                          # new token's cache stores left the prologue, profiles/r03_tuning.md section 10)
     swiglu_epilogue: bool = True    # silu_and_mul in the gate_up projection's epilogue
+    qkv_reduce_in_rope: bool = True  # mixed steps of 33..64 rows: the QKV projection's split-K slabs are summed by the
+                                     # rope + cache-write launch (lvllm_rotary_embedding_and_cache_splitk): 9 launches
+                                     # per layer instead of 10, bit-identical
     argmax_epilogue: bool = True    # greedy arg-max in the lm_head projection's epilogue
     stream_gemm_max_rows: int = 256  # 65..this many rows: projections through lvllm_stream_gemm where it wins
     # decode steps of at least this many rows split o_proj's K over workgroups and leave the fp32 partials to the

@@ -223,6 +223,7 @@ class DecoderModel:
         residual = None
         unified_out = None
         for i, lw in enumerate(self.layers):
+            qkv_roped = False
             if q_once:
                 x8 = self._norm_fp8(hidden, residual, lw.input_norm, lw.qkv.x_scale)
                 if residual is None:
@@ -237,7 +238,24 @@ class DecoderModel:
                     hidden = normed
                 else:
                     hidden = self._add_norm(hidden, residual, lw.input_norm)
-                qkv = linear(hidden, lw.qkv, lw.qkv_bias)
+                qkv = None
+                if (unified is not None and cfg.qkv_reduce_in_rope and 32 < T <= 64 and lw.qkv.packed is not None
+                        and lw.qkv.w8_packed is None and not _CALIBRATING):
+                    # a mixed step of 33..64 rows: the projection splits K over workgroups; its fp32 slabs are summed
+                    # by the rope + cache-write launch instead of a reduce launch of their own (bit-identical)
+                    part = torch.ops._C_amd.skinny_linear_packed_partials(hidden, lw.qkv.packed, lw.qkv.N, lw.qkv.K, False)
+                    if part.shape[0] > 1:
+                        key_cache, value_cache = self.attn.split_kv_cache(kv_caches[i])
+                        qkv = torch.empty(T, lw.qkv.N, dtype=hidden.dtype, device=hidden.device)
+                        if not torch.ops._C_amd.rotary_embedding_and_cache_splitk(
+                                positions, qkv, part, lw.qkv_bias, cfg.num_attention_heads, cfg.num_key_value_heads,
+                                cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache, slot_mapping,
+                                self.attn.kv_cache_dtype, 1.0, 1.0):
+                            qkv = None
+                        else:
+                            qkv_roped = True
+                if qkv is None:
+                    qkv = linear(hidden, lw.qkv, lw.qkv_bias)
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)  # strided views
             fused = False
             attn_out = None
@@ -251,7 +269,9 @@ class DecoderModel:
                                                                  value_cache, attn_metadata, **({"fp8_twin_scale": twin} if twin is not None else {}))
                 if isinstance(attn_out, tuple):
                     attn_out, attn8 = attn_out
-            if decode_only and attn_out is None:
+            if qkv_roped:
+                fused = True  # (rotated and written to the caches by the launch that summed the projection's slabs)
+            elif decode_only and attn_out is None:
                 fused = torch.ops._C_amd.rotary_embedding_and_cache(
                     positions, q, k, v, cfg.head_dim, self.cos_sin_cache, True, key_cache, value_cache,
                     slot_mapping, self.attn.kv_cache_dtype, 1.0, 1.0)

@@ -426,6 +426,57 @@ def test_mixed_steps_replay_one_graph():
         assert int(ref[len(p) - 1].argmax()) == tg[i][0]
 
 
+def test_mixed_steps_sum_the_qkv_slabs_inside_the_rope_launch():
+    """Round 4: at 33..64 rows the QKV projection splits K over workgroups (K = 4 096: two fp32 slabs) and the rope +
+    cache-write launch sums them (`ModelConfig.qkv_reduce_in_rope`).  A two-layer model of the 8B widths under a 48-token
+    budget with captured mixed steps: the op is called, and every token equals the run with the reduce launch of its own
+    (the fused launch is bit-identical, so not one near-tie may flip)."""
+    import light_vllm_amd  # noqa: F401
+    from light_vllm_amd.engine.config import CacheConfig, ModelConfig, SchedulerConfig
+    from light_vllm_amd.engine.llm_engine import LLMEngine
+    import light_vllm_amd.engine.model as model_mod
+
+    def run(fold):
+        cfg = ModelConfig(num_hidden_layers=2, vocab_size=2048, max_position_embeddings=2048)
+        cfg.qkv_reduce_in_rope = fold
+        eng = LLMEngine(cfg, CacheConfig(block_size=16, num_gpu_blocks=128, num_cpu_blocks=0),
+                        SchedulerConfig(max_num_batched_tokens=48, max_num_seqs=8, max_model_len=512, scheduling="sync",
+                                        chunked_prefill_enabled=True), device=DEV, use_hip_graph=True, seed=0)
+        assert eng.worker.mixed_graph_tokens == 48
+        g = torch.Generator().manual_seed(3)
+        for i, n in enumerate((70, 37, 120, 5, 64, 90)):
+            eng.add_request(str(i), torch.randint(0, 2048, (n,), generator=g).tolist(), max_tokens=10)
+        final = {}
+        for _ in range(400):
+            for out in eng.step():
+                if out.finished:
+                    final[out.request_id] = out.token_ids
+            if not eng.has_unfinished_requests():
+                break
+        eng.shutdown()
+        return [final[str(i)] for i in range(6)]
+
+    calls = []
+    real = torch.ops._C_amd.rotary_embedding_and_cache_splitk
+
+    class Spy:
+        def __call__(self, *a, **k):
+            calls.append(a[2].shape[0])
+            return real(*a, **k)
+    import pytest as _pytest
+    mp = _pytest.MonkeyPatch()
+    mp.setattr(model_mod.torch.ops._C_amd, "rotary_embedding_and_cache_splitk", Spy(), raising=False)
+    try:
+        with_fold = run(True)
+        assert calls and min(calls) >= 2, "the fused launch never saw a split projection"
+        n_calls = len(calls)
+        without = run(False)
+        assert len(calls) == n_calls
+    finally:
+        mp.undo()
+    assert with_fold == without and all(len(t) == 10 for t in with_fold)
+
+
 def test_decode_batches_of_65_to_128_rows_take_the_stream_gemm(monkeypatch):
     """96 sequences per decode step: the projections go through lvllm_stream_gemm (X through LDS).  The run
     must finish every request and agree with the same run on the library GEMM wherever near-ties do not

@@ -322,3 +322,51 @@ def test_rope_cache_attention_in_one_launch_over_an_fp8_cache_is_bit_identical(o
     (o0, k0, v0), (o1, k1, v1) = results
     assert torch.equal(k0, k1) and torch.equal(v0, v1)
     assert torch.equal(o0, o1), (o0.float() - o1.float()).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,H,KVH,D,K,kv", [(64, 32, 8, 128, 4096, "auto"), (33, 8, 2, 128, 4096, "auto"),
+                                            (48, 4, 4, 64, 4096, "auto"), (57, 8, 2, 128, 4096, "fp8"),
+                                            (40, 6, 2, 256, 8192, "auto")])
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_qkv_splitk_reduce_inside_the_rope_and_cache_launch_is_bit_identical(ops, dtype, T, H, KVH, D, K, kv, use_bias):
+    """Mixed steps of 33..64 rows (round 4): the QKV projection splits K over workgroups and leaves fp32 slabs; the rope +
+    cache-write launch sums them (lvllm_rotary_embedding_and_cache_splitk) instead of a reduce launch of their own.  The
+    qkv rows (rotated q and k, v) and both caches are bit for bit what projection (with its own reduce pass) ->
+    rotary_embedding_and_cache leaves; padding slots (-1) write no cache line but still get their rows."""
+    g = torch.Generator(device=DEV).manual_seed(11 + T)
+    N = (H + 2 * KVH) * D
+    BS, NB = 16, 9
+    x = (torch.randn(T, K, generator=g, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.03).to(dtype)
+    bias = (torch.randn(N, generator=g, device=DEV) * 0.1).to(dtype) if use_bias else None
+    wp = torch.ops._C_amd.pack_weight(w)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(700).float(), inv)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(DEV)
+    pos = torch.randint(0, 700, (T,), generator=g, device=DEV)
+    slots = torch.randperm(NB * BS, generator=g, device=DEV)[:T].to(torch.int64)
+    slots[T // 2] = -1
+    if kv == "fp8":
+        kc0 = torch.randint(0, 255, (NB, KVH, D // 16, BS, 16), generator=g, device=DEV, dtype=torch.uint8)
+        vc0 = torch.randint(0, 255, (NB, KVH, D, BS), generator=g, device=DEV, dtype=torch.uint8)
+        ks, vs = 0.5, 1.7
+    else:
+        kc0 = torch.randn(NB, KVH, D // 8, BS, 8, generator=g, device=DEV).to(dtype)
+        vc0 = torch.randn(NB, KVH, D, BS, generator=g, device=DEV).to(dtype)
+        ks = vs = 1.0
+    # the two launches
+    qkv_a = torch.ops._C_amd.skinny_linear_packed(x, wp, bias, N, K)
+    kc_a, vc_a = kc0.clone(), vc0.clone()
+    qa, ka, va = qkv_a.split([H * D, KVH * D, KVH * D], dim=-1)
+    assert torch.ops._C_amd.rotary_embedding_and_cache(pos, qa, ka, va, D, cos_sin, True, kc_a, vc_a, slots, kv, ks, vs)
+    # the one
+    part = torch.ops._C_amd.skinny_linear_packed_partials(x, wp, N, K, False)
+    assert part.shape[0] >= 2 and part.dtype == torch.float32  # K is split at these row counts
+    qkv_b = torch.full((T, N), float("nan"), dtype=dtype, device=DEV)
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    assert torch.ops._C_amd.rotary_embedding_and_cache_splitk(pos, qkv_b, part, bias, H, KVH, D, cos_sin, True, kc_b, vc_b,
+                                                              slots, kv, ks, vs)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv_a.view(torch.int16), qkv_b.view(torch.int16))
+    assert torch.equal(kc_a.view(torch.uint8), kc_b.view(torch.uint8)) and torch.equal(vc_a.view(torch.uint8), vc_b.view(torch.uint8))
