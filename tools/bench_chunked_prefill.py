@@ -25,9 +25,12 @@ def main():
     ap.add_argument("--budget", type=int, default=64)
     ap.add_argument("--scheduling", default="async", choices=["sync", "async"])
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--no-qkv-reduce-in-rope", action="store_true",
+                    help="A/B: the QKV projection of a mixed step keeps its own reduce launch (round 3's path)")
     a = ap.parse_args()
     dev = "cuda:0"
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
+    cfg.qkv_reduce_in_rope = not a.no_qkv_reduce_in_rope
     max_len = a.input_len + a.output_len + 16
     bs = 16
     blocks = (a.budget + 8) * ((max_len + bs - 1) // bs + 1) + 64
