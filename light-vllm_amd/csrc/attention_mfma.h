@@ -167,6 +167,15 @@ constexpr int kSrdFlags = 0x00020000;
 #ifndef LVLLM_ATTN_ROPE_DIAG
 #define LVLLM_ATTN_ROPE_DIAG 0
 #endif
+// 1: the ROPE instantiation runs one wave MORE than it has tile walkers, and that wave does nothing but the step's new
+// token: rotate the key row, quantise, leave key and value in the LDS stash (before the prologue's barrier), then write
+// both rows into the caches and exit.  It issues no tile load, so nothing queues behind its scattered cache stores
+// (vmcnt retires in issue order: a walker's loads would), and the stores are acknowledged while the others walk the
+// context instead of holding the workgroup's end (round 4, profiles/r04_tuning.md section 9).  0: a tile walker does it
+// after its walk (round 3).
+#ifndef LVLLM_ATTN_ROPE_KV_WAVE
+#define LVLLM_ATTN_ROPE_KV_WAVE 1
+#endif
 // 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale).
 // scale == 1 (`scaled` false, the common case): gfx950 converts two fp8 straight to two bf16 / f16 in ONE instruction
 // (v_cvt_scalef32_pk_{bf16,f16}_fp8 with a scale of 1.0) -- exact, every e4m3 value is a bf16 and an f16 value -- half
@@ -201,8 +210,14 @@ __device__ __forceinline__ u32x2_t dequant4(uint32_t w, float scale, bool scaled
 // + v_cvt_pk_{bf16,f16}_f32: ~100 vector instructions per tile against ~7 us of HBM time per tile
 // and wave at full bandwidth -- free.
 // ROPE: see AttnParams (rotation of q and the new k, cache write of the new k and v, inside this launch).
+// (head sizes up to 128: NWAVES + 1 waves put three on one SIMD, so the register bound becomes 3 per SIMD = 168
+// registers, which the larger head sizes' accumulators do not fit without spilling)
+template <bool ROPE, int D>
+constexpr int attn_extra_waves() { return ROPE && D <= 128 && LVLLM_ATTN_ROPE_KV_WAVE != 0 ? 1 : 0; }
 template <typename T, int D, int BS, int NWAVES, int NBUF, bool KV8, bool ROPE = false, bool SCALED = false>
-__global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void paged_attn_mfma_kernel(
+__global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
+                             ((attn_extra_waves<ROPE, D>()) && LVLLM_ATTN_MIN_WAVES_PER_SIMD < 3
+                                  ? 3 : LVLLM_ATTN_MIN_WAVES_PER_SIMD)) void paged_attn_mfma_kernel(
     const AttnParams p) {
   using S = typename T::store_t;
   LVLLM_TRACE_BEGIN();
@@ -244,8 +259,10 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
   if (p.partitioned && !split_range(seq_len, p.num_splits, part, &t0, &t1, p.split_tiles)) return;
   const int ntiles = (t1 - t0 + 15) >> 4;
   const int tile0 = t0 >> 4;
-  // tiles of this wave: lt = wave + j * NWAVES, j = 0 .. nmy-1
-  const int nmy = ntiles > wave ? (ntiles - wave + NWAVES - 1) / NWAVES : 0;
+  // tiles of this wave: lt = wave + j * NWAVES, j = 0 .. nmy-1 (the new-token wave of the ROPE instantiation walks none)
+  constexpr int kXW = attn_extra_waves<ROPE, D>();
+  const bool kv_only = kXW != 0 && wave == NWAVES;
+  const int nmy = (ntiles > wave && !kv_only) ? (ntiles - wave + NWAVES - 1) / NWAVES : 0;
 
   const int32_t* block_table = p.block_tables + (int64_t)seq * p.max_num_blocks_per_seq;
   const char* kbytes = (const char*)p.k_cache + (int64_t)kvh * p.kv_head_stride * KVB;
@@ -348,12 +365,14 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
       bnr[s] = block_number(s + NBUF);
     }
   };
-  if constexpr (ROPE) first_loads();  // (without the prologue the Q loads go first, as before: 25.0 against 25.4 us)
+  if constexpr (ROPE) {
+    if (!kv_only) first_loads();  // (without the prologue the Q loads go first, as before: 25.0 against 25.4 us)
+  }
 
   // ---- Q fragments (B operand of the QK product): Q[head c][d = 32j + 8g ..] ----
   constexpr bool kSharedQ = LVLLM_ATTN_ROPE_SHARED_Q != 0 && NSQ / 2 <= NWAVES && NSQ >= 2;
   // (ROPE: the new K / V row is the job of a wave that rotates no Q, when there is one)
-  constexpr int kKvWave = kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0;
+  constexpr int kKvWave = kXW ? NWAVES : (kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0);
   constexpr bool kLateStores = ROPE && LVLLM_ATTN_ROPE_LATE_STORES != 0;
   u32x4_t qf[NSQ];
   {
@@ -683,6 +702,9 @@ __global__ __launch_bounds__(NWAVES * 64, LVLLM_ATTN_MIN_WAVES_PER_SIMD) void pa
     }
   }
 
+  if constexpr (kXW != 0) {
+    if (kv_only) return;  // its stores are on their way; the merge below belongs to the NWAVES walkers
+  }
   // ---- merge the waves of the workgroup -------------------------------------
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
@@ -754,8 +776,9 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   auto launch = [&](auto kern) {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(NWAVES * 64), smem,
-                       stream, p);
+    // (the ROPE instantiation brings its new-token wave: attn_extra_waves)
+    const int threads = (NWAVES + (p.positions != nullptr ? attn_extra_waves<true, D>() : 0)) * 64;
+    hipLaunchKernelGGL(kern, dim3(p.num_kv_heads * HG, num_seqs, num_parts), dim3(threads), smem, stream, p);
   };
   if constexpr (D % 128 == 0 && BS != 8) {
     if (p.positions != nullptr && p.kv_fp8) {  // fused rotation + quantised cache write (host checked the envelope)
