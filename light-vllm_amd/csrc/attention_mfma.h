@@ -171,10 +171,12 @@ constexpr int kSrdFlags = 0x00020000;
 // token: rotate the key row, quantise, leave key and value in the LDS stash (before the prologue's barrier), then write
 // both rows into the caches and exit.  It issues no tile load, so nothing queues behind its scattered cache stores
 // (vmcnt retires in issue order: a walker's loads would), and the stores are acknowledged while the others walk the
-// context instead of holding the workgroup's end (round 4, profiles/r04_tuning.md section 9).  0: a tile walker does it
-// after its walk (round 3).
+// context instead of holding the workgroup's end.  Measured (round 4, profiles/r04_tuning.md section 9): nothing at
+// bs 32 x 1 024 (24.2-24.3 against 24.2 us; fp8 17.1-17.2 against 16.8-17.0) and -9 % at bs 64 x 2 048 over an fp8 cache
+// (nine waves put five on a SIMD when two workgroups share a CU: only one fits) -- so 0 (a tile walker writes the rows
+// after its walk, round 3) stays the default; the switch remains for the record.
 #ifndef LVLLM_ATTN_ROPE_KV_WAVE
-#define LVLLM_ATTN_ROPE_KV_WAVE 1
+#define LVLLM_ATTN_ROPE_KV_WAVE 0
 #endif
 // 4 fp8 (e4m3fn) of one dword -> 4 T in two dwords, each T(float(fp8) * scale).
 // scale == 1 (`scaled` false, the common case): gfx950 converts two fp8 straight to two bf16 / f16 in ONE instruction
