@@ -445,7 +445,46 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
           rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
       }
       owns_new_token = !p.partitioned || t1 == seq_len;
-      if (owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 4)) {
+      if (kLateStores && owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 4)) {
+        // The new token's rows, ONE rotation pair (and two value elements) per lane: the whole workgroup waits at the
+        // barrier below for this wave.  With a 16-byte chunk pair per lane it ran 16 rotations and -- over an fp8 cache --
+        // 24 quantisations with their divisions in 8 .. 16 lanes, ~800 vector instructions that the diagnosis builds priced
+        // at 1.2 us of the fused fp8 launch (round 4, profiles/r04_tuning.md section 10); per element the arithmetic is
+        // the same (rotate<T> of pos_encoding.hip; fp8_kv_quant4 on one value), so the stash holds the same bytes.
+        // (the cache rows themselves are written after the key walk, from the stash)
+        const float ksc = SCALED ? p.k_scale : 1.0f, vsc = SCALED ? p.v_scale : 1.0f;  // (scale 1: the division folds away)
+        const S* krow = (const S*)p.k_new + (int64_t)seq * p.k_new_stride + (int64_t)kvh * D;
+        const S* vrow = (const S*)p.v_new + (int64_t)seq * p.v_new_stride + (int64_t)kvh * D;
+#pragma unroll
+        for (int i = lane; i < D / 2; i += 64) {
+          S x = krow[i], y = krow[D / 2 + i];
+          if constexpr (!(LVLLM_ATTN_ROPE_DIAG & 9)) {
+            const float xf = T::to_float(x), yf = T::to_float(y);
+            const float cf = T::to_float(cosp[i]), sf = T::to_float(sinp[i]);
+            const float xc = T::to_float(T::from_float(xf * cf));
+            const float ys = T::to_float(T::from_float(yf * sf));
+            const float yc = T::to_float(T::from_float(yf * cf));
+            const float xs = T::to_float(T::from_float(xf * sf));
+            x = T::from_float(__fsub_rn(xc, ys));
+            y = T::from_float(__fadd_rn(yc, xs));
+          }
+          if constexpr (KV8) {
+            uint8_t* sk = reinterpret_cast<uint8_t*>(sm_knew);
+            sk[i] = (uint8_t)fp8_kv_quant4(T::to_float(x), 0.f, 0.f, 0.f, ksc);
+            sk[D / 2 + i] = (uint8_t)fp8_kv_quant4(T::to_float(y), 0.f, 0.f, 0.f, ksc);
+          } else {
+            sm_knew[i] = x;
+            sm_knew[D / 2 + i] = y;
+          }
+        }
+#pragma unroll
+        for (int i = lane; i < D; i += 64) {
+          const S v = vrow[i];
+          if constexpr (KV8) reinterpret_cast<uint8_t*>(sm_vnew)[i] = (uint8_t)fp8_kv_quant4(T::to_float(v), 0.f, 0.f, 0.f, vsc);
+          else sm_vnew[i] = v;
+        }
+      }
+      if (!kLateStores && owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 4)) {
         // lanes 0 .. D/16-1: one (x, y) chunk pair of the key row each; lanes 0 .. D/8-1: one chunk of the value row
         int64_t slot = p.slot_mapping[seq];
         if (slot >= p.num_slots) slot = -1;
