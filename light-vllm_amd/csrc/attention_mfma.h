@@ -376,13 +376,6 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
   // (ROPE: the new K / V row is the job of a wave that rotates no Q, when there is one)
   constexpr int kKvWave = kXW ? NWAVES : (kSharedQ && NSQ / 2 < NWAVES ? NSQ / 2 : 0);
   constexpr bool kLateStores = ROPE && LVLLM_ATTN_ROPE_LATE_STORES != 0;
-  // Shared rotation (ROPE): the NSQ/2 fragment pairs are cut into kGPP groups of 4 / kGPP dwords (2 elements each) and
-  // dealt to the waves -- wave w rotates group w % kGPP of pair w / kGPP -- so that at D = 128 all 8 waves rotate a
-  // quarter chunk each instead of two waves a whole pair (round 4: the prologue's barrier waits for the slowest wave)
-  constexpr int kPairs = NSQ / 2 > 0 ? NSQ / 2 : 1;
-  constexpr int kGPP = NWAVES / kPairs >= 4 ? 4 : NWAVES / kPairs >= 2 ? 2 : 1;
-  constexpr int kDW = 4 / kGPP;  // dwords of a chunk per group
-  const int q_pair = wave / kGPP, q_grp = wave % kGPP;
   u32x4_t qf[NSQ];
   {
     const S* qrow = (const S*)p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + c) * D;
@@ -391,16 +384,9 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
       // bf16/f16 cache: d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8 above)
       const int d0 = KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g;
       qf[j] = u32x4_t{0, 0, 0, 0};
-      if constexpr (ROPE && kSharedQ) {
-        // this wave's dwords of the pair it helps to rotate (fragments q_pair and q_pair + NSQ/2)
-        if ((j % kPairs) == q_pair && q_pair < kPairs && c < nh && d0 < D) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(qrow + d0) + q_grp * kDW;
-#pragma unroll
-          for (int w2 = 0; w2 < kDW; ++w2) qf[j][q_grp * kDW + w2] = src[w2];
-        }
-      } else {
-        if (c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
-      }
+      // (shared rotation: wave w loads the pair it rotates, fragments w and w + NSQ/2)
+      const bool mine = !(ROPE && kSharedQ) || (j % (NSQ / 2 > 0 ? NSQ / 2 : 1)) == wave;
+      if (mine && c < nh && d0 < D) qf[j] = *reinterpret_cast<const u32x4_t*>(qrow + d0);
     }
   }
   // ---- ROPE: rotate Q in registers; one wave rotates the new K, stores K and V to the caches and to LDS ----
@@ -443,39 +429,14 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
       };
       // 16-bit cache: fragment j holds d = 32j + 8g ..; fp8 cache: d = 64(j>>1) + 16g + 8(j&1) .. (see KV8)
       if constexpr (kSharedQ) {
-        // wave w rotates dwords [q_grp * kDW, + kDW) of pair (q_pair, q_pair + NSQ/2) and leaves them in LDS,
-        // [fragment][lane] x 16 bytes (lanes of heads past the group write their zeros)
-        uint32_t* sm_q = reinterpret_cast<uint32_t*>(sm_vnew + D);
+        // wave j < NSQ/2 rotates pair (j, j + NSQ/2) and leaves both fragments in LDS, [fragment][lane] x 16 bytes
+        u32x4_t* sm_q = reinterpret_cast<u32x4_t*>(sm_vnew + D);
 #pragma unroll
         for (int j = 0; j < NSQ / 2; ++j) {
-          if (q_pair == j) {
-            const int d0 = (KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g) + 2 * q_grp * kDW;
-#pragma unroll
-            for (int w2 = 0; w2 < kDW; ++w2) {
-              uint32_t xw = qf[j][q_grp * kDW + w2], yw = qf[j + NSQ / 2][q_grp * kDW + w2];
-              if constexpr (!(LVLLM_ATTN_ROPE_DIAG & 9)) {
-                if (c < nh) {
-                  const uint32_t cw = *reinterpret_cast<const uint32_t*>(cosp + d0 + 2 * w2);
-                  const uint32_t sw = *reinterpret_cast<const uint32_t*>(sinp + d0 + 2 * w2);
-                  uint32_t xo = 0, yo = 0;
-#pragma unroll
-                  for (int e = 0; e < 2; ++e) {  // the arithmetic of pos_encoding.hip rotate<T>, operation for operation
-                    const float xf = T::to_float((S)(xw >> (16 * e))), yf = T::to_float((S)(yw >> (16 * e)));
-                    const float cf = T::to_float((S)(cw >> (16 * e))), sf = T::to_float((S)(sw >> (16 * e)));
-                    const float xc = T::to_float(T::from_float(xf * cf));
-                    const float ys = T::to_float(T::from_float(yf * sf));
-                    const float yc = T::to_float(T::from_float(yf * cf));
-                    const float xs = T::to_float(T::from_float(xf * sf));
-                    xo |= (uint32_t)T::from_float(__fsub_rn(xc, ys)) << (16 * e);
-                    yo |= (uint32_t)T::from_float(__fadd_rn(yc, xs)) << (16 * e);
-                  }
-                  xw = xo;
-                  yw = yo;
-                }
-              }
-              sm_q[(j * 64 + lane) * 4 + q_grp * kDW + w2] = xw;
-              sm_q[((j + NSQ / 2) * 64 + lane) * 4 + q_grp * kDW + w2] = yw;
-            }
+          if (wave == j) {
+            if (c < nh) rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
+            sm_q[j * 64 + lane] = qf[j];
+            sm_q[(j + NSQ / 2) * 64 + lane] = qf[j + NSQ / 2];
           }
         }
       } else if (c < nh) {
