@@ -696,7 +696,11 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
     }
   }
 
-  // ---- ROPE: the new token's rows go into the caches now, from the stash (see LVLLM_ATTN_ROPE_LATE_STORES) ----
+  // ---- ROPE: the new token's rows go into the caches now, from the stash (see LVLLM_ATTN_ROPE_LATE_STORES) -- behind
+  // the merge, not in front of it (round 4): the merge's __syncthreads() waits for every outstanding store of a wave
+  // (vmcnt(0) before s_barrier), so with the rows written after the walk the whole workgroup's merge waited ~0.8 us for
+  // the acknowledgement of 144 scattered stores; here they travel together with the result's own stores ----
+  auto store_new_rows = [&]() __attribute__((always_inline)) {
   if constexpr (kLateStores) {
     if (owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
       int64_t slot = p.slot_mapping[seq];
@@ -742,9 +746,12 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
       }
     }
   }
-
+  };
   if constexpr (kXW != 0) {
-    if (kv_only) return;  // its stores are on their way; the merge below belongs to the NWAVES walkers
+    if (kv_only) {
+      store_new_rows();
+      return;
+    }
   }
   // ---- merge the waves of the workgroup -------------------------------------
   l_run += __shfl_xor(l_run, 16);
@@ -789,6 +796,7 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
       p.exp_sums[row] = L;
     }
   }
+  store_new_rows();
   LVLLM_TRACE_END(2);
 }
 
