@@ -175,6 +175,15 @@ constexpr int kSrdFlags = 0x00020000;
 // bs 32 x 1 024 (24.2-24.3 against 24.2 us; fp8 17.1-17.2 against 16.8-17.0) and -9 % at bs 64 x 2 048 over an fp8 cache
 // (nine waves put five on a SIMD when two workgroups share a CU: only one fits) -- so 0 (a tile walker writes the rows
 // after its walk, round 3) stays the default; the switch remains for the record.
+// 1: the new token's cache rows are written by the wave that owns the context's LAST tile, straight from the tile
+// registers it has just patched with the new values -- the whole 16-token V tile of the kv head (full 32-byte sectors,
+// 256 / 512 contiguous bytes per wave store) and the K chunks of the token and its sector partner -- instead of 16 + 128
+// narrow stores (2-byte / 1-byte pieces of 128 different rows: every one a partial-sector write the memory side turns
+// into a read-modify-write).  Only when the slot IS the last position of the context as the block table places it
+// (what an engine passes); any other slot keeps the narrow stores.  0: always the narrow stores (round 3).
+#ifndef LVLLM_ATTN_ROPE_TILE_STORES
+#define LVLLM_ATTN_ROPE_TILE_STORES 1
+#endif
 #ifndef LVLLM_ATTN_ROPE_KV_WAVE
 #define LVLLM_ATTN_ROPE_KV_WAVE 0
 #endif
@@ -395,6 +404,8 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
   S* sm_knew = nullptr;
   S* sm_vnew = nullptr;
   bool owns_new_token = false;  // this workgroup's share ends with the step's new token
+  constexpr bool kTileStores = ROPE && LVLLM_ATTN_ROPE_LATE_STORES != 0 && LVLLM_ATTN_ROPE_TILE_STORES != 0;
+  bool tile_store_ok = false;   // the new rows leave with the last tile's registers (LVLLM_ATTN_ROPE_TILE_STORES)
   if constexpr (ROPE) {
     constexpr int DPAD_ = ((D + 15) / 16) * 16;
     const int nh_l = min(16, G);
@@ -445,6 +456,16 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
           rot8(qf[j], qf[j + NSQ / 2], KV8 ? 64 * (j >> 1) + 16 * g + 8 * (j & 1) : 32 * j + 8 * g);
       }
       owns_new_token = !p.partitioned || t1 == seq_len;
+      if constexpr (kTileStores) {
+        if (owns_new_token) {  // (wave-uniform: every wave answers alike)
+          int64_t slot = p.slot_mapping[seq];
+          if (slot >= p.num_slots) slot = -1;
+          const int P = seq_len - 1;
+          const int blk = ((P >> 4) << 4) / BS;
+          const int64_t bn = (int64_t)min((uint32_t)block_table[min(blk, last_block)], (uint32_t)p.max_block);
+          tile_store_ok = slot >= 0 && slot / BS == bn && (int)(slot % BS) == (P % BS);
+        }
+      }
       if (kLateStores && owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 4)) {
         // The new token's rows, ONE rotation pair (and two value elements) per lane: the whole workgroup waits at the
         // barrier below for this wave.  With a 16-byte chunk pair per lane it ran 16 rotations and -- over an fp8 cache --
@@ -617,6 +638,26 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
             }
           }
         }
+        if constexpr (kTileStores) {
+          if (tile_store_ok) {
+            // the patched tile goes back to the cache: V whole (every lane's piece: full sectors), K the chunks of the
+            // token and of its sector partner (tokens 2i, 2i + 1 share 32 bytes); bytes of other tokens are rewritten
+            // with what this launch loaded from them
+            const int64_t bn = (int64_t)min((uint32_t)block_table[min(((P >> 4) << 4) / BS, last_block)], (uint32_t)p.max_block);
+            const int off = (BS == 32) ? (((P >> 4) << 4) & 16) : 0;
+            __amdgpu_buffer_rsrc_t kw = __builtin_amdgcn_make_buffer_rsrc((void*)(kbytes + bn * bsb), 0, kHeadBytes, kSrdFlags);
+            __amdgpu_buffer_rsrc_t vw = __builtin_amdgcn_make_buffer_rsrc((void*)(vbytes + bn * bsb), 0, kHeadBytes, kSrdFlags);
+            const int kst = ((c | 1) == (cs | 1)) ? koff : kOut;
+#pragma unroll
+            for (int jj = 0; jj < NKL; ++jj)
+              __builtin_amdgcn_raw_buffer_store_b128(kraw[jj], kw, kst + jj * (4 * BS * 16), off * 16, 0);
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+              if constexpr (KV8) __builtin_amdgcn_raw_buffer_store_b32(v[t], vw, voff + t * (16 * BS), off, 0);
+              else __builtin_amdgcn_raw_buffer_store_b64(v[t], vw, voff + t * (16 * BS * 2), off * 2, 0);
+            }
+          }
+        }
       }
     }
     f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -702,7 +743,7 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
   // the acknowledgement of 144 scattered stores; here they travel together with the result's own stores ----
   auto store_new_rows = [&]() __attribute__((always_inline)) {
   if constexpr (kLateStores) {
-    if (owns_new_token && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
+    if (owns_new_token && !tile_store_ok && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
       int64_t slot = p.slot_mapping[seq];
       if (slot >= p.num_slots) slot = -1;
       if (slot >= 0) {
