@@ -181,8 +181,11 @@ constexpr int kSrdFlags = 0x00020000;
 // narrow stores (2-byte / 1-byte pieces of 128 different rows: every one a partial-sector write the memory side turns
 // into a read-modify-write).  Only when the slot IS the last position of the context as the block table places it
 // (what an engine passes); any other slot keeps the narrow stores.  0: always the narrow stores (round 3).
+// Measured (round 4, profiles/r04_tuning.md section 11): bit-identical and SLOWER -- 25.1 against 24.2-24.5 us, over an
+// fp8 cache 18.5 against 15.9: stores under a condition inside the tile body cost every tile its exact vmcnt waits.
+// Off; kept for the record.
 #ifndef LVLLM_ATTN_ROPE_TILE_STORES
-#define LVLLM_ATTN_ROPE_TILE_STORES 1
+#define LVLLM_ATTN_ROPE_TILE_STORES 0
 #endif
 #ifndef LVLLM_ATTN_ROPE_KV_WAVE
 #define LVLLM_ATTN_ROPE_KV_WAVE 0
