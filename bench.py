@@ -295,6 +295,7 @@ def gemm_leg(engine, B):
             x = (torch.randn(B, K, device=dev) * 0.5).to(cfg.dtype)
 
             once = w8 and cfg.fp8_activations_once and B <= 32
+            glu = (not w8) and name == "gate_up" and cfg.swiglu_epilogue and N % 32 == 0
             x8 = torch.randint(0, 120, (B, K), device=dev, dtype=torch.uint8) if once else None
             down_scale = layers[0].down.x_scale
 
@@ -308,6 +309,8 @@ def gemm_leg(engine, B):
                     torch.ops._C_amd.skinny_linear_w8a8_q_partials(x8, w.w8_packed, w.w_scale, w.x_scale, N, K)
                 elif w8:
                     torch.ops._C_amd.skinny_linear_w8a8(x, w.w8_packed, w.w_scale, w.x_scale, N, K, None)
+                elif glu:  # the launch the engine's step makes: gate_up with silu_and_mul in its epilogue
+                    torch.ops._C_amd.skinny_linear_packed_swiglu(x, w.packed, None, N, K)
                 else:
                     torch.ops._C_amd.skinny_linear_packed(x, w.packed, None, N, K)
             for w in ws[:4]:
@@ -322,6 +325,8 @@ def gemm_leg(engine, B):
             torch.cuda.synchronize(dev)
             t = min(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(ws)
             by = N * K * (1 if w8 else 2) + B * K * (1 if once else 2) + B * N * 2  # weights once + activations in + result out
+            if glu:
+                by = N * K * 2 + B * K * 2 + B * (N // 2) * 2  # SwiGLU result out
             if once and name == "gate_up":
                 by = N * K + B * K + B * (N // 2)          # fp8 in, SwiGLU result out as fp8
             elif once and name == "down":
@@ -1024,7 +1029,7 @@ def main():
                 pass
             line["roofline_projections"] = {
                 "bound": "hbm", "kernel": ("skinny_gemm_w8a8_kernel" if gm["w8"] else "skinny_gemm_kernel") +
-                                          f" (qkv, o, gate_up + SwiGLU input, down of one layer, M = {B}, 256 workgroups)",
+                                          f" (qkv, o, gate_up with its SwiGLU epilogue, down of one layer, M = {B}, at most 256 workgroups: the fewest that divide the n-tiles evenly)",
                 "achieved": round(g_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_ach / HBM_PEAK_GBS, 4),
                 "traffic": gm_traffic, "traffic_source": "profiles/r03_pmc_gemm[_w8a8].json (2*FETCH_SIZE + WRITE_SIZE per "
                                                          "launch, the four shapes summed; M = 32; a recording)",
