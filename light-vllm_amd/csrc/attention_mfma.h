@@ -185,7 +185,7 @@ constexpr int kSrdFlags = 0x00020000;
 // fp8 cache 18.5 against 15.9: stores under a condition inside the tile body cost every tile its exact vmcnt waits.
 // Off; kept for the record.
 #ifndef LVLLM_ATTN_ROPE_TILE_STORES
-#define LVLLM_ATTN_ROPE_TILE_STORES 0
+#define LVLLM_ATTN_ROPE_TILE_STORES 2
 #endif
 #ifndef LVLLM_ATTN_ROPE_KV_WAVE
 #define LVLLM_ATTN_ROPE_KV_WAVE 0
@@ -408,6 +408,13 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
   S* sm_vnew = nullptr;
   bool owns_new_token = false;  // this workgroup's share ends with the step's new token
   constexpr bool kTileStores = ROPE && LVLLM_ATTN_ROPE_LATE_STORES != 0 && LVLLM_ATTN_ROPE_TILE_STORES != 0;
+  // mode 2: the last tile's owner only STASHES its patched tile in LDS inside the walk (no store under a condition in
+  // the tile body); the rows leave behind the merge as 16-byte stores of whole sectors
+  constexpr bool kTileStash = kTileStores && LVLLM_ATTN_ROPE_TILE_STORES == 2;
+  constexpr int kTileRowBytes = 16 * KVB;              // one V row of the 16-token tile
+  constexpr int kTileKChunks = D * KVB / 16;           // 16-byte K chunks per token
+  char* tile_stash_v = nullptr;                        // [D rows][16 tokens]
+  char* tile_stash_k = nullptr;                        // [chunk][2 tokens] x 16 bytes
   bool tile_store_ok = false;   // the new rows leave with the last tile's registers (LVLLM_ATTN_ROPE_TILE_STORES)
   if constexpr (ROPE) {
     constexpr int DPAD_ = ((D + 15) / 16) * 16;
@@ -416,6 +423,8 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
     sm_knew = reinterpret_cast<S*>(smem_raw + (size_t)NWAVES * 16 * 2 * sizeof(float) +
                                    (size_t)NWAVES * nh_l * DPAD_ * sizeof(float));
     sm_vnew = sm_knew + D;
+    tile_stash_v = reinterpret_cast<char*>(sm_vnew + D) + (size_t)2 * ((D + 31) / 32) * 1024;
+    tile_stash_k = tile_stash_v + D * kTileRowBytes;
     if (seq_len > 0) {
       const int64_t pos = p.positions[seq];
       const S* cosp = (const S*)p.cos_sin_cache + pos * D;
@@ -641,7 +650,19 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
             }
           }
         }
-        if constexpr (kTileStores) {
+        if constexpr (kTileStash) {
+          if (tile_store_ok) {
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+              *reinterpret_cast<vraw_t*>(tile_stash_v + (16 * t + c) * kTileRowBytes + g * (int)sizeof(vraw_t)) = v[t];
+            if ((c | 1) == (cs | 1)) {
+#pragma unroll
+              for (int jj = 0; jj < NKL; ++jj)
+                if (4 * jj + g < kTileKChunks)
+                  *reinterpret_cast<u32x4_t*>(tile_stash_k + ((4 * jj + g) * 2 + (c & 1)) * 16) = kraw[jj];
+            }
+          }
+        } else if constexpr (kTileStores) {
           if (tile_store_ok) {
             // the patched tile goes back to the cache: V whole (every lane's piece: full sectors), K the chunks of the
             // token and of its sector partner (tokens 2i, 2i + 1 share 32 bytes); bytes of other tokens are rewritten
@@ -745,6 +766,25 @@ __global__ __launch_bounds__((NWAVES + attn_extra_waves<ROPE, D>()) * 64,
   // (vmcnt(0) before s_barrier), so with the rows written after the walk the whole workgroup's merge waited ~0.8 us for
   // the acknowledgement of 144 scattered stores; here they travel together with the result's own stores ----
   auto store_new_rows = [&]() __attribute__((always_inline)) {
+  if constexpr (kTileStash) {
+    if (owns_new_token && tile_store_ok && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
+      const int P = seq_len - 1;
+      const int64_t slot = p.slot_mapping[seq];  // (tile_store_ok: valid and the context's last position)
+      const int64_t bn = slot / BS;
+      const int off = (BS == 32) ? (((P >> 4) << 4) & 16) : 0;
+      char* vdst = (char*)p.v_cache + (bn * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) * KVB + off * KVB;
+      char* kdst = (char*)p.k_cache + (bn * p.kv_block_stride + (int64_t)kvh * p.kv_head_stride) * KVB;
+#pragma unroll
+      for (int i = lane; i < D * kTileRowBytes / 16; i += 64) {
+        const int r = (i * 16) / kTileRowBytes, h = (i * 16) % kTileRowBytes;
+        *reinterpret_cast<u32x4_t*>(vdst + (int64_t)r * BS * KVB + h) = *reinterpret_cast<const u32x4_t*>(tile_stash_v + i * 16);
+      }
+      const int tok0 = (P % BS) & ~1;
+      if (lane < 2 * kTileKChunks)
+        *reinterpret_cast<u32x4_t*>(kdst + ((int64_t)(lane >> 1) * BS + tok0 + (lane & 1)) * 16) =
+            *reinterpret_cast<const u32x4_t*>(tile_stash_k + lane * 16);
+    }
+  }
   if constexpr (kLateStores) {
     if (owns_new_token && !tile_store_ok && wave == kKvWave && !(LVLLM_ATTN_ROPE_DIAG & 6)) {
       int64_t slot = p.slot_mapping[seq];
@@ -864,7 +904,7 @@ static void launch_mfma(const AttnParams& p, int num_seqs, int num_parts, hipStr
   constexpr int DPAD = ((D + 15) / 16) * 16;
   const size_t smem = (size_t)NWAVES * 16 * 2 * sizeof(float) +
                       (size_t)NWAVES * nh_lds * DPAD * sizeof(float) +
-                      (p.positions != nullptr ? (size_t)2 * D * 2 + (size_t)2 * ((D + 31) / 32) * 1024 : 0);  // ROPE: the new
+                      (p.positions != nullptr ? (size_t)2 * D * 2 + (size_t)2 * ((D + 31) / 32) * 1024 + (size_t)D * 32 + (size_t)D * 4 : 0);  // ROPE: the new
                                                                   // token's k and v, the rotated Q fragments (<= 2 NS KiB)
   auto launch = [&](auto kern) {
     if (smem > 64 * 1024)
