@@ -183,9 +183,11 @@ constexpr int kSrdFlags = 0x00020000;
 // (what an engine passes); any other slot keeps the narrow stores.  0: always the narrow stores (round 3).
 // Measured (round 4, profiles/r04_tuning.md section 11): bit-identical and SLOWER -- 25.1 against 24.2-24.5 us, over an
 // fp8 cache 18.5 against 15.9: stores under a condition inside the tile body cost every tile its exact vmcnt waits.
-// Off; kept for the record.
+// 2: the owner only stashes the patched tile in LDS inside the walk and the rows leave behind the merge as 16-byte
+// stores of whole sectors: also slower (25.5 / 18.6 us) -- the ISA shows why: with either form in the tile body hipcc
+// gives up the counted vmcnt waits of the loop (56 -> 21 waits, 14 of them vmcnt(0)).  Off; kept for the record.
 #ifndef LVLLM_ATTN_ROPE_TILE_STORES
-#define LVLLM_ATTN_ROPE_TILE_STORES 2
+#define LVLLM_ATTN_ROPE_TILE_STORES 0
 #endif
 #ifndef LVLLM_ATTN_ROPE_KV_WAVE
 #define LVLLM_ATTN_ROPE_KV_WAVE 0
