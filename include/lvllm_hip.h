@@ -63,7 +63,8 @@ const char* lvllm_version(void);
  * "cache_tile_min_tokens" (reshape_and_cache: token count from which the LDS-tiled kernel is used),
  * "prefill_mfma32_min_query" (paged_prefill_attention: plain launches -- head size 64 or 128, 16-bit cache -- whose
  * longest chunk has at least this many query tokens take the 32x32-MFMA body, and so do launches with chunks of 16+
- * tokens whose grid fits the CUs at once; 0 = never).  lvllm_get_tuning reads a knob back. */
+ * tokens whose grid fits the CUs at once; 0 = never), "varlen_dense" (1 | 0: lvllm_varlen_attention's long plain
+ * launches read key/value in place instead of packing them first).  lvllm_get_tuning reads a knob back. */
 int lvllm_set_tuning(const char* key, int value);
 int lvllm_get_tuning(const char* key, int* value);
 
@@ -402,11 +403,13 @@ int lvllm_paged_prefill_attention_ws(
  * (light_vllm/prefill_only/backends/attention/backends/flash_attn.py: flash_attn_varlen_func(q, k, v,
  * cu_seqlens, causal=...); in-tree definition torch_naive.py:65-149).  query [T, num_heads, D],
  * key/value [T, num_kv_heads, D] (token strides in elements), cu_seqlens int32 [num_seqs + 1] on the
- * device, causal = 1 for AttentionType.DECODER, 0 for ENCODER.  Two launches, no host
- * synchronisation: key/value are packed into paged tiles in `workspace` (sequence s owns the blocks
- * cu_seqlens[s] / 16 + s ...), then lvllm_paged_prefill_attention runs over them with
- * block_tables = seq_lens = NULL, which selects that arithmetic placement.
- * workspace: at least lvllm_varlen_attention_workspace_bytes(...) bytes, 256-byte aligned. */
+ * device, causal = 1 for AttentionType.DECODER, 0 for ENCODER.  No host synchronisation.  Plain launches (head size
+ * 64, no ALiBi / soft cap / window) whose longest sequence has 64+ tokens are ONE launch: the 32x32-MFMA body
+ * reads the key/value rows where they lie (tuning key "varlen_dense", default 1).  Everything else is two: key/value
+ * are packed into paged tiles in `workspace` (sequence s owns the blocks cu_seqlens[s] / 16 + s ...), then
+ * lvllm_paged_prefill_attention runs over them with block_tables = seq_lens = NULL, which selects that arithmetic
+ * placement.  Both give the same bits.
+ * workspace: at least lvllm_varlen_attention_workspace_bytes(...) bytes, 256-byte aligned (required either way). */
 int64_t lvllm_varlen_attention_workspace_bytes(int num_tokens, int num_seqs, int max_seq_len,
                                                int num_kv_heads, int head_size);
 int lvllm_varlen_attention(

@@ -15,6 +15,7 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_ATTN_WAVES")) v.attn_waves = atoi(e);
     if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
+    if (const char* e = getenv("LVLLM_VARLEN_DENSE")) v.varlen_dense = atoi(e) != 0;
     if (const char* e = getenv("LVLLM_PREFILL_MFMA32_MIN_QUERY")) v.prefill_mfma32_min_query = atoi(e);
     if (const char* e = getenv("LVLLM_PREFILL_CHUNK_MAX_QUERY")) v.prefill_chunk_max_query = atoi(e);
     return v;
@@ -41,6 +42,8 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
     lvllm::tuning().gemm_partials_ksplit = value;
   } else if (k == "gemm_balance") {
     lvllm::tuning().gemm_balance = value != 0;
+  } else if (k == "varlen_dense") {
+    lvllm::tuning().varlen_dense = value != 0;
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
@@ -79,6 +82,7 @@ extern "C" int lvllm_get_tuning(const char* key, int* value) {
   else if (k == "gemm_wide_min_tiles") *value = t.gemm_wide_min_tiles;
   else if (k == "gemm_partials_ksplit") *value = t.gemm_partials_ksplit;
   else if (k == "gemm_balance") *value = t.gemm_balance;
+  else if (k == "varlen_dense") *value = t.varlen_dense;
   else if (k == "attn_waves") *value = t.attn_waves;
   else if (k == "attn_splits") *value = t.attn_splits;
   else if (k == "swap_kernel_min_runs") *value = t.swap_kernel_min_runs;

@@ -27,6 +27,7 @@ void set_error(const std::string& msg);
 //   prefill_lds      1 | 0, see Tuning
 //   prefill_mfma32_min_query   see Tuning
 //   prefill_chunk_max_query, prefill_chunk_max_avg_x8    see Tuning
+//   varlen_dense     see Tuning
 struct Tuning {
   int gemm_workgroups = 256;
   int gemm_workgroups_wide = 0;  // for projections with >= gemm_wide_min_tiles n-tiles; 0 = as above
@@ -41,6 +42,8 @@ struct Tuning {
   int cache_tile_min_tokens = 384;  // reshape_and_cache: >= this many tokens take the LDS-tiled kernel (consecutive
                                     // slots: 6.0 us against 6.8 at 512 tokens, 5.8 against 5.0 at 256; scattered
                                     // slots cost the tiled kernel 17 us at any small size)
+  int varlen_dense = 1;  // lvllm_varlen_attention: launches the 32x32 body takes read the caller's K / V rows
+                         // themselves (row-major LDS images, transposed reads of V); 0: always the pack pass first
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
   int prefill_mfma32_min_query = 64;  // launches whose longest chunk has at least this many query tokens take the
                                       // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache) --

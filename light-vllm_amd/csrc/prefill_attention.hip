@@ -215,10 +215,31 @@ extern "C" int lvllm_varlen_attention(
   const VarlenLayout L = varlen_layout(num_tokens, num_seqs, max_seq_len, num_kv_heads, head_size);
   LV_CHECK(workspace != nullptr && workspace_bytes >= L.total && ((uintptr_t)workspace & 255) == 0,
            "workspace too small or misaligned (lvllm_varlen_attention_workspace_bytes)");
+  hipStream_t s = (hipStream_t)stream;
+  if (lvllm::tuning().varlen_dense) {
+    // long plain sequences: the 32x32 body reads the caller's rows itself (prefill_mfma32.h, DENSE): no pack pass
+    PrefillParams p{};
+    p.out = out; p.q = query; p.k_cache = key; p.v_cache = value; p.query_start_loc = cu_seqlens;
+    p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.max_num_blocks_per_seq = 1; p.max_block = 0;
+    p.causal = causal ? 1 : 0; p.k_scale = p.v_scale = 1.f;
+    p.alibi_slopes = alibi_slopes; p.sliding_window = sliding_window; p.scale = scale; p.softcap = softcap;
+    p.q_stride = q_stride; p.out_stride = out_stride; p.num_tokens = num_tokens;
+    p.dense_k_stride = k_stride; p.dense_v_stride = v_stride;
+    p.dense_k_bytes = ((int64_t)(num_tokens - 1) * k_stride + (int64_t)num_kv_heads * head_size) * 2;
+    p.dense_v_bytes = ((int64_t)(num_tokens - 1) * v_stride + (int64_t)num_kv_heads * head_size) * 2;
+    if (dense_mfma32_takes(p, head_size, num_seqs, max_seq_len)) {
+      LV_CHECK((((uintptr_t)query | (uintptr_t)out) & 15) == 0 && (q_stride * 2) % 16 == 0 && (out_stride * 2) % 8 == 0,
+               "operands must be 16-byte aligned");
+      const int rc = dtype == LVLLM_BF16 ? launch_prefill_mfma32_dense<BF16>(p, head_size, num_seqs, max_seq_len, s)
+                                         : launch_prefill_mfma32_dense<F16>(p, head_size, num_seqs, max_seq_len, s);
+      if (rc) return rc;
+      LV_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   char* ws = (char*)workspace;
   void* k_cache = ws;
   void* v_cache = ws + L.off_v;
-  hipStream_t s = (hipStream_t)stream;
   const size_t smem = (size_t)head_size * (kVarlenBS + 8) * 2;
   hipLaunchKernelGGL(varlen_pack_kernel, dim3(L.max_blocks_per_seq, num_kv_heads, num_seqs), dim3(256), smem, s,
                      (const uint16_t*)key, (const uint16_t*)value, (uint16_t*)k_cache, (uint16_t*)v_cache,

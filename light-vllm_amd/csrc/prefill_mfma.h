@@ -69,6 +69,9 @@ struct PrefillParams {
   int num_tokens;  // rows of `query` the caller states (0: unknown)
   void* workspace;
   int64_t workspace_bytes;
+  // the dense twin of the 32x32 body (prefill_mfma32.h, DENSE): k_cache / v_cache are row-major [token][KVH][D] rows
+  // of the caller (token strides in elements), readable for dense_k_bytes / dense_v_bytes from their bases
+  int64_t dense_k_stride, dense_v_stride, dense_k_bytes, dense_v_bytes;
 };
 
 // Column layout of one 16-column MFMA block: column c = (query token c / GP, head c % GP) with

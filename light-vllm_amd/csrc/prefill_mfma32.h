@@ -22,6 +22,15 @@
 //   * accumulators are rescaled only when some column's maximum grew by more than 2^kGrow over the value
 //     the exponentials use (probabilities stay below 2^kGrow; fp32 sums and the bf16/f16 rounding of P are
 //     relative, so nothing is lost).
+//
+// DENSE (the twin for encode-only models, lvllm_varlen_attention): K and V are the caller's row-major [token][KVH][D]
+// rows (slices of a fused qkv projection), copied as whole rows into row-major LDS images -- no pack pass in front of
+// the launch.  K fragments are 16-byte row reads as before; a V^T fragment is two ds_read_b64_tr_b16 (the hardware
+// transposes 4 keys x 16 columns per 16 lanes).  Chunk c of row r sits at r * 2D + 16 * (c ^ f(r)); f makes the row
+// reads, the transposed reads and the copy's writes conflict-free (tools/lds_image_check.py).  Instantiated for head
+// size 64 (the encoders' size: 32 x 512 tokens, 16 heads 91 -> 72 us per call, the pack pass included); at 128 the
+// image addresses are 16 more live registers than the 245 of the paged body and the spills cost more than the pack
+// pass did (8 x 1 024, 32 heads: 127 -> 174 us) -- those launches keep the pack pass (profiles/r04_tuning.md, 12).
 #pragma once
 #include "prefill_mfma.h"
 #include "prefill_partitions.h"
@@ -89,7 +98,9 @@ __device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
 
 // Accumulator layout of the 32x32 MFMA: lane (col = lane & 31, hi = lane >> 5), register r holds row
 // (r & 3) + 8 * (r >> 2) + 4 * hi.
-template <typename T, int D, int BS>
+typedef short i16x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T, int D, int BS, bool DENSE = false>
 __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const PrefillParams p, const ChunkScratch sc) {
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "16-bit element types");
@@ -111,6 +122,15 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   constexpr float kMasked = -FLT_MAX;
   constexpr float kMInit = -1e30f;
   constexpr float kGrow = (float)LVLLM_PREFILL32_GROW;
+  // DENSE: the row-major images
+  constexpr int kRowB = D * 2;            // bytes of a row
+  constexpr int kCPR = D / 8;             // 16-byte chunks of a row
+  constexpr int kRowsPerPiece = 64 / kCPR;
+  static_assert(!DENSE || D == 64, "dense twin: head size 64 (128 spills, see the header)");
+  auto img = [](const int row, const int c) __attribute__((always_inline)) -> int {
+    const int f = D == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3));
+    return row * kRowB + ((c ^ f) << 4);
+  };
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -209,7 +229,23 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   // through registers: fetch(j) issues the loads of tile j, stash(j) writes them to tile j's stage (a block past
   // the walk reads as zeros through its zero-size descriptor)
   u32x4_t staged[kPiecesPerWave];
+  // DENSE: wave w copies rows 16 (w & 3) .. + 15 of the tile's K (w < 4) or V, a piece = kRowsPerPiece whole rows
+  const int dn_row = 16 * (wave & 3) + lane / kCPR, dn_c = lane % kCPR;
+  const int64_t dn_stride_b = (ld_kind ? p.dense_v_stride : p.dense_k_stride) * 2;
+  const uint32_t dn_voff = (uint32_t)((int64_t)(qbeg + dn_row) * dn_stride_b + (int64_t)kvh * kRowB + dn_c * 16);
   auto fetch = [&](const int j, const int bn32) __attribute__((always_inline)) {
+    if constexpr (DENSE) {
+      const bool valid = j * KT < khi_walk;
+      __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(ld_kind ? p.v_cache : p.k_cache), 0,
+          valid ? (int)(ld_kind ? p.dense_v_bytes : p.dense_k_bytes) : 0, kSrdFlags);
+      const uint32_t tile_off = (uint32_t)(j * KT) * (uint32_t)dn_stride_b;
+#pragma unroll
+      for (int i = 0; i < kPiecesPerWave; ++i)  // (a row past the caller's last one reads as zeros)
+        staged[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            r, dn_voff + tile_off + (uint32_t)(i * kRowsPerPiece) * (uint32_t)dn_stride_b, 0, 0);
+      return;
+    }
     const bool valid = (j * kBlocksPerTile + ld_blk) * BS < khi_walk;
     __amdgpu_buffer_rsrc_t r =
         __builtin_amdgcn_make_buffer_rsrc((void*)(ld_base + (int64_t)bn32 * bsb), 0, valid ? kSlice : 0, kSrdFlags);
@@ -223,6 +259,18 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   // This lane's 16 bytes of a V piece are 8 consecutive tokens of one row, starting at ld_tok0 of the tile.
   const int ld_tok0 = ld_blk * BS + (BS == 16 ? (lane >> 5) : (lane >> 4)) * 8;
   auto stash = [&](const int j) __attribute__((always_inline)) {
+    if constexpr (DENSE) {
+      char* st = kv_lds + (j % kStages) * kStage + ld_kind * kImage;
+      const bool tail = ld_kind == 1 && j * KT + KT > seq_len;  // (wave-uniform) a lane's 16 bytes are one token's
+#pragma unroll
+      for (int i = 0; i < kPiecesPerWave; ++i) {
+        const int row = dn_row + i * kRowsPerPiece;
+        u32x4_t v = staged[i];
+        if (tail && j * KT + row >= seq_len) v = u32x4_t{0, 0, 0, 0};
+        *reinterpret_cast<u32x4_t*>(st + img(row, dn_c)) = v;
+      }
+      return;
+    }
     char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024 + lane * 16;
     if (ld_kind == 1 && j * KT + KT > seq_len) {  // (wave-uniform; the copy registers themselves are never modified)
       const int nvalid = seq_len - (j * KT + ld_tok0);  // <= 0: none, >= 8: all
@@ -279,12 +327,27 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   constexpr int kWin = 8;
   constexpr int kWinK = LVLLM_PREFILL32_KWIN;  // window of the K fragments
   constexpr int NV = 4 * NDB;  // V^T fragments of a tile, in the order (row block db, k-step ks)
+  // DENSE, transposed reads: lane 4 q + pp of every 16 addresses row q of a block of 4 keys, columns 4 pp .. 4 pp + 3
+  // of the block's 16; lane i of the 16 receives column i of the 4 keys.  The 16-lane groups of a wave are
+  // (d half col >> 4, key half hi), so a lane ends up with the 8 keys 8 hi .. 8 hi + 7 of row 32 db + col.
+  const int tr_q = (lane & 15) >> 2, tr_c = 2 * (col >> 4) + ((lane & 3) >> 1), tr_b = 8 * (lane & 1);
   auto kread = [&](const char* st, const int kh, const int ks) __attribute__((always_inline)) -> u32x4_t {
     if constexpr (LVLLM_PREFILL32_DIAG & 16) return qf[(ks + 1) % NKS];
+    if constexpr (DENSE) return *reinterpret_cast<const u32x4_t*>(st + img(32 * kh + krow, 2 * ks + hi));
     return *reinterpret_cast<const u32x4_t*>(st + koff[kh] + ks * kKStep);
   };
   auto vread = [&](const char* st, const int i) __attribute__((always_inline)) -> u32x4_t {
     if constexpr (LVLLM_PREFILL32_DIAG & 16) return qf[i % NKS];
+    if constexpr (DENSE) {
+      typedef __attribute__((address_space(3))) i16x4_t* lds_tr_t;
+      const int db = i >> 2, ks = i & 3;
+      const int key = 16 * ks + 8 * hi + tr_q;
+      const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(st + kImage + img(key, 4 * db + tr_c) + tr_b));
+      const i16x4_t up =
+          __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(st + kImage + img(key + 4, 4 * db + tr_c) + tr_b));
+      const u32x2_t a = __builtin_bit_cast(u32x2_t, lo), b = __builtin_bit_cast(u32x2_t, up);
+      return u32x4_t{a.x, a.y, b.x, b.y};
+    }
     return *reinterpret_cast<const u32x4_t*>(st + voff(i >> 2, i & 3));
   };
   auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
@@ -438,8 +501,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
     // barrier that publishes it -- after the softmax of tile j, so that the loads have had K.Q^T and the softmax
     // to arrive and the writes drain under P.V.  The stage of tile j+1 held tile j+1-kStages, which every wave
     // has left behind before the barrier of tile j.
-    load_block_chunk(j0 >> 6, ld_blk);
-    fetch(j0, block_of_tile(j0));
+    if constexpr (!DENSE) load_block_chunk(j0 >> 6, ld_blk);
+    fetch(j0, DENSE ? 0 : block_of_tile(j0));
     stash(j0);
 #if LVLLM_PREFILL32_STAMPS
     // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
@@ -462,8 +525,10 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
       if (j == 0 && threadIdx.x == 0 && wg_id < kWgRecords) g_prefill32_wg[wg_id * kWgFields + 1] = wall_clock64();
 #endif
       if constexpr (!(LVLLM_PREFILL32_DIAG & 1)) {
-        if (((j + 1) & 63) == 0) load_block_chunk((j + 1) >> 6, ld_blk);
-        fetch(j + 1, block_of_tile(j + 1));
+        if constexpr (!DENSE) {
+          if (((j + 1) & 63) == 0) load_block_chunk((j + 1) >> 6, ld_blk);
+        }
+        fetch(j + 1, DENSE ? 0 : block_of_tile(j + 1));
       }
     };
     // The second wave of every SIMD (waves w and w + 4 share one) runs half a tile out of phase: it publishes
@@ -599,8 +664,8 @@ inline Prefill32Plan prefill32_plan(int num_seqs, int max_query_len, int num_hea
   return pl;
 }
 
-template <typename T, int D, int BS>
-static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
+template <typename T, int D, int BS, bool DENSE>
+static int launch_prefill_mfma32_impl(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
   PrefillParams p = p0;
   const int G = p.num_heads / p.num_kv_heads;
   const int HG = (G + 31) / 32;
@@ -612,7 +677,7 @@ static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_
     sc = partition_scratch(p.workspace, pl.rows, pl.parts, pl.part_tokens, D);
   const dim3 grid(p.num_kv_heads * HG, num_seqs, pl.qtiles * sc.num_parts);
   const size_t smem = (size_t)LVLLM_PREFILL32_STAGES * 2 * D * 64 * 2;
-  auto kern = paged_prefill_mfma32_kernel<T, D, BS>;
+  auto kern = paged_prefill_mfma32_kernel<T, D, BS, DENSE>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, sc);
@@ -653,6 +718,26 @@ static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_
   }
 #endif
   return 0;
+}
+
+template <typename T, int D, int BS>
+static int launch_prefill_mfma32(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
+  return launch_prefill_mfma32_impl<T, D, BS, false>(p0, num_seqs, max_query_len, stream);
+}
+
+// The dense twin (DENSE above): whether a launch of lvllm_varlen_attention can read the caller's rows directly ...
+inline bool dense_mfma32_takes(const PrefillParams& p, int head_size, int num_seqs, int max_query_len) {
+  return head_size == 64 && !p.kv_fp8 && p.alibi_slopes == nullptr && p.softcap <= 0.f &&
+         p.sliding_window <= 0 && p.dense_k_bytes > 0 && p.dense_v_bytes > 0 &&
+         p.dense_k_bytes < ((int64_t)1 << 31) && p.dense_v_bytes < ((int64_t)1 << 31) &&
+         takes_mfma32(p, num_seqs, max_query_len);
+}
+// ... and the launch (block_tables = seq_lens = null: context == chunk)
+template <typename T>
+static int launch_prefill_mfma32_dense(const PrefillParams& p, int head_size, int num_seqs, int max_query_len,
+                                       hipStream_t stream) {
+  LV_CHECK(head_size == 64, "dense twin: head size 64");
+  return launch_prefill_mfma32_impl<T, 64, 16, true>(p, num_seqs, max_query_len, stream);
 }
 
 }  // namespace lvllm

@@ -68,6 +68,54 @@ def test_varlen_op_vs_oracle_ragged(ops, causal, H, KVH, D):
     check_attention(out, want)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("H,KVH,D", [(16, 16, 64), (8, 2, 128), (12, 4, 64), (4, 4, 128)])
+def test_rows_read_in_place_equal_the_pack_pass_bit_for_bit(ops, dtype, causal, H, KVH, D):
+    """Launches the 32x32 body takes read K / V where the caller left them (row-major LDS images, transposed reads of
+    V; `varlen_dense`, on by default) -- the same MFMAs on the same operands as behind the pack pass, so the same bits.
+    Strided views of one fused qkv buffer; lengths around the 64-key tile, the 8-key group and the 16-row copy share
+    of a wave; Inf / NaN in the rows of the NEXT sequence and behind the last one must not leak into a sequence.
+    (Head size 128 keeps the pack pass whatever the knob says: the case checks that it is left alone.)"""
+    seq_lens = [64, 65, 127, 128, 129, 200, 1, 7, 63, 333, 512, 72]
+    T = sum(seq_lens)
+    g = torch.Generator().manual_seed(H * 1000 + D + causal)
+    tail = 40  # rows behind the last sequence: another caller's data
+    qkv = (torch.randn(T + tail, (H + 2 * KVH) * D, generator=g) * 0.5).to(dtype)
+    qkv[T:] = float("nan")
+    dq = qkv.to(DEV)
+    q_d, k_d, v_d = (x[:T] for x in dq.split([H * D, KVH * D, KVH * D], dim=1))
+    cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32)
+    outs = []
+    for dense in (1, 0):
+        torch.ops._C_amd.set_tuning("varlen_dense", dense)
+        try:
+            out = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
+            ops.varlen_attention(out, q_d.view(T, H, D), k_d.view(T, KVH, D), v_d.view(T, KVH, D), cu.to(DEV),
+                                 max(seq_lens), D ** -0.5, causal)
+            torch.cuda.synchronize()
+        finally:
+            torch.ops._C_amd.set_tuning("varlen_dense", 1)
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    q, k, v = (x[:T] for x in qkv.split([H * D, KVH * D, KVH * D], dim=1))
+    want = torch.zeros(T, H, D, dtype=dtype)
+    oracle.varlen_attention(want, q.reshape(T, H, D), k.reshape(T, KVH, D), v.reshape(T, KVH, D), cu, D ** -0.5,
+                            causal)
+    check_attention(outs[0], want)
+    # a sequence whose neighbour holds Inf: the neighbour's rows are in its last tile's image, never in its result
+    seq = 4  # 129 tokens: its third tile holds 63 rows of sequence 5
+    poisoned = dq.clone()
+    poisoned[int(cu[seq + 1]):int(cu[seq + 2]), H * D:] = float("inf")
+    pq, pk, pv = (x[:T] for x in poisoned.split([H * D, KVH * D, KVH * D], dim=1))
+    out2 = torch.empty((T, H, D), dtype=dtype, device=DEV)
+    ops.varlen_attention(out2, pq.view(T, H, D), pk.view(T, KVH, D), pv.view(T, KVH, D), cu.to(DEV), max(seq_lens),
+                         D ** -0.5, causal)
+    sl = slice(int(cu[seq]), int(cu[seq + 1]))
+    assert torch.equal(out2[sl].cpu().view(torch.int16), outs[0][sl].view(torch.int16))
+
+
 def test_varlen_long_sequences_properties(ops):
     """bge-m3-like encoder batch (8 x 2048 tokens, 16 heads of 64): sampled rows vs fp64, and the
     encoder output of a sequence does not depend on its neighbours in the batch (bit-exact)."""
