@@ -134,6 +134,7 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
             h = e["hbm"]
             assert h["peak"] == 8000.0 and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-3
         assert o["config3_chunked_prefill"]["requests_per_s"] > 0
+        assert o["config3_chunked_prefill"]["short_run"]["value"] > 0  # the 96-prompt run rounds 2 - 4 quoted
         f8 = o["config5_fp8_weights_fp8_kv"]
         assert f8["roofline_attention"]["bound"] == "hbm" and f8["roofline_attention"]["avg_launch_us"] > 0
         assert set(f8["roofline_projections"]["per_shape"]) == {"qkv", "o", "gate_up", "down"}
