@@ -64,7 +64,8 @@ const char* lvllm_version(void);
  * "prefill_mfma32_min_query" (paged_prefill_attention: plain launches -- head size 64 or 128, 16-bit cache -- whose
  * longest chunk has at least this many query tokens take the 32x32-MFMA body, and so do launches with chunks of 16+
  * tokens whose grid fits the CUs at once; 0 = never), "varlen_dense" (1 | 0: lvllm_varlen_attention's long plain
- * launches read key/value in place instead of packing them first).  lvllm_get_tuning reads a knob back. */
+ * launches read key/value in place instead of packing them first), "varlen_dense_waves" (waves per workgroup of that
+ * launch: 8, 4, or 0 = by the longest sequence).  lvllm_get_tuning reads a knob back. */
 int lvllm_set_tuning(const char* key, int value);
 int lvllm_get_tuning(const char* key, int* value);
 

@@ -16,6 +16,7 @@ Tuning& tuning() {
     if (const char* e = getenv("LVLLM_ATTN_SPLITS")) v.attn_splits = atoi(e);  // read once, at load
     if (const char* e = getenv("LVLLM_PREFILL_LDS")) v.prefill_lds = atoi(e);
     if (const char* e = getenv("LVLLM_VARLEN_DENSE")) v.varlen_dense = atoi(e) != 0;
+    if (const char* e = getenv("LVLLM_VARLEN_DENSE_WAVES")) v.varlen_dense_waves = atoi(e) == 4 ? 4 : atoi(e) == 8 ? 8 : 0;
     if (const char* e = getenv("LVLLM_PREFILL_MFMA32_MIN_QUERY")) v.prefill_mfma32_min_query = atoi(e);
     if (const char* e = getenv("LVLLM_PREFILL_CHUNK_MAX_QUERY")) v.prefill_chunk_max_query = atoi(e);
     return v;
@@ -44,6 +45,9 @@ extern "C" int lvllm_set_tuning(const char* key, int value) {
     lvllm::tuning().gemm_balance = value != 0;
   } else if (k == "varlen_dense") {
     lvllm::tuning().varlen_dense = value != 0;
+  } else if (k == "varlen_dense_waves") {
+    LV_CHECK(value == 0 || value == 4 || value == 8, "varlen_dense_waves must be 0 (by sequence length), 4 or 8");
+    lvllm::tuning().varlen_dense_waves = value;
   } else if (k == "attn_waves") {
     LV_CHECK(value == 4 || value == 8, "attn_waves must be 4 or 8");
     lvllm::tuning().attn_waves = value;
@@ -83,6 +87,7 @@ extern "C" int lvllm_get_tuning(const char* key, int* value) {
   else if (k == "gemm_partials_ksplit") *value = t.gemm_partials_ksplit;
   else if (k == "gemm_balance") *value = t.gemm_balance;
   else if (k == "varlen_dense") *value = t.varlen_dense;
+  else if (k == "varlen_dense_waves") *value = t.varlen_dense_waves;
   else if (k == "attn_waves") *value = t.attn_waves;
   else if (k == "attn_splits") *value = t.attn_splits;
   else if (k == "swap_kernel_min_runs") *value = t.swap_kernel_min_runs;

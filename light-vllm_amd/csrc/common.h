@@ -44,6 +44,8 @@ struct Tuning {
                                     // slots cost the tiled kernel 17 us at any small size)
   int varlen_dense = 1;  // lvllm_varlen_attention: launches the 32x32 body takes read the caller's K / V rows
                          // themselves (row-major LDS images, transposed reads of V); 0: always the pack pass first
+  int varlen_dense_waves = 0;  // waves per workgroup of that launch: 8 (256 columns per tile stream), 4 (128), 0 = by
+                               // the longest sequence (4 up to 256 tokens, causal up to 512)
   int prefill_lds = 1;  // prefill kernel: K/V tiles staged once per workgroup in LDS (0: per-wave loads)
   int prefill_mfma32_min_query = 64;  // launches whose longest chunk has at least this many query tokens take the
                                       // 32x32-MFMA body (prefill_mfma32.h; plain, head size 64 / 128, 16-bit cache) --

@@ -100,8 +100,12 @@ __device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
 // (r & 3) + 8 * (r >> 2) + 4 * hi.
 typedef short i16x4_t __attribute__((ext_vector_type(4)));
 
-template <typename T, int D, int BS, bool DENSE = false>
-__global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const PrefillParams p, const ChunkScratch sc) {
+template <typename T, int D, int BS, bool DENSE = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const PrefillParams p, const ChunkScratch sc) {
+  // NW = waves per workgroup.  8: 256 columns share a tile stream.  4 (DENSE only): 128 columns, two workgroups per CU at
+  // the same two waves per SIMD -- the prologue and epilogue of one run under the tile loop of the other, and the two
+  // waves of a SIMD are no longer tied to one barrier; each wave copies twice as much of a tile.
+  static_assert(NW == 8 || (NW == 4 && DENSE), "4-wave workgroups: the dense twin only");
   using S = typename T::store_t;
   static_assert(sizeof(S) == 2, "16-bit element types");
   static_assert(BS == 16 || BS == 32, "block size 16 or 32");
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   constexpr int kStages = LVLLM_PREFILL32_STAGES;
   constexpr bool kPingPong = LVLLM_PREFILL32_PINGPONG != 0;
   static_assert(kStages >= (kPingPong ? 3 : 2), "stage count");
-  constexpr int kPiecesPerWave = D / 32;         // 1-KiB copies per wave and tile: 2 * kImage / 1024 / 8
+  constexpr int kPiecesPerWave = D / (4 * NW);   // 1-KiB copies per wave and tile: 2 * kImage / 1024 / NW
   constexpr int kPiecesPerSlice = kSlice / 1024;
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr float kMasked = -FLT_MAX;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 
   const int GP = 1 << p.gp_shift;    // heads per query token among the 32 columns (group size rounded up)
   const int TQW = 32 >> p.gp_shift;  // query tokens per wave
-  const int TQWG = 8 * TQW;
+  const int TQWG = NW * TQW;
   const int G = p.num_heads / p.num_kv_heads;
   const int HG = (G + 31) >> 5;
   const int kvh = blockIdx.x / HG;
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
 
   // ---- copies: wave w moves kPiecesPerWave KiB of every tile: K (w < 4) or V, all inside one block ----
   extern __shared__ __attribute__((aligned(16))) char kv_lds[];
-  const int ld_kind = wave >> 2;
-  const int ld_piece_first = (wave & 3) * kPiecesPerWave;
+  const int ld_kind = wave / (NW / 2);
+  const int ld_piece_first = (wave % (NW / 2)) * kPiecesPerWave;
   const int ld_blk = ld_piece_first / kPiecesPerSlice;     // block of the tile
   const int ld_piece0 = ld_piece_first % kPiecesPerSlice;  // first piece inside the block's slice
   // lane -> source offset inside a piece.  K: verbatim.  V, BS 16: piece = 32 rows of 32 bytes, lane i reads
@@ -229,8 +233,10 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
   // through registers: fetch(j) issues the loads of tile j, stash(j) writes them to tile j's stage (a block past
   // the walk reads as zeros through its zero-size descriptor)
   u32x4_t staged[kPiecesPerWave];
-  // DENSE: wave w copies rows 16 (w & 3) .. + 15 of the tile's K (w < 4) or V, a piece = kRowsPerPiece whole rows
-  const int dn_row = 16 * (wave & 3) + lane / kCPR, dn_c = lane % kCPR;
+  // DENSE: wave w copies rows 16 (w & 3) .. + 15 (8 waves; 32 (w & 1) .. + 31 with 4) of the tile's K (the first
+  // half of the waves) or V, a piece = kRowsPerPiece whole rows
+  const int dn_row = (128 / NW) * (wave % (NW / 2)) + lane / kCPR, dn_c = lane % kCPR;
+  static_assert(!DENSE || kPiecesPerWave * kRowsPerPiece == 128 / NW, "a wave's pieces are its share of the 64 rows");
   const int64_t dn_stride_b = (ld_kind ? p.dense_v_stride : p.dense_k_stride) * 2;
   const uint32_t dn_voff = (uint32_t)((int64_t)(qbeg + dn_row) * dn_stride_b + (int64_t)kvh * kRowB + dn_c * 16);
   auto fetch = [&](const int j, const int bn32) __attribute__((always_inline)) {
@@ -573,9 +579,9 @@ __global__ __launch_bounds__(512, 2) void paged_prefill_mfma32_kernel(const Pref
       }
     };
 #if LVLLM_PREFILL32_PRIO == 1
-    if (wave >> 2) __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise
+    if (wave / (NW / 2)) __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise
 #endif
-    if (LVLLM_PREFILL32_PINGPONG == 2 || (kPingPong && (wave >> 2) != 0)) run(std::true_type{});  // 2: diagnosis
+    if (LVLLM_PREFILL32_PINGPONG == 2 || (kPingPong && (wave / (NW / 2)) != 0)) run(std::true_type{});  // 2: diagnosis
     else run(std::false_type{});
     __builtin_amdgcn_s_waitcnt(0);  // no copy may still be landing when the workgroup's LDS is released
   }
@@ -634,7 +640,7 @@ struct Prefill32Plan {
   int64_t rows, ws_bytes;
 };
 inline Prefill32Plan prefill32_plan(int num_seqs, int max_query_len, int num_heads, int num_kv_heads, int head_size,
-                                    int max_seq_len) {
+                                    int max_seq_len, int waves = 8) {
   static const int num_cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -645,7 +651,7 @@ inline Prefill32Plan prefill32_plan(int num_seqs, int max_query_len, int num_hea
   const int G = num_heads / num_kv_heads;
   const int HG = (G + 31) / 32;
   pl.gp_shift = G == 1 ? 0 : G == 2 ? 1 : G <= 4 ? 2 : G <= 8 ? 3 : G <= 16 ? 4 : 5;
-  const int tqwg = 8 * (32 >> pl.gp_shift);
+  const int tqwg = waves * (32 >> pl.gp_shift);
   pl.qtiles = (max_query_len + tqwg - 1) / tqwg;
   pl.parts = 1;
   pl.rows = (int64_t)num_seqs * max_query_len * num_heads;
@@ -664,12 +670,12 @@ inline Prefill32Plan prefill32_plan(int num_seqs, int max_query_len, int num_hea
   return pl;
 }
 
-template <typename T, int D, int BS, bool DENSE>
+template <typename T, int D, int BS, bool DENSE, int NW = 8>
 static int launch_prefill_mfma32_impl(const PrefillParams& p0, int num_seqs, int max_query_len, hipStream_t stream) {
   PrefillParams p = p0;
   const int G = p.num_heads / p.num_kv_heads;
   const int HG = (G + 31) / 32;
-  const Prefill32Plan pl = prefill32_plan(num_seqs, max_query_len, p.num_heads, p.num_kv_heads, D, p.max_seq_len);
+  const Prefill32Plan pl = prefill32_plan(num_seqs, max_query_len, p.num_heads, p.num_kv_heads, D, p.max_seq_len, NW);
   p.gp_shift = pl.gp_shift;
   ChunkScratch sc{};
   sc.num_parts = 1;
@@ -677,10 +683,10 @@ static int launch_prefill_mfma32_impl(const PrefillParams& p0, int num_seqs, int
     sc = partition_scratch(p.workspace, pl.rows, pl.parts, pl.part_tokens, D);
   const dim3 grid(p.num_kv_heads * HG, num_seqs, pl.qtiles * sc.num_parts);
   const size_t smem = (size_t)LVLLM_PREFILL32_STAGES * 2 * D * 64 * 2;
-  auto kern = paged_prefill_mfma32_kernel<T, D, BS, DENSE>;
+  auto kern = paged_prefill_mfma32_kernel<T, D, BS, DENSE, NW>;
   if (smem > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, sc);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, stream, p, sc);
   if (sc.tmp_out != nullptr)
     launch_partition_reduce<T, D>(p, sc, num_seqs, max_query_len, stream);
 #if LVLLM_PREFILL32_STAMPS == 2
@@ -737,6 +743,13 @@ template <typename T>
 static int launch_prefill_mfma32_dense(const PrefillParams& p, int head_size, int num_seqs, int max_query_len,
                                        hipStream_t stream) {
   LV_CHECK(head_size == 64, "dense twin: head size 64");
+  // 4-wave workgroups (two per CU) where a workgroup walks few tiles and its prologue / epilogue weigh most:
+  // 128 x 128 tokens 45.5 -> 35.9 us, 32 x 512 causal 57 -> 52; level at 32 x 512 bidirectional, slower at 8 x 2 048
+  // (225 against 204: twice the K / V copies); profiles/r04_tuning.md, 12
+  int waves = tuning().varlen_dense_waves;
+  if (waves == 0) waves = (max_query_len <= 256 || (p.causal && max_query_len <= 512)) ? 4 : 8;
+  if (waves == 4)
+    return launch_prefill_mfma32_impl<T, 64, 16, true, 4>(p, num_seqs, max_query_len, stream);
   return launch_prefill_mfma32_impl<T, 64, 16, true>(p, num_seqs, max_query_len, stream);
 }
 

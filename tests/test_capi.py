@@ -82,7 +82,7 @@ def test_tuning_knobs_round_trip_through_the_abi():
 
     defaults = {b"gemm_workgroups": 256, b"attn_waves": 8, b"attn_splits": 0, b"swap_kernel_min_runs": 3,
                 b"cache_tile_min_tokens": 384, b"prefill_lds": 1, b"prefill_mfma32_min_query": 64,
-                b"gemm_partials_ksplit": 0, b"gemm_balance": 1, b"varlen_dense": 1}
+                b"gemm_partials_ksplit": 0, b"gemm_balance": 1, b"varlen_dense": 1, b"varlen_dense_waves": 0}
     for key, want in defaults.items():
         if os.environ.get("LVLLM_" + key.decode().upper()) is None:
             assert get(key) == want, key

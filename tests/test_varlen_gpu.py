@@ -87,8 +87,9 @@ def test_rows_read_in_place_equal_the_pack_pass_bit_for_bit(ops, dtype, causal, 
     q_d, k_d, v_d = (x[:T] for x in dq.split([H * D, KVH * D, KVH * D], dim=1))
     cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32)
     outs = []
-    for dense in (1, 0):
+    for dense, waves in ((1, 8), (0, 8), (1, 4)):  # (4 waves per workgroup: the other shape of the in-place launch)
         torch.ops._C_amd.set_tuning("varlen_dense", dense)
+        torch.ops._C_amd.set_tuning("varlen_dense_waves", waves)
         try:
             out = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
             ops.varlen_attention(out, q_d.view(T, H, D), k_d.view(T, KVH, D), v_d.view(T, KVH, D), cu.to(DEV),
@@ -96,9 +97,11 @@ def test_rows_read_in_place_equal_the_pack_pass_bit_for_bit(ops, dtype, causal, 
             torch.cuda.synchronize()
         finally:
             torch.ops._C_amd.set_tuning("varlen_dense", 1)
+            torch.ops._C_amd.set_tuning("varlen_dense_waves", 0)
         outs.append(out.cpu())
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
     q, k, v = (x[:T] for x in qkv.split([H * D, KVH * D, KVH * D], dim=1))
     want = torch.zeros(T, H, D, dtype=dtype)
     oracle.varlen_attention(want, q.reshape(T, H, D), k.reshape(T, KVH, D), v.reshape(T, KVH, D), cu, D ** -0.5,
