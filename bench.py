@@ -168,16 +168,24 @@ def kernel_leg(engine, B, iters, seq_len=None):
     # HIP events on the launch stream around TRAINS of back-to-back launches, one layer's cache per
     # launch: the per-launch average then carries the kernel and its launch gap, not the cost of
     # recording two events per kernel (which added ~3 us to a 24 us kernel and made the figure
-    # disagree with rocprof's duration of the same kernel)
+    # disagree with rocprof's duration of the same kernel).  A train is a captured graph of its launches, as in the
+    # in-step leg: issued one by one from Python (a ctypes call of 35 arguments each) the train is only as fast as
+    # the host on a busy box -- one run of round 4 read 27.3 us average against 23.4 minimum for that reason.
     train = len(caches)
     ntrains = max(2, iters // train)
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(train):
+                launch(k, 1)
+    torch.cuda.synchronize(dev)
+    graph.replay()
+    torch.cuda.synchronize(dev)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ntrains)]
-    k = 0
     for a, b in evs:
         a.record()
-        for _ in range(train):
-            launch(k, 1)
-            k += 1
+        graph.replay()
         b.record()
     torch.cuda.synchronize(dev)
     ts = [a.elapsed_time(b) * 1e-3 / train for a, b in evs]  # seconds per launch
@@ -316,13 +324,24 @@ def gemm_leg(engine, B):
             for w in ws[:4]:
                 call(w)
             torch.cuda.synchronize(dev)
+            # (a train = a captured graph of one launch per layer, as in the attention legs: the host's dispatch of 32
+            # operator calls is not in the figure)
+            side = torch.cuda.Stream(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for w in ws:
+                        call(w)
+            torch.cuda.synchronize(dev)
+            graph.replay()
+            torch.cuda.synchronize(dev)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
             for a, b in evs:
                 a.record()
-                for w in ws:
-                    call(w)
+                graph.replay()
                 b.record()
             torch.cuda.synchronize(dev)
+            del graph
             t = min(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(ws)
             by = N * K * (1 if w8 else 2) + B * K * (1 if once else 2) + B * N * 2  # weights once + activations in + result out
             if glu:
