@@ -751,10 +751,12 @@ def chunked_prefill_leg(a, dev, num_prompts=1000, input_len=512, output_len=512,
     return out
 
 
-def encode_only_leg(a, dev, num_prompts=512, length=512, max_num_seqs=32):
+def encode_only_leg(a, dev, num_prompts=4096, length=512, max_num_seqs=32):
     """BASELINE config 4 beside the headline: bge-m3 shapes (XLM-RoBERTa-large: 24 layers, hidden 1024, 16 heads of
     64) through the prefill-only engine (light_vllm.encode_only workflow: varlen bidirectional attention + the fused
-    add + LayerNorm / GELU kernels, library GEMMs), two steps in flight, dense (CLS) embeddings out.  MFMA-bound:
+    add + LayerNorm / GELU kernels, library GEMMs), two steps in flight, dense (CLS) embeddings out.  4 096 prompts =
+    128 steps = 1.4 s (the reference's benchmarks/benchmark_bge-m3.py:89-100 runs 10 000; rounds 2 - 4 quoted 512 = 16
+    steps, a 0.19 s region that moved +-3 % between runs and in which the pipeline's fill and drain weigh 5 %).  MFMA-bound:
     FLOPs = tokens x (2 x layer weights + 4 x length x hidden per layer)."""
     from light_vllm_amd.prefill_only import PrefillOnlySchedulerConfig
     from light_vllm_amd.prefill_only.engine import PrefillOnlyEngine
