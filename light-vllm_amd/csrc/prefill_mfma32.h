@@ -59,6 +59,9 @@
 #define LVLLM_PREFILL32_GROW 6  // log2 of the growth of a column maximum that forces a rescale
 #endif
 
+#ifndef LVLLM_PREFILL32_PAIRS
+#define LVLLM_PREFILL32_PAIRS 1  // the main loop runs two tiles per trip (stage = compile-time constant); 0: one
+#endif
 #ifndef LVLLM_PREFILL32_STAMPS
 #define LVLLM_PREFILL32_STAMPS 0  // diagnosis builds: 1 = s_memtime at the phase boundaries of one workgroup (tools/stamps_prefill32.py);
                                   // 2 = also start / first barrier / loop end / exit of EVERY workgroup (tools/wg_timeline_prefill32.py)
@@ -264,9 +267,15 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
   // past the sequence is replaced, not used.
   // This lane's 16 bytes of a V piece are 8 consecutive tokens of one row, starting at ld_tok0 of the tile.
   const int ld_tok0 = ld_blk * BS + (BS == 16 ? (lane >> 5) : (lane >> 4)) * 8;
-  auto stash = [&](const int j) __attribute__((always_inline)) {
+  // The stage of tile j: with two stages, (j - j0) & 1 -- the main loop runs two tiles per trip, and a tile's stage is
+  // a compile-time constant there: every fragment address is a loop-invariant register plus an immediate (the dense
+  // images have ten distinct swizzled bases; adding the stage to each cost 43 vector instructions per tile).
+  auto stage_off = [&](const int j) __attribute__((always_inline)) -> int {
+    return (kStages == 2 ? ((j - j0) & 1) : (j % kStages)) * kStage;
+  };
+  auto stash = [&](const int j, const int so) __attribute__((always_inline)) {
     if constexpr (DENSE) {
-      char* st = kv_lds + (j % kStages) * kStage + ld_kind * kImage;
+      char* st = kv_lds + so + ld_kind * kImage;
       const bool tail = ld_kind == 1 && j * KT + KT > seq_len;  // (wave-uniform) a lane's 16 bytes are one token's
 #pragma unroll
       for (int i = 0; i < kPiecesPerWave; ++i) {
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
       }
       return;
     }
-    char* dst = kv_lds + (j % kStages) * kStage + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024 + lane * 16;
+    char* dst = kv_lds + so + ld_kind * kImage + ld_blk * kSlice + ld_piece0 * 1024 + lane * 16;
     if (ld_kind == 1 && j * KT + KT > seq_len) {  // (wave-uniform; the copy registers themselves are never modified)
       const int nvalid = seq_len - (j * KT + ld_tok0);  // <= 0: none, >= 8: all
       uint32_t m[4];
@@ -356,8 +365,8 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
     }
     return *reinterpret_cast<const u32x4_t*>(st + voff(i >> 2, i & 3));
   };
-  auto qk = [&](const int j, f32x16_t (&s)[2]) __attribute__((always_inline)) {
-    const char* st = kv_lds + (j % kStages) * kStage;
+  auto qk = [&](const int so, f32x16_t (&s)[2]) __attribute__((always_inline)) {
+    const char* st = kv_lds + so;
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);  // MFMA phases win the issue arbitration
     u32x4_t kw[kWinK];
 #pragma unroll
@@ -377,8 +386,8 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
     }
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
   };
-  auto vpre = [&](const int j, u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
-    const char* st = kv_lds + (j % kStages) * kStage;
+  auto vpre = [&](const int so, u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
+    const char* st = kv_lds + so;
 #pragma unroll
     for (int i = 0; i < kWin; ++i) vw[i] = vread(st, i);
   };
@@ -483,8 +492,8 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
     __builtin_amdgcn_sched_barrier(0);
   };
   // O^T += V^T.P^T
-  auto pv = [&](const int j, const u32x4_t (&pb)[4], u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
-    const char* st = kv_lds + (j % kStages) * kStage;
+  auto pv = [&](const int so, const u32x4_t (&pb)[4], u32x4_t (&vw)[kWin]) __attribute__((always_inline)) {
+    const char* st = kv_lds + so;
     static_assert(NV >= kWin, "the window is at most one tile of V");
     if constexpr (LVLLM_PREFILL32_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
     // has left behind before the barrier of tile j.
     if constexpr (!DENSE) load_block_chunk(j0 >> 6, ld_blk);
     fetch(j0, DENSE ? 0 : block_of_tile(j0));
-    stash(j0);
+    stash(j0, 0);
 #if LVLLM_PREFILL32_STAMPS
     // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
     const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 8 && lane == 0;
@@ -548,32 +557,63 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
       constexpr bool late = decltype(late_tag)::value;
       if constexpr (late) publish(j0);
       int j = j0;
+      if constexpr (!late && kStages == 2 && LVLLM_PREFILL32_PAIRS) {
+        auto tile = [&](const int jt, auto so_tag) __attribute__((always_inline)) {
+          constexpr int so = decltype(so_tag)::value;
+          stamp(jt, 0);
+          publish(jt);
+          stamp(jt, 1);
+          f32x16_t s[2];
+          u32x4_t pb[4], vw[kWin];
+          qk(so, s);
+          stamp(jt, 2);
+          stamp(jt, 3);
+          vpre(so, vw);  // the first window of V: in flight during the softmax
+          __builtin_amdgcn_sched_barrier(0);
+          softmax(jt, s, pb, jt >= n_plain);
+          stamp(jt, 4);
+          stash(jt + 1, kStage - so);
+          pv(so, pb, vw);
+          stamp(jt, 5);
+        };
 #pragma nounroll
-      for (; j < my_ntiles; ++j) {
-        stamp(j, 0);
-        if constexpr (!late) publish(j);
-        stamp(j, 1);
-        f32x16_t s[2];
-        u32x4_t pb[4], vw[kWin];
-        qk(j, s);
-        stamp(j, 2);
-        if constexpr (late) {
-          stash(j + 1);
-          if (j + 1 < ntiles) publish(j + 1);
+        for (; j + 1 < my_ntiles; j += 2) {
+          tile(j, std::integral_constant<int, 0>{});
+          tile(j + 1, std::integral_constant<int, kStage>{});
         }
-        stamp(j, 3);
-        vpre(j, vw);  // the first window of V: in flight during the softmax
-        __builtin_amdgcn_sched_barrier(0);
-        softmax(j, s, pb, j >= n_plain);
-        stamp(j, 4);
-        if constexpr (!late) stash(j + 1);
-        pv(j, pb, vw);
-        stamp(j, 5);
+        if (j < my_ntiles) {
+          tile(j, std::integral_constant<int, 0>{});
+          ++j;
+        }
+      } else {
+#pragma nounroll
+        for (; j < my_ntiles; ++j) {
+          const int so = stage_off(j);
+          stamp(j, 0);
+          if constexpr (!late) publish(j);
+          stamp(j, 1);
+          f32x16_t s[2];
+          u32x4_t pb[4], vw[kWin];
+          qk(so, s);
+          stamp(j, 2);
+          if constexpr (late) {
+            stash(j + 1, stage_off(j + 1));
+            if (j + 1 < ntiles) publish(j + 1);
+          }
+          stamp(j, 3);
+          vpre(so, vw);  // the first window of V: in flight during the softmax
+          __builtin_amdgcn_sched_barrier(0);
+          softmax(j, s, pb, j >= n_plain);
+          stamp(j, 4);
+          if constexpr (!late) stash(j + 1, stage_off(j + 1));
+          pv(so, pb, vw);
+          stamp(j, 5);
+        }
       }
 #pragma nounroll
       for (j = max(j, j0); j < ntiles; ++j) {  // tiles this wave copies for the others
         if constexpr (!late) publish(j);
-        stash(j + 1);
+        stash(j + 1, stage_off(j + 1));
         if constexpr (late)
           if (j + 1 < ntiles) publish(j + 1);
       }
