@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--no-qkv-reduce-in-rope", action="store_true",
                     help="A/B: the QKV projection of a mixed step keeps its own reduce launch (round 3's path)")
+    ap.add_argument("--gemm-workgroups", type=int, default=None,
+                    help="A/B: SchedulerConfig.gemm_workgroups (default: 128 at two steps in flight)")
     a = ap.parse_args()
     dev = "cuda:0"
     cfg = ModelConfig.tiny() if a.tiny else ModelConfig.llama3_8b()
@@ -37,7 +39,8 @@ def main():
     eng = LLMEngine(cfg, CacheConfig(block_size=bs, num_gpu_blocks=blocks, num_cpu_blocks=0),
                     SchedulerConfig(max_num_batched_tokens=a.budget, max_num_seqs=a.budget,
                                     max_model_len=(max_len + 511) // 512 * 512, scheduling=a.scheduling,
-                                    max_num_on_the_fly=2, chunked_prefill_enabled=True),
+                                    max_num_on_the_fly=2, chunked_prefill_enabled=True,
+                                    gemm_workgroups=a.gemm_workgroups),
                     device=dev, use_hip_graph=True)
     eng.step_returns_outputs = False
     g = torch.Generator().manual_seed(0)
