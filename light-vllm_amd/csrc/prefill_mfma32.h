@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 2) void paged_prefill_mfma32_kernel(const 
     // has left behind before the barrier of tile j.
     if constexpr (!DENSE) load_block_chunk(j0 >> 6, ld_blk);
     fetch(j0, DENSE ? 0 : block_of_tile(j0));
-    stash(j0, 0);
+    stash(j0, stage_off(j0));
 #if LVLLM_PREFILL32_STAMPS
     // workgroup (0, 0, the 9th heaviest): every wave stamps the boundaries of its phases in tiles 8 .. 8 + kStampTiles
     const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 8 && lane == 0;
