@@ -880,7 +880,7 @@ def main():
     reps = a.repeats if a.repeats > 0 else max(1, min(5, 100 // max(1, a.steps)))
     total_steps = a.steps * reps + a.warmup
     reps_extra = min(reps, 3)  # regions of the more-in-flight leg (median reported, like the headline's)
-    max_len = ctx + total_steps // on_the_fly + (a.steps * reps_extra + 2 * k) // max(1, slots) + 2 * k_max + 8
+    max_len = ctx + total_steps // on_the_fly + ((a.steps + 3 * k_max) * reps_extra + 2 * k) // max(1, slots) + 2 * k_max + 8
     max_model_len = (max_len + 511) // 512 * 512
     bs = 16
     blocks = B * slots * ((max_len + bs - 1) // bs + 1) + 64
@@ -963,24 +963,28 @@ def main():
             engine.add_request(str(i), prompt, max_tokens=2 * total_steps + 100)
         engine.prefill_synthetic(seed=rank + 1000)
         run(k * extra, k, in_flight=extra)
+        # whole rounds of `extra` bursts: a region whose burst count is not a multiple of the pipeline depth ends with
+        # bursts that run alone at the single-stream rate (20 steps = 4 bursts of 5 at three in flight read 9.1 k
+        # against 9.6 k at two for that reason alone, profiles/r04_tuning.md section 4)
+        steps_x = max(1, a.steps // (k * extra)) * (k * extra)
         regions_x = []
         for _ in range(reps_extra):
             torch.cuda.synchronize(dev)
             group.barrier()
             t1 = time.perf_counter()
-            tok2 = run(a.steps, k, in_flight=extra)
+            tok2 = run(steps_x, k, in_flight=extra)
             torch.cuda.synchronize(dev)
             group.barrier()
             el2 = group.max(time.perf_counter() - t1)
             regions_x.append((group.sum(tok2) / el2, el2))
         v2, el2 = sorted(regions_x)[len(regions_x) // 2]
         other[f"max_num_on_the_fly={extra}"] = {"value": round(v2, 1), "unit": "tokens/s",
-                                                "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                                                "ms_per_step": round(el2 / steps_x * 1e3, 4), "steps": steps_x,
                                                 "sequences_resident": B * extra,
                                                 "regions_tokens_per_s": [round(v, 1) for v, _ in regions_x],
-                                                "note": "a region is --steps model steps = steps / burst engine steps "
-                                                        "with an empty pipeline on both sides: the fewer bursts a region "
-                                                        "has, the more the fill and drain of a deeper pipeline weigh"}
+                                                "note": "regions of whole rounds of bursts (steps = a multiple of burst x "
+                                                        "steps in flight): a region that ends with fewer bursts than the "
+                                                        "pipeline is deep runs them at the single-stream rate"}
     kl = kernel_leg(engine, B, a.kernel_iters, seq_len=ctx)
     in_step = in_step_attention_leg(engine, B, ctx) if rank == 0 else None
     gm = gemm_leg(engine, B) if B <= 64 else None
