@@ -30,6 +30,9 @@ class RequestOutput:
     token_ids: List[int]
     finished: bool
     finish_reason: Optional[str] = None
+    # SamplingParams.logprobs: per output token {token id: (logprob, rank)} -- the sampled token and the n most
+    # likely ones (the reference's SampleLogprobs, sequence.py Logprob(logprob, rank)); None when not asked for
+    logprobs: Optional[List[dict]] = None
 
 
 @dataclass
@@ -39,6 +42,7 @@ class ExecuteOutput:
     execute_begin_ts: float = 0.0
     execute_end_ts: float = 0.0
     num_steps: int = 1  # model steps this result covers (multi-step decode)
+    logprobs: Optional[List[Optional[dict]]] = None  # per sampled row (sampling.sample_logprobs), rows that asked
 
 
 class Worker:
@@ -210,10 +214,14 @@ class Worker:
         return (t.pin_memory() if self.device.type == "cuda" else t).to(self.device, non_blocking=True)
 
     @torch.inference_mode()
-    def execute(self, execute_input: ExecuteInput, slot: int = 0, state_slots=None) -> ExecuteOutput:
+    def execute(self, execute_input: ExecuteInput, slot: int = 0, state_slots=None, logprob_rows=None) -> ExecuteOutput:
         """`state_slots`: {seq id: sampler state slot} for a step in which some request is not plain greedy (None:
         all plain greedy): the step's logits then go through the device sampler (one launch: penalties, temperature,
-        top-k / top-p / min-p, the draw; rows without a slot take the arg-max)."""
+        top-k / top-p / min-p, the draw; rows without a slot take the arg-max).
+        `logprob_rows`: {seq id: dict(params, prompt, output, eos)} for a step in which some request asks for
+        log-probabilities (SamplingParams.logprobs): the step takes the general path, the adjusted logits of its
+        sampled rows are restated in torch (sampling.SamplingBatch: the stages the device sampler applies) and the
+        sample half of the reference's get_logprobs is read off them (sampler.py:726-990)."""
         wi, mi = execute_input.worker_input, execute_input.model_input
         ce = self.cache_engine
         if wi.blocks_to_swap_in.numel() > 0:
@@ -227,6 +235,8 @@ class Worker:
         md = mi.attn_metadata
         graphs = self.graph_pools[slot] if self.graph_pools is not None else None
         row_slots = None if state_slots is None else [state_slots.get(sid, -1) for sid in mi.sample_seq_ids]
+        if logprob_rows is not None:
+            graphs = None
         if graphs is not None and mi.decode_only and md.block_tables.shape[1] <= graphs.max_blocks_per_seq:
             n = mi.input_tokens.shape[0]
             g = graphs.get(n, sampler=self.sampler if row_slots is not None else None)
@@ -257,10 +267,23 @@ class Worker:
             logits = self.model.compute_logits(hidden)
             if self.capture_logits:
                 self.last_logits = logits.float().cpu()
+            lps = None
+            if logprob_rows is not None and logits.shape[0] > 0:  # before the draw: the sampler appends what it draws
+                from ..sampling import SamplingBatch
+                rows = [logprob_rows.get(sid) or dict(params=None, prompt=(), output=(), eos=None)
+                        for sid in mi.sample_seq_ids]
+                lps = SamplingBatch(rows, logits.shape[1], self.device).logprobs(logits)
             if row_slots is None or logits.shape[0] == 0:
                 tokens = torch.argmax(logits, dim=-1)
             else:
                 tokens = self.sampler.sample(logits, self._slots_tensor(row_slots))
+            if lps is not None:
+                from ..sampling import sample_logprobs
+                nums = [logprob_rows[sid]["params"].logprobs if sid in logprob_rows else None
+                        for sid in mi.sample_seq_ids]
+                out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
+                out.copy_(tokens, non_blocking=True)
+                return ExecuteOutput(out, mi.sample_seq_ids, logprobs=sample_logprobs(lps, tokens, nums))
         out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, mi.sample_seq_ids)
@@ -481,6 +504,7 @@ class LLMEngine:
             return self._process_burst(sched, out)
         sampled = out.sampled.tolist() if out.sampled is not None else []
         tok_of = dict(zip(out.sample_seq_ids, sampled))
+        lp_of = dict(zip(out.sample_seq_ids, out.logprobs)) if out.logprobs is not None else None
         self.stat_model_steps += 1 if sched.scheduled_seq_groups else 0
         self.stat_tokens_appended += len(sampled)
         results: List[RequestOutput] = []
@@ -493,7 +517,12 @@ class LLMEngine:
                 seq = seqs[0]
                 seq.data.update_num_computed_tokens(s.token_chunk_size)
                 tok = tok_of[seq.seq_id]
-                seq.append_token_id(tok, 0.0)
+                lp = lp_of.get(seq.seq_id) if lp_of is not None else None
+                if lp is not None:
+                    seq.output_logprobs.append(lp)
+                    seq.append_token_id(tok, lp[tok][0])
+                else:
+                    seq.append_token_id(tok, 0.0)
                 sp = g.sampling_params
                 if ((self.eos_token_id is not None and tok == self.eos_token_id and not (sp is not None and sp.ignore_eos))
                         or (sp is not None and tok in sp.stop_token_ids)):
@@ -507,7 +536,8 @@ class LLMEngine:
                     self.scheduler.free_seq(seq)
                 if self.step_returns_outputs:
                     results.append(RequestOutput(g.request_id, list(seq.get_output_token_ids()), finished,
-                                                 SequenceStatus.get_finished_reason(seq.status)))
+                                                 SequenceStatus.get_finished_reason(seq.status),
+                                                 list(seq.output_logprobs) if seq.output_logprobs else None))
                 else:
                     results.append(RequestOutput(g.request_id, [], finished))
                 continue
@@ -516,7 +546,12 @@ class LLMEngine:
                 if seq.seq_id not in tok_of:
                     continue  # a prompt chunk that sampled nothing
                 tok = tok_of[seq.seq_id]
-                seq.append_token_id(tok, 0.0)
+                lp = lp_of.get(seq.seq_id) if lp_of is not None else None
+                if lp is not None:
+                    seq.output_logprobs.append(lp)
+                    seq.append_token_id(tok, lp[tok][0])
+                else:
+                    seq.append_token_id(tok, 0.0)
                 sp = g.sampling_params
                 if ((self.eos_token_id is not None and tok == self.eos_token_id and not (sp is not None and sp.ignore_eos))
                         or (sp is not None and tok in sp.stop_token_ids)):
@@ -530,7 +565,8 @@ class LLMEngine:
             if self.step_returns_outputs:
                 seq0 = g.seqs[0]
                 results.append(RequestOutput(g.request_id, list(seq0.get_output_token_ids()), g.is_finished(),
-                                             SequenceStatus.get_finished_reason(seq0.status)))
+                                             SequenceStatus.get_finished_reason(seq0.status),
+                                             list(seq0.output_logprobs) if seq0.output_logprobs else None))
             else:
                 results.append(RequestOutput(g.request_id, [], g.is_finished()))
         for g in sched.ignored_seq_groups:
@@ -568,6 +604,10 @@ class LLMEngine:
         other step through the general input builder.  Steps with requests that are not plain greedy carry their
         sampler state slots along and stay on the same paths (fast decode inputs, multi-step bursts included)."""
         state_slots = self._sampler_slots(sched)
+        logprob_rows = self._logprob_rows(sched)
+        if logprob_rows is not None:  # the general path, one model step (the reference's multi-step has none either)
+            return self.worker.execute(self.input_builder(sched), slot, state_slots=state_slots,
+                                       logprob_rows=logprob_rows)
         if self.fast_decode_inputs:
             from .input_builder import DecodeStepArrays, MixedStepArrays
             plain = not (sched.blocks_to_swap_in or sched.blocks_to_swap_out or sched.blocks_to_copy)
@@ -582,6 +622,21 @@ class LLMEngine:
                 if out is not None:
                     return out
         return self.worker.execute(self.input_builder(sched), slot, state_slots=state_slots)
+
+    def _logprob_rows(self, sched: SchedulerOutput) -> Optional[Dict[int, dict]]:
+        """None unless some request of the step asks for log-probabilities; then, per running sequence of such a
+        request, what sampling.SamplingBatch needs to restate its adjusted logits."""
+        rows: Dict[int, dict] = {}
+        for s in sched.scheduled_seq_groups:
+            g = s.seq_group
+            sp = g.sampling_params
+            if sp is None or sp.logprobs is None:
+                continue
+            for seq in g.seqs:
+                if seq.status == SequenceStatus.RUNNING:
+                    rows[seq.seq_id] = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(),
+                                            eos=self.eos_token_id)
+        return rows or None
 
     def _sampler_slots(self, sched: SchedulerOutput) -> Optional[Dict[int, int]]:
         """None when every request of the step is plain greedy (the captured arg-max serves it); otherwise

@@ -24,6 +24,8 @@ class SamplingParams:
     ignore_eos: bool = False
     max_tokens: Optional[int] = 16
     min_tokens: int = 0
+    logprobs: Optional[int] = None         # log-probabilities of the sampled token and of the n most likely ones
+    prompt_logprobs: Optional[int] = None  # (accepted for the signature; not computed: ValueError when set)
 
     def __post_init__(self) -> None:  # sampling_params.py:_verify_args
         if not -2.0 <= self.presence_penalty <= 2.0:
@@ -44,6 +46,10 @@ class SamplingParams:
             raise ValueError(f"max_tokens must be at least 1, got {self.max_tokens}.")
         if self.min_tokens < 0:
             raise ValueError(f"min_tokens must be greater than or equal to 0, got {self.min_tokens}.")
+        if self.logprobs is not None and self.logprobs < 0:
+            raise ValueError(f"logprobs must be non-negative, got {self.logprobs}.")
+        if self.prompt_logprobs is not None:
+            raise ValueError("prompt_logprobs is not supported by this engine (sample logprobs are: `logprobs`).")
         if self.temperature < _SAMPLING_EPS:  # zero temperature means greedy sampling (sampling_params.py:320-326)
             self.top_p, self.top_k, self.min_p = 1.0, -1, 0.0
 

@@ -123,6 +123,7 @@ class Sequence:
         self.data = SequenceData(prompt_token_ids)
         self.status = SequenceStatus.WAITING
         self.stop_reason = None
+        self.output_logprobs: List[dict] = []  # one {token id: (logprob, rank)} per output token when asked for
 
     @property
     def n_blocks(self) -> int:

@@ -129,7 +129,8 @@ class SamplingBatch:
         self.banned = [(i, t) for i, (p, r) in enumerate(zip(ps, rows)) if p.min_tokens > len(r["output"])
                        for t in set(p.stop_token_ids) | ({r["eos"]} if r.get("eos") is not None and not p.ignore_eos else set())]
 
-    def sample(self, logits: torch.Tensor) -> torch.Tensor:
+    def penalised(self, logits: torch.Tensor) -> torch.Tensor:
+        """The logits after the min-tokens mask and the penalties (what a greedy row takes its arg-max of)."""
         assert logits.shape[0] == self.n
         x = logits.float()
         if self.banned:
@@ -137,15 +138,31 @@ class SamplingBatch:
             x[list(rows), list(toks)] = float("-inf")
         if self.do_penalties:
             x = apply_penalties(x, self.prompt, self.output, self.presence, self.frequency, self.repetition)
-        greedy = greedy_sample(x)
+        return x
+
+    def shaped(self, x: torch.Tensor) -> torch.Tensor:
+        """Temperature, top-k / top-p and min-p on penalised logits: what the softmax of Sampler.forward sees
+        (sampler.py:158-176) -- the probabilities the draw uses and the log-probabilities `get_logprobs` reports."""
         if self.all_greedy:
-            return greedy
+            return x
         t = torch.where(self.temperature >= _SAMPLING_EPS, self.temperature, torch.ones_like(self.temperature))
         x = x / t[:, None]
         if self.do_top:
             x = apply_top_k_top_p(x, self.top_p, self.top_k)
         if self.do_min_p:
             x = apply_min_p(x, self.min_p)
+        return x
+
+    def logprobs(self, logits: torch.Tensor) -> torch.Tensor:
+        """log_softmax of the adjusted logits, fp32 (sampler.py:178-180)."""
+        return torch.log_softmax(self.shaped(self.penalised(logits)), dim=-1, dtype=torch.float)
+
+    def sample(self, logits: torch.Tensor) -> torch.Tensor:
+        x = self.penalised(logits)
+        greedy = greedy_sample(x)
+        if self.all_greedy:
+            return greedy
+        x = self.shaped(x)
         probs = torch.softmax(x, dim=-1)
         drawn = random_sample(probs, self.generator)
         for i, seed in enumerate(self.seeds):  # a seeded request draws from its own stream (sampler.py:479-493)
@@ -158,3 +175,32 @@ class SamplingBatch:
 
     def _step_of(self, i: int) -> int:
         return self._steps[i] if hasattr(self, "_steps") else 0
+
+
+
+def sample_logprobs(logprobs: torch.Tensor, tokens: torch.Tensor, nums: List[Optional[int]]) -> List[Optional[dict]]:
+    """The sample half of get_logprobs (sampler.py:726-990) for one sampled token per row: row i with nums[i] = n
+    (SamplingParams.logprobs) gets {sampled token: (logprob, rank)} updated with its n most likely tokens
+    {token: (logprob, 1 .. n)}; rank = 1 + the number of strictly larger log-probabilities of the row (_get_ranks,
+    sampler.py:705-723).  Rows with nums[i] None get None.  One top-k of the largest n for the whole batch, as there."""
+    rows = [i for i, n in enumerate(nums) if n is not None]
+    out: List[Optional[dict]] = [None] * len(nums)
+    if not rows:
+        return out
+    idx = torch.tensor(rows, dtype=torch.long, device=logprobs.device)
+    lp = logprobs.index_select(0, idx)
+    tok = tokens.to(lp.device).long().index_select(0, idx)
+    sel = lp.gather(1, tok[:, None])[:, 0]
+    ranks = (lp > sel[:, None]).sum(1).add_(1)
+    largest = max(nums[i] for i in rows)
+    sel_l, rank_l, tok_l = sel.tolist(), ranks.tolist(), tok.tolist()
+    if largest > 0:
+        top_lp, top_id = torch.topk(lp, min(largest, lp.shape[1]), dim=-1)
+        top_lp, top_id = top_lp.tolist(), top_id.tolist()
+    for j, i in enumerate(rows):
+        d = {tok_l[j]: (sel_l[j], rank_l[j])}
+        n = min(nums[i], lp.shape[1])
+        if n > 0:
+            d.update({t: (v, r) for t, v, r in zip(top_id[j][:n], top_lp[j][:n], range(1, n + 1))})
+        out[i] = d
+    return out

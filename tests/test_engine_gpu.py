@@ -771,3 +771,74 @@ def test_sampler_state_is_rebuilt_after_eviction():
     roomy, none = run(64)
     assert tight == roomy and none == 0
     print("sampler slots evicted:", evicted)
+
+
+@pytest.mark.parametrize("scheduling", ["sync", "async"])
+def test_requests_that_ask_for_logprobs_get_the_reference_dictionaries(scheduling):
+    """SamplingParams.logprobs (sampler.py:726-990, the sample half): a step with such a request takes the general path
+    and returns, per output token, {sampled token: (logprob, rank)} + the n most likely tokens at ranks 1 .. n, read off
+    the log_softmax of the step's adjusted logits.  Checked here: tokens are the ones the same requests produce without
+    the option (greedy rows and a seeded sampled row), greedy rows' dictionaries equal log_softmax of the step's captured
+    logits, a sampled row's dictionary lives on its top-k support, rows that did not ask get nothing, and the other
+    requests of the batch stay on their tokens."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    ps = prompts()
+
+    def params(with_lp):
+        lp = (lambda n: n) if with_lp else (lambda n: None)
+        return [SamplingParams(temperature=0.0, max_tokens=6, logprobs=lp(3)),
+                None,
+                SamplingParams(temperature=0.8, top_k=5, seed=11, max_tokens=6, logprobs=lp(2)),
+                SamplingParams(temperature=0.0, repetition_penalty=1.3, max_tokens=6, logprobs=lp(0)),
+                None,
+                SamplingParams(temperature=0.0, max_tokens=6)]
+
+    def run(with_lp):
+        e = make_engine(graph=False, scheduling=scheduling)
+        e.worker.capture_logits = True
+        for i, (p, sp) in enumerate(zip(ps, params(with_lp))):
+            e.add_request(str(i), p, max_tokens=6, sampling_params=sp)
+        final, rows = {}, {str(i): [] for i in range(len(ps))}
+        step = e.async_step if scheduling == "async" else e.step
+        for _ in range(1000):
+            outs = step()
+            if scheduling == "sync" and outs:
+                lg = e.worker.last_logits
+                assert lg.shape[0] == len(outs)
+                for row, o in zip(lg, outs):
+                    rows[o.request_id].append(row)
+            for o in outs:
+                final[o.request_id] = o
+            if not e.has_unfinished_requests() and e.num_on_the_fly == 0:
+                break
+        e.shutdown()
+        return final, rows
+
+    base, _ = run(False)
+    got, rows = run(True)
+    for i in range(len(ps)):
+        assert got[str(i)].token_ids == base[str(i)].token_ids, i  # the option changes no token
+    for i in (1, 4, 5):
+        assert got[str(i)].logprobs is None
+    for i, n in ((0, 3), (2, 2), (3, 0)):
+        o = got[str(i)]
+        assert len(o.logprobs) == len(o.token_ids) == 6
+        for j, (tok, d) in enumerate(zip(o.token_ids, o.logprobs)):
+            assert tok in d and n <= len(d) <= n + 1
+            lp, rank = d[tok]
+            assert lp <= 0.0 and rank >= 1 and math.isfinite(lp)
+            ranks = sorted(r for _, r in d.values())
+            assert ranks[:n] == list(range(1, n + 1)) or (n == 0 and len(ranks) == 1)
+            if i == 0:
+                # greedy without penalties: no token is more likely than the sampled one (bf16 logits of the tiny model
+                # tie now and then: the top-n entry then overrides the sampled token's rank, as in the reference)
+                assert lp == max(v for v, _ in d.values())
+            if i == 2:
+                assert rank <= 5  # inside its top-k support
+            if scheduling == "sync" and i == 0:  # against log_softmax of the step's own logits
+                want = torch.log_softmax(rows["0"][j].float(), -1)
+                assert abs(lp - float(want[tok])) <= 1e-4
+                top = torch.topk(want, 3)  # (values, not ids: tied logits may enter the top three in another order)
+                by_rank = sorted((r, v) for v, r in d.values() if r <= 3)[:3]
+                for (r, v), val in zip(by_rank, top.values.tolist()):
+                    assert abs(v - val) <= 1e-4

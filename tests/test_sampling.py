@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import light_vllm_amd  # noqa: F401
@@ -133,3 +134,67 @@ def test_the_draw_uniform_is_strictly_inside_the_unit_interval():
     assert (q > 0).all() and np.isfinite(np.log(q)).all()
     old = ((r >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
     assert old.max() == np.float32(1.0)
+
+
+def test_sample_logprobs_follow_the_reference_rank_and_top_n():
+    """The sample half of get_logprobs (sampler.py:726-990): {sampled token: (logprob, rank)} updated with the n most
+    likely tokens at ranks 1 .. n; rank = 1 + the number of strictly larger log-probabilities (the reference's own
+    _get_ranks, imported where the reference is present); rows that did not ask get None; one request with n = 0 gets
+    the sampled token alone."""
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(6, 97, generator=g)
+    logits[2, 10] = logits[2, 11] = logits[2].max() + 1.0  # a tie at the top: both "rank 1"
+    lp = torch.log_softmax(logits, dim=-1)
+    toks = torch.tensor([3, 96, 11, 0, 50, 7])
+    nums = [5, None, 2, 0, 1, None]
+    got = sampling.sample_logprobs(lp, toks, nums)
+    assert got[1] is None and got[5] is None
+    for i, n in enumerate(nums):
+        if n is None:
+            continue
+        d, t = got[i], int(toks[i])
+        want_rank = int((lp[i] > lp[i, t]).sum()) + 1
+        top = torch.topk(lp[i], n) if n > 0 else None
+        if n > 0 and t in top.indices.tolist():  # the top-n entry replaces the sampled token's (dict.update)
+            want_rank = top.indices.tolist().index(t) + 1
+        assert d[t][0] == pytest.approx(float(lp[i, t])) and d[t][1] == want_rank, (i, d[t], want_rank)
+        assert len(d) == n + (0 if n > 0 and t in top.indices.tolist() else 1)
+        if n > 0:
+            for r, (tid, val) in enumerate(zip(top.indices.tolist(), top.values.tolist()), start=1):
+                assert d[tid] == (pytest.approx(val), r)
+    assert got[3] == {0: (pytest.approx(float(lp[3, 0])), int((lp[3] > lp[3, 0]).sum()) + 1)}
+    if os.path.isdir("/root/reference/light_vllm"):  # dev container: the reference's own rank function
+        from oracle import ref_block_manager
+        ref_block_manager.load()  # registers the light_vllm namespace + stubs
+        from light_vllm.decoding.backends import sampler as S
+        rows = [i for i, n in enumerate(nums) if n == 0]
+        assert [got[i][int(toks[i])][1] for i in rows] == S._get_ranks(lp[rows], toks[rows]).tolist()
+
+
+def test_sampling_batch_logprobs_are_the_log_softmax_the_draw_uses():
+    """SamplingBatch.logprobs = log_softmax of the logits after the min-tokens mask, the penalties, the temperature
+    and the filters (sampler.py:158-180): greedy rows see temperature 1, filtered tokens are -inf, each row sums to 1."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    V = 64
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(3, V, generator=g) * 3
+    rows = [dict(params=SamplingParams(temperature=0.0, logprobs=2), prompt=[1, 2], output=[3], eos=None),
+            dict(params=SamplingParams(temperature=0.5, top_k=4, logprobs=1), prompt=[5], output=[], eos=None),
+            dict(params=SamplingParams(temperature=1.0, repetition_penalty=1.5, presence_penalty=0.5, logprobs=0),
+                 prompt=[7, 8], output=[9, 9], eos=None)]
+    b = sampling.SamplingBatch(rows, V, "cpu")
+    lp = b.logprobs(logits.clone())
+    assert torch.allclose(lp.exp().sum(-1), torch.ones(3), atol=1e-5)
+    assert torch.allclose(lp[0], torch.log_softmax(logits[0], -1), atol=1e-6)       # greedy, no penalties: raw
+    assert int(torch.isfinite(lp[1]).sum()) == 4                                    # top-k 4
+    kept = torch.topk(logits[1], 4).indices
+    assert torch.allclose(lp[1, kept], torch.log_softmax(logits[1, kept] / 0.5, -1), atol=1e-5)
+    x = logits[2].clone()
+    seen = torch.tensor([7, 8, 9])
+    x[seen] = torch.where(x[seen] > 0, x[seen] / 1.5, x[seen] * 1.5)
+    x[9] -= 0.5
+    assert torch.allclose(lp[2], torch.log_softmax(x, -1), atol=1e-5)
+    with pytest.raises(ValueError, match="logprobs must be non-negative"):
+        SamplingParams(logprobs=-1)
+    with pytest.raises(ValueError, match="prompt_logprobs"):
+        SamplingParams(prompt_logprobs=1)
