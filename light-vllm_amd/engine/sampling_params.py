@@ -1,6 +1,6 @@
 """Sampling parameters of a request: the numeric subset of light_vllm/decoding/backends/sampling_params.py:94-216
 that the sampler's front half reads (penalties, temperature, top-k / top-p / min-p, seed) plus the stop criteria
-the output processor checks (max_tokens, stop_token_ids, ignore_eos).  Same names, defaults and validation
+the output processor checks (max_tokens, stop_token_ids, ignore_eos) and `logprobs` (sample log-probabilities).  Same names, defaults and validation
 messages; text-side fields (stop strings, detokenisation, guided decoding) belong to the tokenizer front end,
 which is out of this path's scope."""
 from dataclasses import dataclass, field
