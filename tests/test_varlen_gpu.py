@@ -119,6 +119,35 @@ def test_rows_read_in_place_equal_the_pack_pass_bit_for_bit(ops, dtype, causal, 
     assert torch.equal(out2[sl].cpu().view(torch.int16), outs[0][sl].view(torch.int16))
 
 
+def test_rows_read_in_place_with_different_key_and_value_strides(ops):
+    """K and V of different buffers, different token strides, V not at the start of its rows: the in-place launch
+    takes each operand's own stride and base (bit-identical to the pack pass, as above)."""
+    H, KVH, D = 8, 8, 64
+    seq_lens = [300, 64, 97]
+    T = sum(seq_lens)
+    g = torch.Generator().manual_seed(21)
+    q = (torch.randn(T, H, D, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    kbuf = (torch.randn(T, 2 * KVH * D + 64, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    vbuf = (torch.randn(T, KVH * D + 8, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    k = kbuf[:, KVH * D:2 * KVH * D].view(T, KVH, D)   # stride 2 KVH D + 64, offset KVH D
+    v = vbuf[:, 8:].view(T, KVH, D)                     # stride KVH D + 8, offset 8 elements (16 bytes)
+    cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32, device=DEV)
+    outs = []
+    for dense in (1, 0):
+        torch.ops._C_amd.set_tuning("varlen_dense", dense)
+        try:
+            out = torch.empty(T, H, D, dtype=torch.bfloat16, device=DEV)
+            ops.varlen_attention(out, q, k, v, cu, max(seq_lens), D ** -0.5, False)
+            torch.cuda.synchronize()
+        finally:
+            torch.ops._C_amd.set_tuning("varlen_dense", 1)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    want = torch.zeros(T, H, D, dtype=torch.bfloat16)
+    oracle.varlen_attention(want, q.cpu(), k.cpu().contiguous(), v.cpu().contiguous(), cu.cpu(), D ** -0.5, False)
+    check_attention(outs[0], want)
+
+
 def test_varlen_long_sequences_properties(ops):
     """bge-m3-like encoder batch (8 x 2048 tokens, 16 heads of 64): sampled rows vs fp64, and the
     encoder output of a sequence does not depend on its neighbours in the batch (bit-exact)."""
