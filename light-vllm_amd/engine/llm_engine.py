@@ -33,6 +33,8 @@ class RequestOutput:
     # SamplingParams.logprobs: per output token {token id: (logprob, rank)} -- the sampled token and the n most
     # likely ones (the reference's SampleLogprobs, sequence.py Logprob(logprob, rank)); None when not asked for
     logprobs: Optional[List[dict]] = None
+    # SamplingParams.prompt_logprobs: [None] + one dictionary per further prompt token computed so far (PromptLogprobs)
+    prompt_logprobs: Optional[List[Optional[dict]]] = None
 
 
 @dataclass
@@ -43,6 +45,7 @@ class ExecuteOutput:
     execute_end_ts: float = 0.0
     num_steps: int = 1  # model steps this result covers (multi-step decode)
     logprobs: Optional[List[Optional[dict]]] = None  # per sampled row (sampling.sample_logprobs), rows that asked
+    prompt_logprobs: Optional[Dict[int, List[dict]]] = None  # {seq id: dictionaries of this step's prompt positions}
 
 
 class Worker:
@@ -262,16 +265,20 @@ class Worker:
         else:
             mi.to(self.device)
             hidden = self.model.forward(mi.input_tokens, mi.input_positions, ce.gpu_cache, md)
+            hidden_all = hidden
             if len(mi.sample_indices) != hidden.shape[0]:
                 hidden = hidden[torch.tensor(mi.sample_indices, dtype=torch.long, device=self.device)]
             logits = self.model.compute_logits(hidden)
             if self.capture_logits:
                 self.last_logits = logits.float().cpu()
+            prompt_lps = None
+            if logprob_rows is not None:
+                prompt_lps = self._prompt_logprobs(hidden_all, logprob_rows)
             lps = None
             if logprob_rows is not None and logits.shape[0] > 0:  # before the draw: the sampler appends what it draws
                 from ..sampling import SamplingBatch
-                rows = [logprob_rows.get(sid) or dict(params=None, prompt=(), output=(), eos=None)
-                        for sid in mi.sample_seq_ids]
+                rows = [logprob_rows.get(sid) if sid in logprob_rows and logprob_rows[sid]["params"].logprobs is not None
+                        else dict(params=None, prompt=(), output=(), eos=None) for sid in mi.sample_seq_ids]
                 lps = SamplingBatch(rows, logits.shape[1], self.device).logprobs(logits)
             if row_slots is None or logits.shape[0] == 0:
                 tokens = torch.argmax(logits, dim=-1)
@@ -283,11 +290,40 @@ class Worker:
                         for sid in mi.sample_seq_ids]
                 out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
                 out.copy_(tokens, non_blocking=True)
-                return ExecuteOutput(out, mi.sample_seq_ids, logprobs=sample_logprobs(lps, tokens, nums))
+                return ExecuteOutput(out, mi.sample_seq_ids, logprobs=sample_logprobs(lps, tokens, nums),
+                                     prompt_logprobs=prompt_lps)
+            if prompt_lps:
+                out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
+                out.copy_(tokens, non_blocking=True)
+                return ExecuteOutput(out, mi.sample_seq_ids, prompt_logprobs=prompt_lps)
         out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
         out.copy_(tokens, non_blocking=True)
         return ExecuteOutput(out, mi.sample_seq_ids)
 
+
+    def _prompt_logprobs(self, hidden_all: torch.Tensor, logprob_rows) -> Optional[Dict[int, List[dict]]]:
+        """The prompt half of get_logprobs (sampler.py:863-915) for the prompt chunks of this step whose requests ask:
+        the logits of the chunk's positions that predict another PROMPT token (all of them, or all but the last when
+        the chunk completes the prompt: that row samples), adjusted by the request's temperature / top-k / top-p / min-p
+        but no penalty (sampling_metadata.py:447-456), log_softmax, then {next prompt token: (logprob, rank)} + the n
+        most likely tokens per position.  `logprob_rows[seq id]["prompt_rows"]` = (first row of the chunk in the step's
+        token batch, number of such positions, their next tokens)."""
+        import dataclasses
+        from ..sampling import SamplingBatch, sample_logprobs
+        out: Dict[int, List[dict]] = {}
+        for sid, r in logprob_rows.items():
+            pr = r.get("prompt_rows")
+            if pr is None or pr[1] == 0:
+                continue
+            start, n, nxt = pr
+            sp = dataclasses.replace(r["params"], presence_penalty=0.0, frequency_penalty=0.0, repetition_penalty=1.0,
+                                     min_tokens=0)
+            logits = self.model.compute_logits(hidden_all[start:start + n])
+            batch = SamplingBatch([dict(params=sp, prompt=(), output=(), eos=None)] * n, logits.shape[1], self.device)
+            lps = batch.logprobs(logits)
+            out[sid] = sample_logprobs(lps, torch.tensor(nxt, dtype=torch.long, device=self.device),
+                                       [r["params"].prompt_logprobs] * n)
+        return out or None
 
     @torch.inference_mode()
     def execute_decode(self, metas, slot: int = 0, num_steps: int = 1, state_slots=None) -> Optional[ExecuteOutput]:
@@ -505,6 +541,14 @@ class LLMEngine:
         sampled = out.sampled.tolist() if out.sampled is not None else []
         tok_of = dict(zip(out.sample_seq_ids, sampled))
         lp_of = dict(zip(out.sample_seq_ids, out.logprobs)) if out.logprobs is not None else None
+        if out.prompt_logprobs:
+            for sid, dicts in out.prompt_logprobs.items():
+                g_ = self.seq_to_group.get(sid)
+                seq_ = next((q for q in g_.seqs if q.seq_id == sid), None) if g_ is not None else None
+                if seq_ is not None:
+                    if not seq_.prompt_logprobs:
+                        seq_.prompt_logprobs.append(None)  # the first prompt token has none (sampler.py:868-870)
+                    seq_.prompt_logprobs.extend(dicts)
         self.stat_model_steps += 1 if sched.scheduled_seq_groups else 0
         self.stat_tokens_appended += len(sampled)
         results: List[RequestOutput] = []
@@ -537,7 +581,8 @@ class LLMEngine:
                 if self.step_returns_outputs:
                     results.append(RequestOutput(g.request_id, list(seq.get_output_token_ids()), finished,
                                                  SequenceStatus.get_finished_reason(seq.status),
-                                                 list(seq.output_logprobs) if seq.output_logprobs else None))
+                                                 list(seq.output_logprobs) if seq.output_logprobs else None,
+                                                 list(seq.prompt_logprobs) if seq.prompt_logprobs else None))
                 else:
                     results.append(RequestOutput(g.request_id, [], finished))
                 continue
@@ -566,7 +611,8 @@ class LLMEngine:
                 seq0 = g.seqs[0]
                 results.append(RequestOutput(g.request_id, list(seq0.get_output_token_ids()), g.is_finished(),
                                              SequenceStatus.get_finished_reason(seq0.status),
-                                             list(seq0.output_logprobs) if seq0.output_logprobs else None))
+                                             list(seq0.output_logprobs) if seq0.output_logprobs else None,
+                                             list(seq0.prompt_logprobs) if seq0.prompt_logprobs else None))
             else:
                 results.append(RequestOutput(g.request_id, [], g.is_finished()))
         for g in sched.ignored_seq_groups:
@@ -627,15 +673,42 @@ class LLMEngine:
         """None unless some request of the step asks for log-probabilities; then, per running sequence of such a
         request, what sampling.SamplingBatch needs to restate its adjusted logits."""
         rows: Dict[int, dict] = {}
+        wanted = False
         for s in sched.scheduled_seq_groups:
-            g = s.seq_group
-            sp = g.sampling_params
-            if sp is None or sp.logprobs is None:
-                continue
-            for seq in g.seqs:
-                if seq.status == SequenceStatus.RUNNING:
-                    rows[seq.seq_id] = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(),
-                                            eos=self.eos_token_id)
+            sp = s.seq_group.sampling_params
+            if sp is not None and (sp.logprobs is not None or sp.prompt_logprobs is not None):
+                wanted = True
+                break
+        if not wanted:
+            return None
+        # the step's token batch is laid out group by group in the order of the metadata list (input_builder.py
+        # prepare_model_input): a prompt chunk contributes its not yet computed tokens (after a prefix-cache hit: the
+        # tokens behind the cached blocks), a decoding sequence one row
+        row = 0
+        bs = self.cache_config.block_size
+        for m in sched.seq_group_metadata_list:
+            g = self.groups.get(m.request_id)
+            sp = g.sampling_params if g is not None else None
+            for sid, data in m.seq_data.items():
+                if not m.is_prompt:
+                    n_rows = 1
+                else:
+                    ctx = data.get_num_computed_tokens()
+                    end = min(data.get_len(), ctx + m.token_chunk_size)
+                    if m.computed_block_nums and self.cache_config.sliding_window is None:
+                        ctx = len(m.computed_block_nums) * bs
+                    n_rows = end - ctx
+                if sp is not None and (sp.logprobs is not None or sp.prompt_logprobs is not None):
+                    seq = next(q for q in g.seqs if q.seq_id == sid)
+                    entry = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(),
+                                 eos=self.eos_token_id)
+                    if m.is_prompt and sp.prompt_logprobs is not None:
+                        toks = data.get_token_ids()
+                        n_lp = n_rows - 1 if (m.do_sample and end >= len(toks)) else n_rows
+                        n_lp = max(0, min(n_lp, len(toks) - 1 - ctx))
+                        entry["prompt_rows"] = (row, n_lp, list(toks[ctx + 1:ctx + 1 + n_lp]))
+                    rows[sid] = entry
+                row += n_rows
         return rows or None
 
     def _sampler_slots(self, sched: SchedulerOutput) -> Optional[Dict[int, int]]:

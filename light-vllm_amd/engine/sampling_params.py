@@ -1,6 +1,6 @@
 """Sampling parameters of a request: the numeric subset of light_vllm/decoding/backends/sampling_params.py:94-216
 that the sampler's front half reads (penalties, temperature, top-k / top-p / min-p, seed) plus the stop criteria
-the output processor checks (max_tokens, stop_token_ids, ignore_eos) and `logprobs` (sample log-probabilities).  Same names, defaults and validation
+the output processor checks (max_tokens, stop_token_ids, ignore_eos) and `logprobs` / `prompt_logprobs` (get_logprobs, sampler.py:726-990).  Same names, defaults and validation
 messages; text-side fields (stop strings, detokenisation, guided decoding) belong to the tokenizer front end,
 which is out of this path's scope."""
 from dataclasses import dataclass, field
@@ -25,7 +25,7 @@ class SamplingParams:
     max_tokens: Optional[int] = 16
     min_tokens: int = 0
     logprobs: Optional[int] = None         # log-probabilities of the sampled token and of the n most likely ones
-    prompt_logprobs: Optional[int] = None  # (accepted for the signature; not computed: ValueError when set)
+    prompt_logprobs: Optional[int] = None  # the same for every prompt token but the first
 
     def __post_init__(self) -> None:  # sampling_params.py:_verify_args
         if not -2.0 <= self.presence_penalty <= 2.0:
@@ -48,8 +48,8 @@ class SamplingParams:
             raise ValueError(f"min_tokens must be greater than or equal to 0, got {self.min_tokens}.")
         if self.logprobs is not None and self.logprobs < 0:
             raise ValueError(f"logprobs must be non-negative, got {self.logprobs}.")
-        if self.prompt_logprobs is not None:
-            raise ValueError("prompt_logprobs is not supported by this engine (sample logprobs are: `logprobs`).")
+        if self.prompt_logprobs is not None and self.prompt_logprobs < 0:
+            raise ValueError(f"prompt_logprobs must be non-negative, got {self.prompt_logprobs}.")
         if self.temperature < _SAMPLING_EPS:  # zero temperature means greedy sampling (sampling_params.py:320-326)
             self.top_p, self.top_k, self.min_p = 1.0, -1, 0.0
 

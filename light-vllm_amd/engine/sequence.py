@@ -124,6 +124,7 @@ class Sequence:
         self.status = SequenceStatus.WAITING
         self.stop_reason = None
         self.output_logprobs: List[dict] = []  # one {token id: (logprob, rank)} per output token when asked for
+        self.prompt_logprobs: List[Optional[dict]] = []  # [None] + one per further prompt token when asked for
 
     @property
     def n_blocks(self) -> int:

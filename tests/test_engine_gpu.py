@@ -842,3 +842,44 @@ def test_requests_that_ask_for_logprobs_get_the_reference_dictionaries(schedulin
                 by_rank = sorted((r, v) for v, r in d.values() if r <= 3)[:3]
                 for (r, v), val in zip(by_rank, top.values.tolist()):
                     assert abs(v - val) <= 1e-4
+
+
+@pytest.mark.parametrize("chunked", [False, True])
+def test_prompt_logprobs_follow_the_prompt_through_its_chunks(chunked):
+    """SamplingParams.prompt_logprobs (sampler.py:863-915): [None] + one {next prompt token: (logprob, rank)} (+ the n
+    most likely tokens) per further prompt token, whole prompts and prompts cut into chunks alike (the position that
+    completes the prompt samples instead); values against log_softmax of a dense fp32 forward of the same weights."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    ps = prompts()
+    e = make_engine(graph=False, chunked=chunked, budget=32 if chunked else 2048)
+    want_lp = {1: 2, 3: 0, 5: 1}
+    for i, p in enumerate(ps):
+        sp = SamplingParams(temperature=0.0, max_tokens=3, prompt_logprobs=want_lp[i], logprobs=1) if i in want_lp else None
+        e.add_request(str(i), p, max_tokens=3, sampling_params=sp)
+    final = {}
+    for _ in range(1000):
+        for o in e.step():
+            final[o.request_id] = o
+        if not e.has_unfinished_requests():
+            break
+    model = e.worker.model
+    for i, p in enumerate(ps):
+        o = final[str(i)]
+        if i not in want_lp:
+            assert o.prompt_logprobs is None
+            continue
+        n = want_lp[i]
+        pl = o.prompt_logprobs
+        assert len(pl) == len(p) and pl[0] is None and all(d is not None for d in pl[1:]), (i, len(pl), len(p))
+        ref = torch.log_softmax(dense_reference_logits(model, p + o.token_ids)[:len(p) - 1].float(), -1).cpu()
+        for pos in range(1, len(p)):
+            d = pl[pos]
+            tok = p[pos]
+            assert tok in d and n <= len(d) <= n + 1
+            lp, rank = d[tok]
+            assert abs(lp - float(ref[pos - 1, tok])) <= 3e-2 + 2e-2 * abs(float(ref[pos - 1, tok])), (i, pos, lp, float(ref[pos - 1, tok]))
+            if n > 0:  # the most likely token of the position as the dense forward sees it (values: ties move ids)
+                best = max(v for v, r in d.values())
+                assert abs(best - float(ref[pos - 1].max())) <= 3e-2 + 2e-2 * abs(float(ref[pos - 1].max()))
+        assert len(o.logprobs) == len(o.token_ids) == 3  # and the sample half beside it
+    e.shutdown()

@@ -196,5 +196,5 @@ def test_sampling_batch_logprobs_are_the_log_softmax_the_draw_uses():
     assert torch.allclose(lp[2], torch.log_softmax(x, -1), atol=1e-5)
     with pytest.raises(ValueError, match="logprobs must be non-negative"):
         SamplingParams(logprobs=-1)
-    with pytest.raises(ValueError, match="prompt_logprobs"):
-        SamplingParams(prompt_logprobs=1)
+    with pytest.raises(ValueError, match="prompt_logprobs must be non-negative"):
+        SamplingParams(prompt_logprobs=-2)
