@@ -187,6 +187,29 @@ class ModelInputBuilder:
                             model_input=self.prepare_model_input(out.seq_group_metadata_list))
 
 
+def token_rows(metas: List[SequenceGroupMetadata], block_size: int, sliding_window: Optional[int]):
+    """Where every sequence of a step sits in the token batch `ModelInputBuilder.prepare_model_input` lays out: a list of
+    (seq id, meta, first row, rows, context length, end) in batch order -- a prompt chunk contributes its not yet computed
+    tokens [context, end) (after a prefix-cache hit: the tokens behind the cached blocks), a decoding sequence one row.
+    Used by the log-probability path to find the rows of a prompt's positions (tests/test_input_builder.py checks it
+    against the builder on every recorded scenario)."""
+    out = []
+    row = 0
+    for m in metas:
+        for sid, data in m.seq_data.items():
+            if not m.is_prompt:
+                ctx, end, n = data.get_len() - 1, data.get_len(), 1
+            else:
+                ctx = data.get_num_computed_tokens()
+                end = min(data.get_len(), ctx + m.token_chunk_size)
+                if m.computed_block_nums and sliding_window is None:
+                    ctx = len(m.computed_block_nums) * block_size
+                n = end - ctx
+            out.append((sid, m, row, n, ctx, end))
+            row += n
+    return out
+
+
 class DecodeStepArrays:
     """The five arrays a captured decode step reads -- token ids, positions, slot mapping, sequence
     lengths, block tables -- as numpy views of ONE staging buffer, filled straight from the scheduler's

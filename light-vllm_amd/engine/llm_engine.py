@@ -681,34 +681,22 @@ class LLMEngine:
                 break
         if not wanted:
             return None
-        # the step's token batch is laid out group by group in the order of the metadata list (input_builder.py
-        # prepare_model_input): a prompt chunk contributes its not yet computed tokens (after a prefix-cache hit: the
-        # tokens behind the cached blocks), a decoding sequence one row
-        row = 0
-        bs = self.cache_config.block_size
-        for m in sched.seq_group_metadata_list:
+        from .input_builder import token_rows
+        for sid, m, row, n_rows, ctx, end in token_rows(sched.seq_group_metadata_list, self.cache_config.block_size,
+                                                        self.cache_config.sliding_window):
             g = self.groups.get(m.request_id)
             sp = g.sampling_params if g is not None else None
-            for sid, data in m.seq_data.items():
-                if not m.is_prompt:
-                    n_rows = 1
-                else:
-                    ctx = data.get_num_computed_tokens()
-                    end = min(data.get_len(), ctx + m.token_chunk_size)
-                    if m.computed_block_nums and self.cache_config.sliding_window is None:
-                        ctx = len(m.computed_block_nums) * bs
-                    n_rows = end - ctx
-                if sp is not None and (sp.logprobs is not None or sp.prompt_logprobs is not None):
-                    seq = next(q for q in g.seqs if q.seq_id == sid)
-                    entry = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(),
-                                 eos=self.eos_token_id)
-                    if m.is_prompt and sp.prompt_logprobs is not None:
-                        toks = data.get_token_ids()
-                        n_lp = n_rows - 1 if (m.do_sample and end >= len(toks)) else n_rows
-                        n_lp = max(0, min(n_lp, len(toks) - 1 - ctx))
-                        entry["prompt_rows"] = (row, n_lp, list(toks[ctx + 1:ctx + 1 + n_lp]))
-                    rows[sid] = entry
-                row += n_rows
+            if sp is None or (sp.logprobs is None and sp.prompt_logprobs is None):
+                continue
+            seq = next(q for q in g.seqs if q.seq_id == sid)
+            entry = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(), eos=self.eos_token_id)
+            if m.is_prompt and sp.prompt_logprobs is not None:
+                toks = m.seq_data[sid].get_token_ids()
+                # positions ctx .. end - 1 predict tokens ctx + 1 .. end; the one that completes the prompt samples
+                n_lp = n_rows - 1 if (m.do_sample and end >= len(toks)) else n_rows
+                n_lp = max(0, min(n_lp, len(toks) - 1 - ctx))
+                entry["prompt_rows"] = (row, n_lp, list(toks[ctx + 1:ctx + 1 + n_lp]))
+            rows[sid] = entry
         return rows or None
 
     def _sampler_slots(self, sched: SchedulerOutput) -> Optional[Dict[int, int]]:

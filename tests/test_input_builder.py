@@ -292,3 +292,25 @@ def test_rocm_platform_has_the_reference_platform_interface(ref_ns):
     finally:
         P.current_platform = before
         gpu_worker.current_platform = before
+
+
+@pytest.mark.parametrize("sc", SCENARIOS, ids=[s["name"] for s in SCENARIOS])
+def test_token_rows_name_the_rows_the_builder_lays_out(sc):
+    """`token_rows` (the log-probability path's map from a sequence to its rows of the step's token batch) against the
+    builder itself on every recorded scenario: rows are consecutive, cover the batch, and hold the sequence's tokens
+    [context, end) -- chunks, prefix-cache hits and decode rows alike."""
+    from light_vllm_amd.engine.input_builder import token_rows
+    metas = our_metas(sc)
+    b = our_builder(sc, prompt_block_tables=False)
+    mi = b.prepare_model_input(metas)
+    rows = token_rows(metas, b.block_size, sc["sliding_window"])
+    toks = mi.input_tokens.tolist() if mi.input_tokens is not None else []
+    pos = mi.input_positions.tolist() if mi.input_positions is not None else []
+    at = 0
+    for sid, m, row, n, ctx, end in rows:
+        assert row == at and n == end - ctx
+        data = m.seq_data[sid]
+        assert toks[row:row + n] == list(data.get_token_ids()[ctx:end])
+        assert pos[row:row + n] == list(range(ctx, end))
+        at += n
+    assert at == len(toks)
