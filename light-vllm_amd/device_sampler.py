@@ -66,7 +66,7 @@ class DeviceSampler:
         self._seeds.pop(seq_id, None)
 
     def ensure(self, seq_id: int, sp, prompt_ids: Sequence[int], output_ids: Sequence[int], eos: Optional[int],
-               pinned=()) -> int:
+               pinned=(), salt: int = 0) -> int:
         """The slot of `seq_id`, built on the CURRENT stream from the request's histories when it has none (new
         request, or evicted while it waited).  `pinned`: sequence ids whose slots must stay (steps in flight, the step
         being built), or a callable returning them -- asked only when a slot has to be evicted."""
@@ -79,6 +79,8 @@ class DeviceSampler:
         seed = self._seeds.get(seq_id)
         if seed is None:
             seed = sp.seed if sp.seed is not None else self._rng.getrandbits(64)
+            if salt:  # the further sequences of a request that forks (SamplingParams.n): streams of their own
+                seed = (seed * 0x9E3779B97F4A7C15 + salt * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
             self._seeds[seq_id] = seed
         rec = pack_params(sp, self.vocab_size, len(output_ids), seed, eos)
         pin = self.device.type == "cuda"

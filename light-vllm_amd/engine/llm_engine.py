@@ -35,6 +35,9 @@ class RequestOutput:
     logprobs: Optional[List[dict]] = None
     # SamplingParams.prompt_logprobs: [None] + one dictionary per further prompt token computed so far (PromptLogprobs)
     prompt_logprobs: Optional[List[Optional[dict]]] = None
+    # SamplingParams.n > 1: the n sequences of the request (of its best_of, by cumulative log-probability), token ids
+    # each; `token_ids` is the first of them
+    outputs: Optional[List[List[int]]] = None
 
 
 @dataclass
@@ -46,6 +49,9 @@ class ExecuteOutput:
     num_steps: int = 1  # model steps this result covers (multi-step decode)
     logprobs: Optional[List[Optional[dict]]] = None  # per sampled row (sampling.sample_logprobs), rows that asked
     prompt_logprobs: Optional[Dict[int, List[dict]]] = None  # {seq id: dictionaries of this step's prompt positions}
+    # {parent seq id: [(token, logprob dictionary or None, logprob), ...]}: the further samples of a prompt whose
+    # request asks for several sequences (SamplingParams.n / best_of)
+    extra_samples: Optional[Dict[int, list]] = None
 
 
 class Worker:
@@ -277,7 +283,7 @@ class Worker:
             lps = None
             if logprob_rows is not None and logits.shape[0] > 0:  # before the draw: the sampler appends what it draws
                 from ..sampling import SamplingBatch
-                rows = [logprob_rows.get(sid) if sid in logprob_rows and logprob_rows[sid]["params"].logprobs is not None
+                rows = [logprob_rows[sid] if sid in logprob_rows and logprob_rows[sid].get("num") is not None
                         else dict(params=None, prompt=(), output=(), eos=None) for sid in mi.sample_seq_ids]
                 lps = SamplingBatch(rows, logits.shape[1], self.device).logprobs(logits)
             if row_slots is None or logits.shape[0] == 0:
@@ -285,13 +291,26 @@ class Worker:
             else:
                 tokens = self.sampler.sample(logits, self._slots_tensor(row_slots))
             if lps is not None:
-                from ..sampling import sample_logprobs
-                nums = [logprob_rows[sid]["params"].logprobs if sid in logprob_rows else None
-                        for sid in mi.sample_seq_ids]
+                from ..sampling import random_sample, sample_logprobs
+                nums = [logprob_rows[sid].get("num") if sid in logprob_rows else None for sid in mi.sample_seq_ids]
+                extra = None
+                for r, sid in enumerate(mi.sample_seq_ids):  # the further samples of a prompt that forks (n / best_of)
+                    k = logprob_rows[sid].get("extra", 0) if sid in logprob_rows else 0
+                    if k > 0:
+                        gen = None
+                        seed = logprob_rows[sid]["params"].seed
+                        if seed is not None:
+                            gen = torch.Generator(device=self.device).manual_seed(
+                                (seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (1 << 63))
+                        rep_lps = lps[r:r + 1].expand(k, -1)
+                        toks = random_sample(rep_lps.exp(), gen)
+                        dicts = sample_logprobs(rep_lps, toks, [nums[r]] * k)
+                        extra = extra or {}
+                        extra[sid] = list(zip(toks.tolist(), dicts))
                 out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
                 out.copy_(tokens, non_blocking=True)
                 return ExecuteOutput(out, mi.sample_seq_ids, logprobs=sample_logprobs(lps, tokens, nums),
-                                     prompt_logprobs=prompt_lps)
+                                     prompt_logprobs=prompt_lps, extra_samples=extra)
             if prompt_lps:
                 out = torch.empty(tokens.shape, dtype=tokens.dtype, pin_memory=True)
                 out.copy_(tokens, non_blocking=True)
@@ -476,7 +495,8 @@ class LLMEngine:
         self.seq_counter += 1
         if sampling_params is not None:
             max_tokens = sampling_params.max_tokens
-        g = SequenceGroup(request_id, [seq], time.time(), max_tokens=max_tokens, sampling_params=sampling_params)
+        g = SequenceGroup(request_id, [seq], time.time(), max_tokens=max_tokens, sampling_params=sampling_params,
+                          n=sampling_params.num_samples if sampling_params is not None else 1)
         self.groups[request_id] = g
         self.seq_to_group[seq.seq_id] = g
         self.scheduler.add_request(g)
@@ -556,7 +576,7 @@ class LLMEngine:
         for s in sched.scheduled_seq_groups:
             g = s.seq_group
             seqs = g.seqs
-            if len(seqs) == 1 and seqs[0].status == SequenceStatus.RUNNING and seqs[0].seq_id in tok_of:
+            if len(seqs) == 1 and g.n <= 1 and seqs[0].status == SequenceStatus.RUNNING and seqs[0].seq_id in tok_of:
                 # one running sequence that sampled a token: the loop below, without its lists
                 seq = seqs[0]
                 seq.data.update_num_computed_tokens(s.token_chunk_size)
@@ -587,17 +607,16 @@ class LLMEngine:
                     results.append(RequestOutput(g.request_id, [], finished))
                 continue
             g.update_num_computed_tokens(s.token_chunk_size)
-            for seq in g.get_seqs(status=SequenceStatus.RUNNING):
-                if seq.seq_id not in tok_of:
-                    continue  # a prompt chunk that sampled nothing
-                tok = tok_of[seq.seq_id]
-                lp = lp_of.get(seq.seq_id) if lp_of is not None else None
+            sp = g.sampling_params
+            show_lp = sp is not None and sp.logprobs is not None
+
+            def take(seq, tok, lp):  # one sampled token of one sequence: the dictionary, the token, the stop checks
                 if lp is not None:
-                    seq.output_logprobs.append(lp)
+                    if show_lp:
+                        seq.output_logprobs.append(lp)
                     seq.append_token_id(tok, lp[tok][0])
                 else:
                     seq.append_token_id(tok, 0.0)
-                sp = g.sampling_params
                 if ((self.eos_token_id is not None and tok == self.eos_token_id and not (sp is not None and sp.ignore_eos))
                         or (sp is not None and tok in sp.stop_token_ids)):
                     seq.status = SequenceStatus.FINISHED_STOPPED
@@ -607,12 +626,35 @@ class LLMEngine:
                     seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
                 if seq.is_finished():
                     self.scheduler.free_seq(seq)
+
+            for seq in list(g.get_seqs(status=SequenceStatus.RUNNING)):
+                if seq.seq_id not in tok_of:
+                    continue  # a prompt chunk that sampled nothing
+                extra = out.extra_samples.get(seq.seq_id) if out.extra_samples else None
+                if extra:
+                    # SamplingParams.n / best_of: the prompt's last position drew for every sequence of the request
+                    # (sampler.py:385-432); the further ones fork from the parent BEFORE it takes its own token
+                    # (output_processor.py:84-92: scheduler.fork_seq shares the prompt's blocks copy-on-write)
+                    for tok_x, lp_x in extra:
+                        child = seq.fork(self.seq_counter)
+                        self.seq_counter += 1
+                        g.seqs.append(child)
+                        g.seqs_dict[child.seq_id] = child
+                        self.seq_to_group[child.seq_id] = g
+                        self.scheduler.fork_seq(seq, child)
+                        take(child, tok_x, lp_x)
+                        self.stat_tokens_appended += 1
+                take(seq, tok_of[seq.seq_id], lp_of.get(seq.seq_id) if lp_of is not None else None)
             if self.step_returns_outputs:
-                seq0 = g.seqs[0]
+                ranked = g.seqs
+                if g.n > 1 and sp is not None:  # the n most likely of the request's sequences (cumulative log-probability)
+                    ranked = sorted(g.seqs, key=lambda q: q.data.cumulative_logprob, reverse=True)[:sp.n]
+                seq0 = ranked[0]
                 results.append(RequestOutput(g.request_id, list(seq0.get_output_token_ids()), g.is_finished(),
                                              SequenceStatus.get_finished_reason(seq0.status),
                                              list(seq0.output_logprobs) if seq0.output_logprobs else None,
-                                             list(seq0.prompt_logprobs) if seq0.prompt_logprobs else None))
+                                             list(seq0.prompt_logprobs) if seq0.prompt_logprobs else None,
+                                             [list(q.get_output_token_ids()) for q in ranked] if g.n > 1 else None))
             else:
                 results.append(RequestOutput(g.request_id, [], g.is_finished()))
         for g in sched.ignored_seq_groups:
@@ -676,7 +718,7 @@ class LLMEngine:
         wanted = False
         for s in sched.scheduled_seq_groups:
             sp = s.seq_group.sampling_params
-            if sp is not None and (sp.logprobs is not None or sp.prompt_logprobs is not None):
+            if sp is not None and (sp.logprobs is not None or sp.prompt_logprobs is not None or sp.num_samples > 1):
                 wanted = True
                 break
         if not wanted:
@@ -686,10 +728,15 @@ class LLMEngine:
                                                         self.cache_config.sliding_window):
             g = self.groups.get(m.request_id)
             sp = g.sampling_params if g is not None else None
-            if sp is None or (sp.logprobs is None and sp.prompt_logprobs is None):
+            if sp is None or (sp.logprobs is None and sp.prompt_logprobs is None and sp.num_samples <= 1):
                 continue
             seq = next(q for q in g.seqs if q.seq_id == sid)
             entry = dict(params=sp, prompt=seq.prompt_token_ids, output=seq.get_output_token_ids(), eos=self.eos_token_id)
+            # what the sampled token's dictionary holds: the request's n; 0 (the token alone) for a request that
+            # forks, whose sequences are ranked by cumulative log-probability at the end; None: nothing
+            entry["num"] = sp.logprobs if sp.logprobs is not None else (0 if sp.num_samples > 1 else None)
+            if m.is_prompt and m.do_sample and sp.num_samples > len(g.seqs):
+                entry["extra"] = sp.num_samples - len(g.seqs)  # the prompt's last position draws for every sequence
             if m.is_prompt and sp.prompt_logprobs is not None:
                 toks = m.seq_data[sid].get_token_ids()
                 # positions ctx .. end - 1 predict tokens ctx + 1 .. end; the one that completes the prompt samples
@@ -719,10 +766,11 @@ class LLMEngine:
             return keep
         out: Dict[int, int] = {}
         for g in groups:
-            for seq in g.seqs:
+            for k, seq in enumerate(g.seqs):
                 if seq.status == SequenceStatus.RUNNING:
                     out[seq.seq_id] = self.device_sampler.ensure(seq.seq_id, g.sampling_params, seq.prompt_token_ids,
-                                                                 seq.get_output_token_ids(), self.eos_token_id, pinned)
+                                                                 seq.get_output_token_ids(), self.eos_token_id, pinned,
+                                                                 salt=k)
         return out or None
 
     def _burst_steps(self, sched: SchedulerOutput) -> int:

@@ -11,7 +11,8 @@ _SAMPLING_EPS = 1e-5  # sampling_params.py:17
 
 @dataclass
 class SamplingParams:
-    n: int = 1
+    n: int = 1                      # sequences returned per prompt
+    best_of: Optional[int] = None   # sequences generated per prompt (>= n; the n most likely are returned); None = n
     presence_penalty: float = 0.0
     frequency_penalty: float = 0.0
     repetition_penalty: float = 1.0
@@ -28,6 +29,10 @@ class SamplingParams:
     prompt_logprobs: Optional[int] = None  # the same for every prompt token but the first
 
     def __post_init__(self) -> None:  # sampling_params.py:_verify_args
+        if self.n < 1:
+            raise ValueError(f"n must be at least 1, got {self.n}.")
+        if self.best_of is not None and self.best_of < self.n:
+            raise ValueError(f"best_of must be greater than or equal to n, got n={self.n} and best_of={self.best_of}.")
         if not -2.0 <= self.presence_penalty <= 2.0:
             raise ValueError(f"presence_penalty must be in [-2, 2], got {self.presence_penalty}.")
         if not -2.0 <= self.frequency_penalty <= 2.0:
@@ -52,6 +57,13 @@ class SamplingParams:
             raise ValueError(f"prompt_logprobs must be non-negative, got {self.prompt_logprobs}.")
         if self.temperature < _SAMPLING_EPS:  # zero temperature means greedy sampling (sampling_params.py:320-326)
             self.top_p, self.top_k, self.min_p = 1.0, -1, 0.0
+            if self.num_samples > 1:  # sampling_params.py:_verify_greedy_sampling
+                raise ValueError(f"best_of must be 1 when using greedy sampling, got {self.num_samples}.")
+
+    @property
+    def num_samples(self) -> int:
+        """Sequences forked from the prompt (the reference folds best_of into n, sampling_params.py:285-297)."""
+        return self.best_of if self.best_of is not None else self.n
 
     @property
     def greedy(self) -> bool:

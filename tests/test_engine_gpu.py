@@ -883,3 +883,57 @@ def test_prompt_logprobs_follow_the_prompt_through_its_chunks(chunked):
                 assert abs(best - float(ref[pos - 1].max())) <= 3e-2 + 2e-2 * abs(float(ref[pos - 1].max()))
         assert len(o.logprobs) == len(o.token_ids) == 3  # and the sample half beside it
     e.shutdown()
+
+
+@pytest.mark.parametrize("scheduling", ["sync", "async"])
+def test_requests_that_ask_for_several_sequences_fork_after_the_prompt(scheduling):
+    """SamplingParams.n / best_of (sampler.py:385-432, output_processor.py:84-92): the prompt's last position draws for
+    every sequence of the request, the further ones fork from the parent (blocks shared copy-on-write) and decode as
+    rows of their own.  With top_k = 1 every draw is the arg-max, so all n sequences must equal the greedy continuation
+    token for token -- any block shared wrongly after the fork would show; a seeded request returns its n most likely
+    of best_of sequences, ranked by cumulative log-probability, the same sync and with two steps in flight; the plain
+    requests beside them keep their tokens."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    ps = prompts()
+    greedy = run_to_completion(make_engine(graph=True), max_tokens=10)
+
+    def run(use_async):
+        e = make_engine(graph=True, scheduling="async" if use_async else "sync", max_seqs=12)
+        params = [None, SamplingParams(temperature=1.0, top_k=1, n=3, max_tokens=10), None,
+                  SamplingParams(temperature=0.9, top_k=8, seed=3, n=2, best_of=4, max_tokens=10, logprobs=0), None, None]
+        for i, (p, sp) in enumerate(zip(ps, params)):
+            e.add_request(str(i), p, max_tokens=10, sampling_params=sp)
+        final = {}
+        step = e.async_step if use_async else e.step
+        for _ in range(2000):
+            for o in step():
+                if o.finished:
+                    final[o.request_id] = o
+            if not e.has_unfinished_requests() and e.num_on_the_fly == 0:
+                break
+        free = e.scheduler.block_manager.get_num_free_gpu_blocks()
+        final["model"] = e.worker.model
+        e.shutdown()
+        return final, free
+
+    got, free = run(scheduling == "async")
+    assert free == 256  # every block of every fork came back
+    for i in (0, 2, 4, 5):
+        assert got[str(i)].token_ids == greedy[i] and got[str(i)].outputs is None
+    o1 = got["1"]
+    assert len(o1.outputs) == 3
+    # top_k = 1: every token of every sequence is an arg-max of ITS OWN history (the tiny model's bf16 logits tie now and
+    # then, and a tie may go either way per sequence): checked against a dense fp32 forward of prompt + that sequence
+    model = got["model"]
+    for toks in o1.outputs:
+        assert len(toks) == 10
+        ref = dense_reference_logits(model, ps[1] + toks).cpu()
+        for j, t in enumerate(toks):
+            row = ref[len(ps[1]) - 1 + j]
+            assert float(row[t]) >= float(row.max()) - (2e-2 * float(row.abs().max()) + 1e-3), (j, t, int(row.argmax()))
+    o3 = got["3"]
+    assert len(o3.outputs) == 2 and o3.token_ids == o3.outputs[0] and all(len(t) == 10 for t in o3.outputs)
+    assert len(o3.logprobs) == 10 and all(tok in d for tok, d in zip(o3.token_ids, o3.logprobs))
+    if scheduling == "sync":
+        again, _ = run(False)
+        assert again["3"].outputs == o3.outputs  # seeded: repeatable

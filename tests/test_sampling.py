@@ -198,3 +198,17 @@ def test_sampling_batch_logprobs_are_the_log_softmax_the_draw_uses():
         SamplingParams(logprobs=-1)
     with pytest.raises(ValueError, match="prompt_logprobs must be non-negative"):
         SamplingParams(prompt_logprobs=-2)
+
+
+def test_sampling_params_n_and_best_of():
+    """sampling_params.py:285-297, _verify_greedy_sampling: best_of >= n, several sequences need a temperature."""
+    from light_vllm_amd.engine.sampling_params import SamplingParams
+    assert SamplingParams().num_samples == 1
+    assert SamplingParams(n=3, temperature=0.7).num_samples == 3
+    assert SamplingParams(n=2, best_of=5, temperature=0.7).num_samples == 5
+    with pytest.raises(ValueError, match="best_of must be greater than or equal to n"):
+        SamplingParams(n=3, best_of=2, temperature=0.7)
+    with pytest.raises(ValueError, match="best_of must be 1 when using greedy sampling"):
+        SamplingParams(n=2, temperature=0.0)
+    with pytest.raises(ValueError, match="n must be at least 1"):
+        SamplingParams(n=0)
