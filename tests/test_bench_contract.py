@@ -139,7 +139,8 @@ def test_bench_runs_end_to_end_on_a_tiny_model(extra):
         assert f8["roofline_attention"]["bound"] == "hbm" and f8["roofline_attention"]["avg_launch_us"] > 0
         assert set(f8["roofline_projections"]["per_shape"]) == {"qkv", "o", "gate_up", "down"}
         m = o["config4_encode_only"]["mfma"]
-        assert m["peak"] == 2500.0 and m["unit"] == "TFLOP/s" and 0 < m["frac"] < 1
+        # (the tiny model's FLOPs are a few 1e-5 of the peak: the fraction may round to 0.0000)
+        assert m["peak"] == 2500.0 and m["unit"] == "TFLOP/s" and 0 <= m["frac"] < 1
         sd = o["sampled_decode"]  # the headline workload with sampled requests (the device-side sampler in the step)
         assert sd["value"] > 0 and sd["unit"] == "tokens/s" and sd["ms_per_step"] > 0 and "top-p" in sd["config"]
     else:
